@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""bench.py — forward images/sec of the BASELINE.json workload on N MI355X GPUs of one node.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload resnet50|vit_b16]
+
+Workload (config.workload): BASELINE.json configs[1] — ResNet-50 fp16 forward, batch 256 per GPU,
+synthetic ImageNet-shaped input already resident in HBM, seeded random weights of the real
+architecture.  A "step" is one forward of one batch on every rank followed, for N>1, by the RCCL
+all-gather of the (256, 1000) logits (the only exchange); scaling is weak.
+Prints ONE JSON line (rank 0).  Extra objects on the same line:
+  roofline      the implicit-GEMM kernel family (every conv + the classifier GEMM): algorithmic
+                bytes per launch / mean launch duration, timed with HIP events on the launch stream
+                in an instrumented pass right after the timed region; bound = HBM.
+  cpu_baseline  the CPU oracle (oracle/functional.py, torch fp32 on all host cores) on a bounded
+                sample — the stand-in for "TensorLayerX torch-CPU backend", which cannot be installed.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+MFMA_F16_PEAK_TF = 2500.0  # dense fp16 MFMA
+
+
+def build_model(workload, dev):
+    from tlxcv_amd import models, seeded
+    ctor = {"resnet50": "resnet50", "vit_b16": "vit_base_patch16_224"}[workload]
+    m = getattr(models, ctor)()
+    params = seeded.fill(seeded.shapes_of(m), 1)
+    m.load_dict(params)
+    return m.to(dev).set_eval(), params
+
+
+def cpu_baseline(workload, params, batch=32, warm=1, iters=4):
+    """Oracle restatement timed on the host cores (rank 0, N=1 only)."""
+    from oracle import functional as OF
+    from tlxcv_amd import seeded
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    p = {k: torch.from_numpy(v) for k, v in params.items()}
+    x = torch.from_numpy(seeded.image_batch(batch, 0))
+    fn = {"resnet50": lambda: OF.resnet(p, x, 50), "vit_b16": lambda: OF.vit(p, x, "vit_base_patch16_224")}[workload]
+    with torch.no_grad():
+        for _ in range(warm):
+            fn()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        dt = time.perf_counter() - t0
+    return {"value": round(batch * iters / dt, 2), "unit": "images/sec", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": f"{iters} forwards of batch {batch}, fp32, oracle/functional.py on torch-CPU "
+            f"({dt:.1f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU")
+    ap.add_argument("--workload", default="resnet50", choices=["resnet50", "vit_b16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import tlxcv_amd
+    from tlxcv_amd import dist as D, engine as E, seeded
+    import torch.distributed as dist
+
+    rank, world, local = D.init()
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    tlxcv_amd.set_precision("fp16")
+
+    model, params = build_model(a.workload, dev)
+    x = torch.from_numpy(seeded.image_batch(min(a.batch, 32), rank)).to(dev)
+    x = x.repeat((a.batch + x.shape[0] - 1) // x.shape[0], 1, 1, 1)[: a.batch].contiguous()   # resident in HBM
+
+    def step():
+        y = model(x)
+        return D.all_gather_logits(y) if world > 1 else y
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        y = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        y = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(y.float()).all(), "non-finite logits"
+    total_images = a.batch * world * a.steps
+    value = total_images / dt
+
+    line = {
+        "metric": "images/sec fwd", "value": round(value, 1), "unit": "images/sec", "n_gpus": world,
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+        "config": {"workload": {"resnet50": "ResNet-50 fp16 forward, 224x224, batch 256 per GPU (BASELINE configs[1])",
+                                "vit_b16": "ViT-B/16 fp16 forward, 224x224, batch 256 per GPU (BASELINE configs[2])"}[a.workload],
+                   "global_batch": a.batch * world, "per_gpu_batch": a.batch, "weights": "seeded random (tlxcv_amd.seeded, seed 1)",
+                   "parallelism": f"batch-sharded x{world}, all-gather logits" if world > 1 else "single GPU"},
+    }
+
+    if rank == 0:
+        # ---- roofline of the implicit-GEMM kernel family: instrumented pass, HIP events per launch
+        probe = []
+        E.set_probe(probe)
+        nprobe = min(a.steps, 5)
+        for _ in range(nprobe):
+            model(x)
+        torch.cuda.synchronize()
+        E.set_probe(None)
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in probe)
+        nl = len(probe)
+        alg_bytes = sum(b for _, _, b, _ in probe)
+        flops = sum(f for _, _, _, f in probe)
+        per_launch_us = 1e3 * ms / nl
+        achieved = alg_bytes / (ms * 1e-3) / 1e9
+        line["roofline"] = {
+            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "kernel": "conv_igemm_kernel (all instantiations: 53 convs + classifier per forward)",
+            "launches_per_step": nl // nprobe, "avg_launch_us": round(per_launch_us, 2),
+            "alg_bytes_per_launch": int(alg_bytes / nl), "mfma_tflops": round(flops / (ms * 1e-3) / 1e12, 1),
+            "mfma_frac": round(flops / (ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TF, 4),
+            "gemm_ms_per_step": round(ms / nprobe, 3),
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(a.workload, params)
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,218 @@
+/*
+ * tlxmi.h — C-ABI of libtlxmi.so, the MI355X (gfx950) forward-pass engine that sits under the
+ * TensorLayerX-compatible layer surface of tlxcv_amd.
+ *
+ * The reference (tensorlayer/TLXCV) has NO native interface: every op on the hot path is a
+ * `tlx.nn.*` layer call that TensorLayerX forwards to a backend library.  Each entry point below
+ * therefore names the reference *call site* it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - plain C, POD descriptors, raw device pointers, sizes in elements unless stated otherwise;
+ *   - the caller owns every buffer; nothing is retained after the call returns;
+ *   - every launch is asynchronous on the `stream` argument (a hipStream_t passed as void*);
+ *   - no allocation, no synchronisation inside a call (hipGraph-capturable);
+ *   - returns TLXMI_OK (0) or a negative tlxmi_status; tlxmi_last_error() gives a thread-local
+ *     message.  Nothing throws across this boundary.
+ *   - activations are NHWC ("pixel-major"): element (n,h,w,c) of a tensor with pixel stride `ld`
+ *     lives at ((n*H + h)*W + w)*ld + c.  A token matrix [rows][features] is the H=W=1 case.
+ *   - dtype: TLXMI_F16 = IEEE binary16 storage, fp32 accumulate; TLXMI_F32 = fp32 storage, exact
+ *     fp32 MFMA/FMA accumulate (the parity mode: 1e-4 vs the CPU oracle).
+ */
+#ifndef TLXMI_H
+#define TLXMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TLXMI_VERSION 100
+
+typedef enum tlxmi_status {
+    TLXMI_OK = 0,
+    TLXMI_ERR_BAD_ARG = -1,      /* null pointer, non-positive extent, inconsistent descriptor */
+    TLXMI_ERR_UNSUPPORTED = -2,  /* legal request this build has no kernel for */
+    TLXMI_ERR_ALIGNMENT = -3,    /* pointer / stride does not meet the documented alignment */
+    TLXMI_ERR_LAUNCH = -4,       /* HIP reported an error at launch */
+    TLXMI_ERR_NO_DEVICE = -5     /* no gfx950 device visible */
+} tlxmi_status;
+
+typedef enum tlxmi_dtype { TLXMI_F16 = 0, TLXMI_F32 = 1 } tlxmi_dtype;
+
+/* Activations fused into epilogues.  Reference layers: nn.ReLU (resnet.py:50), nn.ReLU6
+ * (mobilenetv2.py), nn.LeakyReLU(0.1) (darknet.py:50), nn.Hardswish / nn.HardSigmoid
+ * (mobilenetv3.py), tlx.ops.GeLU exact-erf (vision_transformer.py:70), nn.Sigmoid, swish. */
+typedef enum tlxmi_act {
+    TLXMI_ACT_NONE = 0,
+    TLXMI_ACT_RELU = 1,
+    TLXMI_ACT_RELU6 = 2,
+    TLXMI_ACT_LEAKY = 3,       /* x>=0 ? x : act_param*x */
+    TLXMI_ACT_HARDSWISH = 4,   /* x*relu6(x+3)/6 */
+    TLXMI_ACT_HARDSIGMOID = 5, /* relu6(x+3)/6 */
+    TLXMI_ACT_GELU = 6,        /* 0.5x(1+erf(x/sqrt2)) */
+    TLXMI_ACT_SIGMOID = 7,
+    TLXMI_ACT_SILU = 8
+} tlxmi_act;
+
+/* epilogue flag bits */
+#define TLXMI_EPI_RES_AFTER_ACT 1u /* y = act(a*scale+shift) + res   (darknet.py:155-159)      */
+                                   /* default: y = act(a*scale+shift+res) (resnet.py:154-155)  */
+#define TLXMI_EPI_RES_BCAST_N 2u   /* res has no batch axis (pos_embed, vision_transformer.py:323) */
+
+/* ------------------------------------------------------------------------------------------
+ * Library / device
+ * ---------------------------------------------------------------------------------------- */
+int tlxmi_version(void);
+const char* tlxmi_last_error(void);
+/* Number of visible HIP devices whose gcnArchName starts with "gfx950"; <0 on HIP error. */
+int tlxmi_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Layout conversion at the model boundary.
+ * Replaces the implicit NCHW handling of tlx.nn.GroupConv2d(data_format='channels_first')
+ * (resnet.py:199-207, vision_transformer.py:197-204): the engine is NHWC inside.
+ *   src: [N][C][H][W] contiguous, src_dtype;  dst: [N][H][W][Cpad] dst_dtype, channels C..Cpad-1 = 0.
+ * ---------------------------------------------------------------------------------------- */
+int tlxmi_nchw_to_nhwc(const void* src, int src_dtype, void* dst, int dst_dtype, int N, int C, int H,
+                       int W, int Cpad, void* stream);
+/* dst: [N][C][H][W] contiguous; src: NHWC with pixel stride ld (>= C). */
+int tlxmi_nhwc_to_nchw(const void* src, int src_dtype, int ld, void* dst, int dst_dtype, int N, int C,
+                       int H, int W, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Filter packing (once, at set_eval()).
+ *   src: OIHW fp32 [Cout][Cin/groups][R][S] (the layout TensorLayerX's torch backend keeps)
+ *   dst: [Cout_pad][Kpad] dtype, K index = (r*S + s)*Cin_pad + c, zero padded;
+ *        Cin_pad*sizeof(dtype) % 16 == 0, Cout_pad % 128 == 0, Kpad*sizeof(dtype) % 64 == 0.
+ * ---------------------------------------------------------------------------------------- */
+size_t tlxmi_packed_filter_bytes(int Cout, int Cin, int R, int S, int dtype);
+int tlxmi_pack_filter(const float* src_oihw, void* dst, int Cout, int Cin, int R, int S, int dtype,
+                      void* stream);
+
+/* Fold eval-mode BatchNorm into per-channel (scale, shift):
+ *   scale = gamma / sqrt(var + eps);  shift = beta - mean*scale + conv_bias*scale
+ * Reference: nn.BatchNorm2d after every GroupConv2d (resnet.py:107,122,134; darknet.py:48;
+ * mobilenetv1.py:61).  Any of gamma/beta/mean/var/conv_bias may be NULL (1/0/0/1/0). */
+int tlxmi_fold_bn(const float* gamma, const float* beta, const float* mean, const float* var,
+                  const float* conv_bias, float eps, int C, float* scale, float* shift, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Conv2d as implicit GEMM, groups == 1.
+ * Replaces nn.GroupConv2d(+BatchNorm2d +activation +residual add): resnet.py:142-156,
+ * vision_transformer.py:197-220 (patch embed), darknet.py:54-58, yolov3.py:313-322;
+ * with R=S=1,H=W=1 it is also nn.Linear (+bias +GELU +residual): vision_transformer.py:81-87,
+ * 112-123, resnet.py:234-237.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct tlxmi_conv2d_desc {
+    int32_t dtype;           /* tlxmi_dtype of x, w, y, res */
+    int32_t N, H, W, C;      /* input extent; C = padded input channels (C*elt % 16 == 0) */
+    int32_t Cout;            /* true output channels */
+    int32_t R, S;            /* filter height, width */
+    int32_t stride_h, stride_w, pad_h, pad_w, dil_h, dil_w;
+    int32_t Ho, Wo;          /* output extent (caller computed; checked) */
+    int32_t x_ld, y_ld, res_ld; /* pixel strides in elements (x_ld >= C, y_ld >= Cout) */
+    int32_t y_nstride;       /* elements between images of y; 0 = dense (Ho*Wo*y_ld).  Lets the   */
+    int32_t res_nstride;     /* patch-embed conv write rows 1.. of a [B][1+P][D] token matrix     */
+                             /* (vision_transformer.py:321-323).  res: 0 = dense, or see BCAST.   */
+    int32_t act;             /* tlxmi_act */
+    float act_param;         /* LEAKY slope */
+    uint32_t flags;          /* TLXMI_EPI_* */
+} tlxmi_conv2d_desc;
+
+int tlxmi_conv2d(const tlxmi_conv2d_desc* d, const void* x, const void* w_packed,
+                 const float* scale /* [Cout] or NULL=1 */, const float* shift /* [Cout] or NULL=0 */,
+                 const void* res /* or NULL */, void* y, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Depthwise conv (groups == C == Cout), HBM-bound, no MFMA.
+ * Replaces nn.GroupConv2d(n_group=C)+BN+act: mobilenetv1.py:79-88, mobilenetv2.py:30,
+ * mobilenetv3.py (k3/k5).   w: [R][S][C] dtype.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct tlxmi_dwconv2d_desc {
+    int32_t dtype;
+    int32_t N, H, W, C;
+    int32_t R, S, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w;
+    int32_t Ho, Wo;
+    int32_t x_ld, y_ld;
+    int32_t act;
+    float act_param;
+} tlxmi_dwconv2d_desc;
+int tlxmi_dwconv2d(const tlxmi_dwconv2d_desc* d, const void* x, const void* w_rsc, const float* scale,
+                   const float* shift, void* y, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Pooling.  nn.MaxPool2d(3,2,padding=1) resnet.py:213-218 (padding value -inf);
+ * nn.AdaptiveAvgPool2d((1,1)) resnet.py:228-231 / mobilenetv1.py:246; AdaptiveAvgPool1d(1) over
+ * tokens swin_transformer.py:609.
+ * ---------------------------------------------------------------------------------------- */
+int tlxmi_maxpool2d(const void* x, void* y, int dtype, int N, int H, int W, int C, int x_ld, int y_ld,
+                    int R, int S, int stride_h, int stride_w, int pad_h, int pad_w, int Ho, int Wo,
+                    void* stream);
+/* y[n][c] = mean over H*W of x[n][.][.][c];  y pixel stride y_ld */
+int tlxmi_global_avgpool(const void* x, void* y, int dtype, int N, int HW, int C, int x_ld, int y_ld,
+                         void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Elementwise: y = act(x*scale[c] + shift[c]) (+ res).  Used when a BatchNorm / activation / add
+ * cannot be fused into a producer (stand-alone nn.BatchNorm2d, nn.ReLU, `out += identity`).
+ * ---------------------------------------------------------------------------------------- */
+int tlxmi_affine_act(const void* x, const float* scale, const float* shift, const void* res, void* y,
+                     int dtype, int64_t rows, int C, int x_ld, int res_ld, int y_ld, int act,
+                     float act_param, uint32_t flags, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * LayerNorm over the last dimension (biased variance), nn.LayerNorm(dim, epsilon)
+ * vision_transformer.py:144,159,283; swin_transformer.py:258,279,371,495,591.
+ * ---------------------------------------------------------------------------------------- */
+int tlxmi_layernorm(const void* x, const float* gamma, const float* beta, void* y, int dtype,
+                    int64_t rows, int C, int x_ld, int y_ld, float eps, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused multi-head self attention on a packed qkv matrix (the output of the qkv Linear):
+ *   qkv: [B][Ntok][3][heads][hd]   (vision_transformer.py:112-116; swin_transformer.py:194-200)
+ *   out: [B][Ntok][heads*hd]       softmax(scale * q k^T + bias + mask) v, heads re-interleaved
+ *   bias: optional [heads][Ntok][Ntok] fp32 (Swin relative position bias, :205-215)
+ *   mask: optional [nW][Ntok][Ntok] fp32, window index = b % nW (Swin shift mask, :216-220)
+ * Supported: hd in {32, 64}, Ntok <= 256.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct tlxmi_attn_desc {
+    int32_t dtype;
+    int32_t B, Ntok, heads, hd;
+    float scale;
+    int32_t nW;              /* mask windows (0 = no mask) */
+} tlxmi_attn_desc;
+int tlxmi_attention(const tlxmi_attn_desc* d, const void* qkv, const float* bias, const float* mask,
+                    void* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Swin window plumbing folded into index math (swin_transformer.py:85-116, 317-333):
+ *   partition: x[B][H][W][C] --roll(-shift)--> windows [B*nW][ws*ws][C]
+ *   reverse:   windows --> x (+roll(+shift)), optionally y = res + reverse(windows)
+ * ---------------------------------------------------------------------------------------- */
+int tlxmi_window_partition(const void* x, void* win, int dtype, int B, int H, int W, int C, int ws,
+                           int shift, void* stream);
+int tlxmi_window_reverse(const void* win, const void* res, void* y, int dtype, int B, int H, int W,
+                         int C, int ws, int shift, void* stream);
+/* PatchMerging gather (swin_transformer.py:373-388): x[B][H][W][C] -> y[B][H/2][W/2][4C],
+ * channel blocks in the order (0,0),(1,0),(0,1),(1,1). */
+int tlxmi_patch_merge_gather(const void* x, void* y, int dtype, int B, int H, int W, int C,
+                             void* stream);
+
+/* nearest x2 upsample written at a channel offset of a wider NHWC buffer (yolov3.py:250-256:
+ * interpolate(scale_factor=2) + concat).  y has pixel stride y_ld; channels [c_off, c_off+C). */
+int tlxmi_upsample2x_nearest(const void* x, void* y, int dtype, int N, int H, int W, int C, int x_ld,
+                             int y_ld, int c_off, void* stream);
+/* strided copy of an NHWC tensor into a channel window of another (tlx.concat along channels) */
+int tlxmi_copy_channels(const void* x, void* y, int dtype, int64_t rows, int C, int x_ld, int y_ld,
+                        void* stream);
+
+/* argmax over the last dimension -> int64 (tasks/image_classification.py:23) */
+int tlxmi_argmax_lastdim(const void* x, int dtype, int64_t rows, int C, int x_ld, int64_t* out,
+                         void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TLXMI_H */

@@ -1,0 +1,92 @@
+"""Generate tests/golden/*.npz — run ONLY in the development container (needs /root/reference).
+
+For each torch-capable reference model file it
+  1. imports the file UNMODIFIED from /root/reference by path, with `tensorlayerx` resolved to the
+     oracle's torch-CPU stand-in (oracle/tlx_cpu) — the reference source is never copied;
+  2. fills it and the restatement (oracle/functional.py) from the same seeded numpy recipe;
+  3. requires restatement == reference graph (max abs diff <= 1e-5, same argmax);
+  4. writes a small fixture: recipe ids + expected fp32 logits + argmax.
+Paddle-only reference files (swin, mobilenetv2/v3) cannot be imported; their fixtures come from the
+restatement alone and are marked `pinned_by="restatement-only"`.
+
+    python -m oracle.gen_golden            # writes tests/golden/
+"""
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+REF = "/root/reference"
+OUT = os.path.join(REPO, "tests", "golden")
+
+from oracle import functional as OF  # noqa: E402
+from tlxcv_amd import seeded  # noqa: E402
+
+
+def import_reference(relpath, modname):
+    """Load one reference source file by path with tensorlayerx -> oracle.tlx_cpu."""
+    import oracle.tlx_cpu as tlx_cpu
+    saved = {k: sys.modules.get(k) for k in ("tensorlayerx", "tensorlayerx.nn", "tensorlayerx.ops",
+                                             "tensorlayerx.nn.initializers")}
+    sys.modules["tensorlayerx"] = tlx_cpu
+    sys.modules["tensorlayerx.nn"] = tlx_cpu.nn
+    sys.modules["tensorlayerx.ops"] = tlx_cpu.ops
+    sys.modules["tensorlayerx.nn.initializers"] = tlx_cpu.nn.initializers
+    try:
+        spec = importlib.util.spec_from_file_location(modname, os.path.join(REF, relpath))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
+def _check(name, ref_out, re_out):
+    d = (ref_out - re_out).abs().max().item()
+    same = bool((ref_out.argmax(-1) == re_out.argmax(-1)).all()) if ref_out.dim() == 2 else True
+    print(f"[{name}] reference-file vs restatement: max|diff| = {d:.3e}, argmax equal = {same}")
+    assert d <= 1e-5 and same, f"{name}: restatement disagrees with the reference graph"
+    return d
+
+
+def gen_resnet(depth, batch, wseed, xseed, fname):
+    ref = import_reference("tlxcv/models/classification/resnet.py", "ref_resnet")
+    model = getattr(ref, f"resnet{depth}")()
+    shapes = seeded.shapes_of(model)
+    params = seeded.fill(shapes, wseed)
+    model.load_dict(params)
+    model.set_eval()
+    x = torch.from_numpy(seeded.image_batch(batch, xseed))
+    torch.manual_seed(0)
+    with torch.no_grad():
+        ref_out = model(x)
+        re_out = OF.resnet({k: torch.from_numpy(v) for k, v in params.items()}, x, depth)
+    d = _check(f"resnet{depth}", ref_out, re_out)
+    np.savez_compressed(
+        os.path.join(OUT, fname), arch=f"resnet{depth}", weight_seed=wseed, input_seed=xseed, batch=batch,
+        logits=ref_out.numpy().astype(np.float32), argmax=ref_out.argmax(-1).numpy().astype(np.int64),
+        restatement_max_abs_diff=np.float64(d), pinned_by="reference-file-on-tlx_cpu",
+        param_names=np.array(list(shapes.keys())), torch_version=torch.__version__)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(os.cpu_count() or 1)
+    gen_resnet(50, 4, 1, 0, "resnet50_b4.npz")      # BASELINE.json configs[0]
+    gen_resnet(18, 2, 11, 10, "resnet18_b2.npz")
+    for extra in EXTRA:
+        extra()
+
+
+EXTRA = []
+
+if __name__ == "__main__":
+    main()

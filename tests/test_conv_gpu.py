@@ -1,0 +1,127 @@
+"""HIP implicit-GEMM conv / linear vs the CPU oracle, through the C-ABI (tlxmi_conv2d).
+
+Every unique conv shape of ResNet-50 at batch 1-2, plus the edge cases the tiling
+has: pixel-tile tails, channel tails that force the scalar store path (Cout 1000, 291, 3), padded
+input channels (3 -> 8/4), dilation, asymmetric stride/padding, every epilogue combination.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import functional as OF
+from tlxcv_amd import engine as E
+from util import rnd, q16, nchw_to_engine, engine_to_nchw, tol
+
+pytestmark = pytest.mark.gpu
+
+# (Cin, Cout, k, stride, Hin) — resnet.py graph at 224 input, see SURVEY §8 a3
+RESNET50_CONVS = [
+    (3, 64, 7, 2, 224), (64, 64, 1, 1, 56), (64, 64, 3, 1, 56), (64, 256, 1, 1, 56), (256, 64, 1, 1, 56),
+    (256, 128, 1, 1, 56), (128, 128, 3, 2, 56), (128, 512, 1, 1, 28), (256, 512, 1, 2, 56), (512, 128, 1, 1, 28),
+    (128, 128, 3, 1, 28), (512, 256, 1, 1, 28), (256, 256, 3, 2, 28), (256, 1024, 1, 1, 14), (512, 1024, 1, 2, 28),
+    (1024, 256, 1, 1, 14), (256, 256, 3, 1, 14), (1024, 512, 1, 1, 14), (512, 512, 3, 2, 14), (512, 2048, 1, 1, 7),
+    (1024, 2048, 1, 2, 14), (2048, 512, 1, 1, 7), (512, 512, 3, 1, 7),
+]
+
+
+def run_case(dev, dtype, N, Cin, Cout, k, stride, pad, H, W=None, dil=1, act=0, act_param=0.0, with_bn=True,
+             with_res=False, res_after=False, seed=0):
+    W = W or H
+    rng = np.random.default_rng(seed)
+    kh, kw = (k, k) if isinstance(k, int) else k
+    x = rnd(rng, (N, Cin, H, W))
+    w = rnd(rng, (Cout, Cin, kh, kw), (2.0 / (Cin * kh * kw)) ** 0.5)
+    scale = torch.from_numpy(rng.uniform(0.5, 1.5, Cout).astype(np.float32)) if with_bn else None
+    shift = rnd(rng, (Cout,), 0.1) if with_bn else None
+    if dtype == torch.float16:
+        x, w = q16(x), q16(w)
+    sh, sw = (stride, stride) if isinstance(stride, int) else stride
+    ph, pw = (pad, pad) if isinstance(pad, int) else pad
+    Ho = (H + 2 * ph - dil * (kh - 1) - 1) // sh + 1
+    Wo = (W + 2 * pw - dil * (kw - 1) - 1) // sw + 1
+    res = rnd(rng, (N, Cout, Ho, Wo)) if with_res else None
+    if res is not None and dtype == torch.float16:
+        res = q16(res)
+    want = OF.conv_bn_act(x, w, scale, shift, res, act, act_param, (sh, sw), (ph, pw), dil, 1, res_after)
+
+    pk = E.PackedFilter(w.to(dev), dtype)
+    xe = nchw_to_engine(x, dtype, dev)
+    re_ = res.permute(0, 2, 3, 1).contiguous().to(dtype).to(dev) if res is not None else None
+    got = E.conv2d(xe, pk, (sh, sw), (ph, pw), dil, scale.to(dev) if with_bn else None,
+                   shift.to(dev) if with_bn else None, re_, act, act_param, res_after)
+    torch.cuda.synchronize()
+    assert got.shape == (N, Ho, Wo, Cout)
+    torch.testing.assert_close(engine_to_nchw(got), want, **tol(dtype))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["fp32", "fp16"])
+@pytest.mark.parametrize("cfg", RESNET50_CONVS, ids=lambda c: "x".join(map(str, c)))
+def test_resnet50_conv_shapes(dev, dtype, cfg):
+    Cin, Cout, k, s, H = cfg
+    run_case(dev, dtype, 2 if H <= 56 else 1, Cin, Cout, k, s, k // 2, H, act=1, with_res=(k == 1 and Cout >= 256))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["fp32", "fp16"])
+@pytest.mark.parametrize("act", list(range(9)))
+def test_every_activation_epilogue(dev, dtype, act):
+    run_case(dev, dtype, 1, 32, 48, 3, 1, 1, 9, act=act, act_param=0.1, with_res=True, res_after=(act == 3))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["fp32", "fp16"])
+@pytest.mark.parametrize("case", [
+    dict(N=1, Cin=3, Cout=3, k=3, stride=1, pad=1, H=5),                      # tiny everything, scalar stores
+    dict(N=3, Cin=16, Cout=291, k=1, stride=1, pad=0, H=13),                  # YOLO head width (yolov3.py:352)
+    dict(N=5, Cin=2048, Cout=1000, k=1, stride=1, pad=0, H=1, with_bn=True),  # classifier GEMM
+    dict(N=2, Cin=24, Cout=40, k=3, stride=1, pad=2, H=17, dil=2),            # dilation
+    dict(N=1, Cin=8, Cout=72, k=(3, 5), stride=(2, 1), pad=(1, 2), H=19, W=23),  # asymmetric
+    dict(N=2, Cin=3, Cout=768, k=16, stride=16, pad=0, H=64),                 # ViT patch embed geometry
+    dict(N=1, Cin=3, Cout=128, k=4, stride=4, pad=0, H=56),                   # Swin patch embed geometry
+    dict(N=1, Cin=64, Cout=64, k=1, stride=1, pad=0, H=1, with_bn=False),     # a single row
+    dict(N=1, Cin=40, Cout=136, k=3, stride=2, pad=1, H=31, with_res=True),   # odd sizes + residual
+], ids=lambda c: f"{c['Cin']}to{c['Cout']}k{c['k']}")
+def test_edge_geometries(dev, dtype, case):
+    run_case(dev, dtype, **case)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["fp32", "fp16"])
+def test_linear_with_bias_gelu_and_residual(dev, dtype):
+    rng = np.random.default_rng(3)
+    x, w, b, r = rnd(rng, (3, 50, 96)), rnd(rng, (96, 200), 0.1), rnd(rng, (200,), 0.1), rnd(rng, (3, 50, 200))
+    if dtype == torch.float16:
+        x, w, r = q16(x), q16(w), q16(r)
+    pk = E.PackedFilter(w.t().contiguous().to(dev), dtype)
+    got = E.linear(x.to(dtype).to(dev), pk, b.to(dev), act=E.ACT_GELU)
+    want = torch.nn.functional.gelu(x @ w + b)
+    torch.testing.assert_close(got.float().cpu(), want, **tol(dtype))
+    got = E.linear(x.to(dtype).to(dev), pk, b.to(dev), res=r.to(dtype).to(dev))
+    torch.testing.assert_close(got.float().cpu(), x @ w + b + r, **tol(dtype))
+
+
+def test_linearity_at_full_size(dev):
+    """Size-independent property at the BASELINE shape (bs 256, 56x56, 64->256, fp16): conv is linear,
+    so conv(a) + conv(b) == conv(a + b) up to fp16 rounding, with no oracle in the loop."""
+    rng = np.random.default_rng(1)
+    g = torch.Generator(device="cpu").manual_seed(1)
+    a = (torch.randn((256, 56, 56, 64), generator=g) * 0.5).half().to(dev)
+    b = (torch.randn((256, 56, 56, 64), generator=g) * 0.5).half().to(dev)
+    w = q16(rnd(rng, (256, 64, 1, 1), 0.15))
+    pk = E.PackedFilter(w.to(dev), torch.float16)
+    ya, yb, yab = E.conv2d(a, pk), E.conv2d(b, pk), E.conv2d((a.float() + b.float()).half(), pk)
+    torch.cuda.synchronize()
+    # a+b is rounded to fp16 before the conv: bound by K * ulp(a+b) * |w|
+    err = (ya.float() + yb.float() - yab.float()).abs().max().item()
+    assert err < 2e-2, err
+    # and a spot check of 512 random output pixels against the oracle
+    idx = torch.randint(0, 256 * 56 * 56, (512,), generator=g)
+    xa = a.view(-1, 64)[idx.to(dev)].float().cpu()
+    want = xa @ w.view(256, 64).t()
+    torch.testing.assert_close(ya.view(-1, 256)[idx.to(dev)].float().cpu(), want, atol=2e-3, rtol=2e-3)
+
+
+def test_descriptor_errors_raise(dev):
+    pk = E.PackedFilter(torch.zeros(8, 8, 3, 3, device=dev), torch.float16)
+    x = torch.zeros((1, 2, 2, 8), dtype=torch.float16, device=dev)
+    with pytest.raises(RuntimeError, match="empty output"):
+        E.conv2d(x, pk, 1, 0)                      # 3x3 valid on 2x2
+    with pytest.raises(RuntimeError, match="dtype"):
+        E.conv2d(x.float(), pk, 1, 1)

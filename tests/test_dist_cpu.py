@@ -1,0 +1,61 @@
+"""N>1 path on CPU: two gloo ranks exercise the shard/all-gather logic of tlxcv_amd.dist (the
+exchange step of SURVEY §8e).  No engine compute here — logits are synthetic — because the product
+has no CPU compute path; what is under test is ordering, ragged shards and shapes."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, total, q):
+    sys.path.insert(0, REPO)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from tlxcv_amd import dist as D
+    D.init(backend="gloo")
+    full = torch.arange(total * 5, dtype=torch.float32).reshape(total, 5)       # "logits" of the whole batch
+    mine = D.shard_batch(full)
+    lo, hi = D.shard_bounds(total, rank, world)
+    assert mine.shape[0] == hi - lo
+    out = D.all_gather_logits(mine.clone(), total=total)
+    q.put((rank, bool(torch.equal(out, full)), tuple(out.shape)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [8, 7])
+def test_two_rank_all_gather_of_logits(total):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == [0, 1]
+    assert all(ok for _, ok, _ in res)
+    assert all(shape == (total, 5) for _, _, shape in res)
+
+
+def test_shard_bounds_cover_exactly():
+    from tlxcv_amd.dist import shard_bounds
+    for n in (0, 1, 7, 256, 2048):
+        for w in (1, 2, 3, 8):
+            spans = [shard_bounds(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))

@@ -1,0 +1,181 @@
+"""HBM-bound kernels and attention vs the CPU oracle (torch fp32 on the same seeded inputs)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tlxcv_amd import engine as E
+from util import rnd, q16, nchw_to_engine, engine_to_nchw, tol
+
+pytestmark = pytest.mark.gpu
+DT = pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["fp32", "fp16"])
+
+
+def prep(t, dtype):
+    return q16(t) if dtype == torch.float16 else t
+
+
+@DT
+@pytest.mark.parametrize("shape", [(2, 3, 17, 23), (1, 64, 8, 8), (3, 20, 5, 7)])
+def test_layout_roundtrip_and_padding(dev, dtype, shape):
+    rng = np.random.default_rng(0)
+    x = prep(rnd(rng, shape), dtype)
+    y = E.nchw_to_nhwc(x.to(dev), dtype)
+    v = E.vec(dtype)
+    cp = (shape[1] + v - 1) // v * v
+    assert y.shape == (shape[0], shape[2], shape[3], cp)
+    got = y.float().cpu()
+    assert torch.equal(got[..., :shape[1]], x.permute(0, 2, 3, 1))
+    assert (got[..., shape[1]:] == 0).all()
+    back = E.nhwc_to_nchw(y, shape[1], torch.float32)
+    assert torch.equal(back.cpu(), x)
+
+
+@DT
+def test_maxpool_resnet_stem_and_borders(dev, dtype):
+    rng = np.random.default_rng(1)
+    for (N, C, H, W, k, s, p) in [(2, 64, 112, 112, 3, 2, 1), (1, 8, 7, 9, 3, 2, 1), (1, 16, 6, 6, 2, 2, 0)]:
+        x = prep(rnd(rng, (N, C, H, W)) - 3.0, dtype)       # all-negative rows: -inf padding must not win as 0
+        got = E.maxpool2d(nchw_to_engine(x, dtype, dev), k, s, p)
+        torch.testing.assert_close(engine_to_nchw(got), F.max_pool2d(x, k, s, p), atol=0, rtol=0)
+
+
+@DT
+def test_global_avgpool(dev, dtype):
+    rng = np.random.default_rng(2)
+    x = prep(rnd(rng, (3, 2048, 7, 7)), dtype)
+    got = E.global_avgpool(nchw_to_engine(x, dtype, dev))
+    torch.testing.assert_close(got.float().cpu(), x.mean((2, 3)), **tol(dtype))
+
+
+@DT
+@pytest.mark.parametrize("act", [0, 1, 3, 6])
+def test_affine_act(dev, dtype, act):
+    rng = np.random.default_rng(3)
+    x, r = prep(rnd(rng, (37, 72)), dtype), prep(rnd(rng, (37, 72)), dtype)
+    sc, sh = rnd(rng, (72,)), rnd(rng, (72,))
+    from oracle.functional import ACTS
+    want = ACTS[act](x * sc + sh + r, 0.2)
+    got = E.affine_act(x.to(dtype).to(dev), sc.to(dev), sh.to(dev), r.to(dtype).to(dev), act, 0.2)
+    torch.testing.assert_close(got.float().cpu(), want, **tol(dtype))
+
+
+@DT
+@pytest.mark.parametrize("C,eps", [(768, 1e-6), (128, 1e-5), (4096, 1e-5), (24, 1e-5)])
+def test_layernorm(dev, dtype, C, eps):
+    rng = np.random.default_rng(4)
+    x = prep(rnd(rng, (2, 19, C), 2.0) + 0.5, dtype)
+    g, b = rnd(rng, (C,)) * 0.1 + 1, rnd(rng, (C,), 0.1)
+    got = E.layernorm(x.to(dtype).to(dev), g.to(dev), b.to(dev), eps)
+    torch.testing.assert_close(got.float().cpu(), F.layer_norm(x, (C,), g, b, eps), **tol(dtype))
+
+
+@DT
+@pytest.mark.parametrize("k,s,p,act", [(3, 1, 1, 1), (3, 2, 1, 2), (5, 1, 2, 4), (5, 2, 2, 1)])
+def test_depthwise_conv(dev, dtype, k, s, p, act):
+    rng = np.random.default_rng(5)
+    C = 40
+    x = prep(rnd(rng, (2, C, 15, 13)), dtype)
+    w = prep(rnd(rng, (C, 1, k, k), 0.3), dtype)
+    sc, sh = torch.from_numpy(rng.uniform(0.5, 1.5, C).astype(np.float32)), rnd(rng, (C,), 0.1)
+    from oracle.functional import conv_bn_act
+    want = conv_bn_act(x, w, sc, sh, None, act, 0.0, s, p, 1, C)
+    w_rsc = w[:, 0].permute(1, 2, 0).contiguous().to(dtype).to(dev)
+    got = E.dwconv2d(nchw_to_engine(x, dtype, dev), w_rsc, s, p, 1, sc.to(dev), sh.to(dev), act)
+    torch.testing.assert_close(engine_to_nchw(got), want, **tol(dtype))
+
+
+def _ref_attention(qkv, heads, scale, bias=None, mask=None):
+    """vision_transformer.py:112-120 / swin_transformer.py:194-224 on torch CPU."""
+    B, N, C3 = qkv.shape
+    hd = C3 // 3 // heads
+    t = qkv.reshape(B, N, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    q, k, v = t[0], t[1], t[2]
+    attn = (q @ k.transpose(-1, -2)) * scale
+    if bias is not None:
+        attn = attn + bias.unsqueeze(0)
+    if mask is not None:
+        nW = mask.shape[0]
+        attn = (attn.reshape(B // nW, nW, heads, N, N) + mask.unsqueeze(1).unsqueeze(0)).reshape(-1, heads, N, N)
+    attn = torch.softmax(attn, -1)
+    return (attn @ v).permute(0, 2, 1, 3).reshape(B, N, heads * hd)
+
+
+@DT
+@pytest.mark.parametrize("B,N,heads,hd,swin", [(3, 197, 12, 64, False), (2, 50, 3, 64, False), (8, 49, 4, 32, True),
+                                                (4, 49, 32, 32, True), (2, 16, 2, 32, False), (1, 256, 1, 64, False)])
+def test_attention(dev, dtype, B, N, heads, hd, swin):
+    rng = np.random.default_rng(6)
+    qkv = prep(rnd(rng, (B, N, 3 * heads * hd)), dtype)
+    bias = rnd(rng, (heads, N, N), 0.5) if swin else None
+    mask = None
+    if swin:
+        nW = 4
+        ids = torch.from_numpy(rng.integers(0, 3, (nW, N)))
+        mask = (ids.unsqueeze(1) != ids.unsqueeze(2)).float() * -100.0        # swin_transformer.py:303-305
+    scale = hd ** -0.5
+    want = _ref_attention(qkv, heads, scale, bias, mask)
+    got = E.attention(qkv.to(dtype).to(dev), heads, scale, bias.to(dev) if swin else None,
+                      mask.to(dev) if swin else None)
+    t = tol(dtype) if dtype == torch.float32 else dict(atol=4e-3, rtol=4e-3)
+    torch.testing.assert_close(got.float().cpu(), want, **t)
+
+
+def test_attention_softmax_is_stable_for_large_scores(dev):
+    """Forces the max-subtraction path: one key dominates with a score ~ +80 (exp overflows in fp16)."""
+    rng = np.random.default_rng(7)
+    B, N, heads, hd = 1, 64, 1, 64
+    qkv = rnd(rng, (B, N, 3 * hd), 0.1)
+    qkv[0, 5, :hd] = 8.0          # q row 5
+    qkv[0, 9, hd:2 * hd] = 10.0   # k row 9  -> score 8*10*64/8 = 640*... scaled
+    qkv = q16(qkv)
+    want = _ref_attention(qkv, heads, hd ** -0.5)
+    got = E.attention(qkv.half().to(dev), heads, hd ** -0.5)
+    assert torch.isfinite(got).all()
+    torch.testing.assert_close(got.float().cpu(), want, atol=4e-3, rtol=4e-3)
+
+
+@DT
+@pytest.mark.parametrize("shift", [0, 3])
+def test_window_partition_reverse(dev, dtype, shift):
+    rng = np.random.default_rng(8)
+    B, H, W, C, ws = 2, 14, 14, 32, 7
+    x = prep(rnd(rng, (B, H, W, C)), dtype)
+    xs = torch.roll(x, (-shift, -shift), (1, 2)) if shift else x                       # swin :317-319
+    want = xs.reshape(B, H // ws, ws, W // ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws, C)  # :85-99
+    win = E.window_partition(x.to(dtype).to(dev), ws, shift)
+    assert torch.equal(win.float().cpu(), want)
+    back = E.window_reverse(win, B, H, W, ws, shift)
+    assert torch.equal(back.float().cpu(), x)                                          # reverse o partition = id
+    r = prep(rnd(rng, (B, H, W, C)), dtype)
+    fused = E.window_reverse(win, B, H, W, ws, shift, res=r.to(dtype).to(dev))
+    torch.testing.assert_close(fused.float().cpu(), x + r, **tol(dtype))
+
+
+@DT
+def test_patch_merge_gather(dev, dtype):
+    rng = np.random.default_rng(9)
+    x = prep(rnd(rng, (2, 8, 6, 16)), dtype)
+    want = torch.cat([x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]], -1)   # swin :381-386
+    got = E.patch_merge_gather(x.to(dtype).to(dev))
+    assert torch.equal(got.float().cpu(), want)
+
+
+@DT
+def test_upsample_concat(dev, dtype):
+    rng = np.random.default_rng(10)
+    a, b = prep(rnd(rng, (1, 16, 5, 4)), dtype), prep(rnd(rng, (1, 24, 10, 8)), dtype)
+    want = torch.cat([F.interpolate(a, scale_factor=2, mode="nearest"), b], 1)                         # yolov3.py:250-256
+    out = torch.empty((1, 10, 8, 40), dtype=dtype, device=dev)
+    E.upsample2x_into(nchw_to_engine(a, dtype, dev), out, 0)
+    E.copy_channels_into(nchw_to_engine(b, dtype, dev), out, 16)
+    assert torch.equal(engine_to_nchw(out), want)
+
+
+def test_argmax_ties_nan_and_tail(dev):
+    x = torch.tensor([[1.0, 5.0, 5.0, 2.0], [3.0, float("nan"), 9.0, 1.0], [-2.0, -1.0, -3.0, -1.0]])
+    got = E.argmax_lastdim(x.to(dev)).cpu()
+    assert got.tolist() == torch.argmax(x, -1).tolist() == [1, 1, 1]
+    g = torch.Generator().manual_seed(0)
+    big = torch.randn((257, 1000), generator=g)
+    assert torch.equal(E.argmax_lastdim(big.half().to(dev)).cpu(), torch.argmax(big.half().float(), -1))

@@ -1,0 +1,98 @@
+"""ctypes binding of libtlxmi.so (the C-ABI declared in include/tlxmi.h).
+
+The product path has no CPU fallback: if the shared library is missing, or a call returns a
+non-zero status, a RuntimeError is raised (the reference's convention for bad input is a plain
+Python exception / assert, e.g. tlxcv/models/classification/vision_transformer.py:217-219).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtlxmi.so")
+
+F16, F32 = 0, 1
+ACT_NONE, ACT_RELU, ACT_RELU6, ACT_LEAKY, ACT_HARDSWISH, ACT_HARDSIGMOID, ACT_GELU, ACT_SIGMOID, ACT_SILU = range(9)
+EPI_RES_AFTER_ACT = 1
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "dtype", "N", "H", "W", "C", "Cout", "R", "S", "stride_h", "stride_w", "pad_h", "pad_w",
+        "dil_h", "dil_w", "Ho", "Wo", "x_ld", "y_ld", "res_ld", "y_nstride", "res_nstride", "act")] + [
+        ("act_param", C.c_float), ("flags", C.c_uint32)]
+
+
+class DwConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "dtype", "N", "H", "W", "C", "R", "S", "stride_h", "stride_w", "pad_h", "pad_w", "dil_h",
+        "dil_w", "Ho", "Wo", "x_ld", "y_ld", "act")] + [("act_param", C.c_float)]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("dtype", "B", "Ntok", "heads", "hd")] + [
+        ("scale", C.c_float), ("nW", C.c_int32)]
+
+
+_vp, _i, _f, _u, _l = C.c_void_p, C.c_int, C.c_float, C.c_uint32, C.c_int64
+
+# name -> argtypes; every function returns int status unless listed in _SPECIAL
+PROTOTYPES = {
+    "tlxmi_nchw_to_nhwc": [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "tlxmi_nhwc_to_nchw": [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp],
+    "tlxmi_pack_filter": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "tlxmi_fold_bn": [_vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp],
+    "tlxmi_conv2d": [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "tlxmi_dwconv2d": [C.POINTER(DwConvDesc), _vp, _vp, _vp, _vp, _vp, _vp],
+    "tlxmi_maxpool2d": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "tlxmi_global_avgpool": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "tlxmi_affine_act": [_vp, _vp, _vp, _vp, _vp, _i, _l, _i, _i, _i, _i, _i, _f, _u, _vp],
+    "tlxmi_layernorm": [_vp, _vp, _vp, _vp, _i, _l, _i, _i, _i, _f, _vp],
+    "tlxmi_attention": [C.POINTER(AttnDesc), _vp, _vp, _vp, _vp, _vp],
+    "tlxmi_window_partition": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "tlxmi_window_reverse": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "tlxmi_patch_merge_gather": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "tlxmi_upsample2x_nearest": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "tlxmi_copy_channels": [_vp, _vp, _i, _l, _i, _i, _i, _vp],
+    "tlxmi_argmax_lastdim": [_vp, _i, _l, _i, _i, _vp, _vp],
+}
+_SPECIAL = {
+    "tlxmi_version": ([], C.c_int),
+    "tlxmi_last_error": ([], C.c_char_p),
+    "tlxmi_device_count": ([], C.c_int),
+    "tlxmi_packed_filter_bytes": ([_i, _i, _i, _i, _i], C.c_size_t),
+}
+ALL_SYMBOLS = sorted(list(PROTOTYPES) + list(_SPECIAL))
+
+_lib = None
+
+
+def load():
+    """Load libtlxmi.so (built by __graft_entry__.build() / `make -C tlxcv_amd/csrc`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"tlxcv_amd: {LIB_PATH} is missing — the HIP engine has not been built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C tlxcv_amd/csrc`). "
+            "There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in PROTOTYPES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    for name, (argtypes, restype) in _SPECIAL.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = restype
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Invoke a status-returning entry point; non-zero status -> RuntimeError."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.tlxmi_last_error()
+        raise RuntimeError(f"{name} failed ({rc}): {msg.decode() if msg else ''}")

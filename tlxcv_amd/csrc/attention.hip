@@ -1,0 +1,132 @@
+// Fused multi-head self attention on the packed qkv matrix.
+// Reference: Attention.forward vision_transformer.py:112-123 (scale applied to q k^T, :117);
+// WindowAttention.forward swin_transformer.py:192-229 (q scaled first :202, + relative position
+// bias :205-215, + shift mask viewed as (B, nW, heads, N, N) :216-220, softmax, @v).
+//
+//   qkv [B][N][3][heads][hd]  ->  out [B][N][heads*hd]
+//   out[b,i,h,:] = sum_j softmax_j(scale * q_i.k_j + bias[h,i,j] + mask[b % nW,i,j]) v_j
+//
+// Two kernels:
+//   attn_rows_kernel  — exact-fp32 arithmetic, any hd <= 128, N <= 256: K and V of one (b, head)
+//                       staged once in LDS as fp32, one wave per query row, wave-shuffle softmax.
+//                       This is the fp32 parity path and the generic fallback.
+//   attn_mfma_kernel  — fp16 throughput path (see below), hd in {32, 64}.
+#include "common.h"
+
+namespace tlxmi {
+
+struct AttnArgs {
+    const void* qkv;
+    const float* bias;
+    const float* mask;
+    void* out;
+    int B, N, heads, hd, nW;
+    float scale;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_rows_kernel(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* Ks = reinterpret_cast<float*>(smem_raw);
+    const int N = a.N, hd = a.hd, ldk = hd + 1;
+    float* Vs = Ks + N * ldk;
+    float* ps = Vs + N * ldk;   // [4][256]
+    float* qs = ps + 4 * 256;   // [4][128]
+    const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const long tok_ld = 3L * a.heads * hd;
+    const T* base = reinterpret_cast<const T*>(a.qkv) + (long)b * N * tok_ld + (long)h * hd;
+    for (int i = t; i < N * hd; i += 256) {
+        const int n = i / hd, d = i - n * hd;
+        Ks[n * ldk + d] = (float)base[n * tok_ld + (long)a.heads * hd + d];
+        Vs[n * ldk + d] = (float)base[n * tok_ld + 2L * a.heads * hd + d];
+    }
+    __syncthreads();
+    const float* bias = a.bias ? a.bias + (long)h * N * N : nullptr;
+    const float* mask = (a.mask && a.nW > 0) ? a.mask + (long)(b % a.nW) * N * N : nullptr;
+    T* out = reinterpret_cast<T*>(a.out) + (long)b * N * a.heads * hd + (long)h * hd;
+    float* myq = qs + wv * 128;
+    float* myp = ps + wv * 256;
+    for (int row = wv; row < N; row += 4) {
+        for (int d = lane; d < hd; d += 64) myq[d] = (float)base[row * tok_ld + d];
+        __builtin_amdgcn_wave_barrier();
+        float s[4];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int j = lane + 64 * jj;
+            s[jj] = -INFINITY;
+            if (j < N) {
+                float acc = 0.f;
+                for (int d = 0; d < hd; ++d) acc = fmaf(myq[d], Ks[j * ldk + d], acc);
+                acc *= a.scale;
+                if (bias) acc += bias[(long)row * N + j];
+                if (mask) acc += mask[(long)row * N + j];
+                s[jj] = acc;
+                mx = fmaxf(mx, acc);
+            }
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int j = lane + 64 * jj;
+            if (j < N) {
+                s[jj] = expf(s[jj] - mx);
+                sum += s[jj];
+            }
+        }
+        sum = wave_sum(sum);
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int j = lane + 64 * jj;
+            if (j < N) myp[j] = s[jj] * inv;
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int d = lane; d < hd; d += 64) {
+            float o = 0.f;
+            for (int j = 0; j < N; ++j) o = fmaf(myp[j], Vs[j * ldk + d], o);
+            out[(long)row * a.heads * hd + d] = (T)o;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <typename T> static int launch_rows(const AttnArgs& a, hipStream_t st) {
+    const size_t lds = ((size_t)2 * a.N * (a.hd + 1) + 4 * 256 + 4 * 128) * sizeof(float);
+    if (lds > 160 * 1024) return fail(TLXMI_ERR_UNSUPPORTED, "attention: N=%d hd=%d needs %zu B of LDS", a.N, a.hd, lds);
+    static thread_local size_t raised = 0;
+    if (lds > 64 * 1024 && lds > raised) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_rows_kernel<T>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return fail(TLXMI_ERR_LAUNCH, "attention: cannot raise LDS limit: %s", hipGetErrorString(e));
+        raised = 160 * 1024;
+    }
+    hipLaunchKernelGGL((attn_rows_kernel<T>), dim3(a.B * a.heads), dim3(256), lds, st, a);
+    return check_launch("attention(rows)");
+}
+
+// TEMPORARY: MFMA path not written yet -> generic rows kernel
+int launch_attn_mfma(const AttnArgs& a, hipStream_t st) { return launch_rows<half_t>(a, st); }
+
+}  // namespace tlxmi
+
+using namespace tlxmi;
+
+extern "C" int tlxmi_attention(const tlxmi_attn_desc* d, const void* qkv, const float* bias, const float* mask,
+                               void* out, void* stream) {
+    TLXMI_REQUIRE(d && qkv && out, TLXMI_ERR_BAD_ARG, "attention: null argument");
+    TLXMI_REQUIRE(d->dtype == TLXMI_F16 || d->dtype == TLXMI_F32, TLXMI_ERR_BAD_ARG, "attention: bad dtype");
+    TLXMI_REQUIRE(d->B > 0 && d->Ntok > 0 && d->heads > 0 && d->hd > 0, TLXMI_ERR_BAD_ARG, "attention: bad extent");
+    TLXMI_REQUIRE(d->Ntok <= 256 && d->hd <= 128, TLXMI_ERR_UNSUPPORTED, "attention: Ntok=%d (<=256) hd=%d (<=128)", d->Ntok, d->hd);
+    TLXMI_REQUIRE(!mask || d->nW > 0, TLXMI_ERR_BAD_ARG, "attention: mask given but nW=%d", d->nW);
+    TLXMI_REQUIRE(!mask || d->B % d->nW == 0, TLXMI_ERR_BAD_ARG, "attention: B=%d not a multiple of nW=%d", d->B, d->nW);
+    AttnArgs a;
+    a.qkv = qkv; a.bias = bias; a.mask = mask; a.out = out;
+    a.B = d->B; a.N = d->Ntok; a.heads = d->heads; a.hd = d->hd; a.nW = mask ? d->nW : 0; a.scale = d->scale;
+    hipStream_t st = as_stream(stream);
+    if (d->dtype == TLXMI_F32) return launch_rows<float>(a, st);
+    if ((d->hd == 64 || d->hd == 32) && aligned16(qkv) && aligned16(out)) return launch_attn_mfma(a, st);
+    return launch_rows<half_t>(a, st);
+}

@@ -1,0 +1,113 @@
+// LayerNorm over the last dimension — HBM-bound row scan, one wave64 per row, the row held in
+// registers between the two statistics passes (mean, then centred variance: the same two-pass
+// form torch's CPU kernel uses, so fp32 results agree to rounding), reductions by wave shuffles.
+// Reference: nn.LayerNorm(dim, epsilon=...) vision_transformer.py:144,159,283 (eps 1e-6 for
+// ViT-B :355), swin_transformer.py:258,279,371,495,591.
+#include "common.h"
+
+namespace tlxmi {
+
+template <typename T, int NCH>  // NCH = 16-byte chunks per lane
+__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, T* __restrict__ y, long rows,
+                                                        int C, int x_ld, int y_ld, float eps) {
+    constexpr int V = 16 / (int)sizeof(T);
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nch = C / V;
+    float v[NCH][V];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < nch) {
+            if constexpr (sizeof(T) == 2) {
+                half8v h = *reinterpret_cast<const half8v*>(x + row * x_ld + ch * V);
+#pragma unroll
+                for (int e = 0; e < V; ++e) v[i][e] = (float)h[e];
+            } else {
+                f32x4 h = *reinterpret_cast<const f32x4*>(x + row * x_ld + ch * V);
+#pragma unroll
+                for (int e = 0; e < V; ++e) v[i][e] = h[e];
+            }
+#pragma unroll
+            for (int e = 0; e < V; ++e) sum += v[i][e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < V; ++e) v[i][e] = 0.f;
+        }
+    }
+    const float mean = wave_sum(sum) / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < nch) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const float d = v[i][e] - mean;
+                sq += d * d;
+            }
+        }
+    }
+    const float rstd = 1.f / sqrtf(wave_sum(sq) / (float)C + eps);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < nch) {
+            float o[V];
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const int c = ch * V + e;
+                const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+                o[e] = (v[i][e] - mean) * rstd * g + b;
+            }
+            if constexpr (sizeof(T) == 2) {
+                half8v h;
+#pragma unroll
+                for (int e = 0; e < V; ++e) h[e] = (half_t)o[e];
+                *reinterpret_cast<half8v*>(y + row * y_ld + ch * V) = h;
+            } else {
+                f32x4 h;
+#pragma unroll
+                for (int e = 0; e < V; ++e) h[e] = o[e];
+                *reinterpret_cast<f32x4*>(y + row * y_ld + ch * V) = h;
+            }
+        }
+    }
+}
+
+template <typename T>
+static int launch_ln(const void* x, const float* gamma, const float* beta, void* y, long rows, int C, int x_ld,
+                     int y_ld, float eps, hipStream_t st) {
+    constexpr int V = 16 / (int)sizeof(T);
+    const int per_lane = (C / V + 63) / 64;
+    dim3 g((unsigned)((rows + 3) / 4)), b(256);
+#define LN_CASE(n)                                                                                              \
+    hipLaunchKernelGGL((layernorm_kernel<T, n>), g, b, 0, st, (const T*)x, gamma, beta, (T*)y, rows, C, x_ld, \
+                       y_ld, eps)
+    if (per_lane <= 1) LN_CASE(1);
+    else if (per_lane <= 2) LN_CASE(2);
+    else if (per_lane <= 4) LN_CASE(4);
+    else if (per_lane <= 8) LN_CASE(8);
+    else if (per_lane <= 16) LN_CASE(16);
+    else return fail(TLXMI_ERR_UNSUPPORTED, "layernorm: C=%d too wide for the in-register row kernel", C);
+#undef LN_CASE
+    return check_launch("layernorm");
+}
+
+}  // namespace tlxmi
+
+using namespace tlxmi;
+
+extern "C" int tlxmi_layernorm(const void* x, const float* gamma, const float* beta, void* y, int dt, int64_t rows,
+                               int C, int x_ld, int y_ld, float eps, void* stream) {
+    TLXMI_REQUIRE(x && y && rows > 0 && C > 0, TLXMI_ERR_BAD_ARG, "layernorm: bad argument");
+    TLXMI_REQUIRE(dt == TLXMI_F16 || dt == TLXMI_F32, TLXMI_ERR_BAD_ARG, "layernorm: bad dtype");
+    const int V = 16 / (int)elt_size(dt);
+    TLXMI_REQUIRE(C % V == 0 && x_ld % V == 0 && y_ld % V == 0 && x_ld >= C && y_ld >= C && aligned16(x) && aligned16(y),
+                  TLXMI_ERR_ALIGNMENT, "layernorm: C=%d / strides must be whole 16-byte chunks", C);
+    if (dt == TLXMI_F16) return launch_ln<half_t>(x, gamma, beta, y, (long)rows, C, x_ld, y_ld, eps, as_stream(stream));
+    return launch_ln<float>(x, gamma, beta, y, (long)rows, C, x_ld, y_ld, eps, as_stream(stream));
+}

@@ -1,0 +1,464 @@
+// HBM-bound scan kernels: layout conversion, pooling, affine/activation, depthwise conv, upsample,
+// channel copies, argmax.  No MFMA here by design: every kernel moves 16-byte chunks of the NHWC
+// channel axis per lane (consecutive lanes -> consecutive chunks) so wave accesses are full lines.
+#include "common.h"
+
+namespace tlxmi {
+
+template <typename T> struct Chunk;  // 16 bytes of T <-> fp32 registers
+template <> struct Chunk<half_t> {
+    static constexpr int N = 8;
+    static __device__ __forceinline__ void load(const void* p, float* v) {
+        half8v h = *reinterpret_cast<const half8v*>(p);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (float)h[i];
+    }
+    static __device__ __forceinline__ void store(void* p, const float* v) {
+        half8v h;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) h[i] = (half_t)v[i];
+        *reinterpret_cast<half8v*>(p) = h;
+    }
+};
+template <> struct Chunk<float> {
+    static constexpr int N = 4;
+    static __device__ __forceinline__ void load(const void* p, float* v) {
+        f32x4 h = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = h[i];
+    }
+    static __device__ __forceinline__ void store(void* p, const float* v) {
+        f32x4 h;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) h[i] = v[i];
+        *reinterpret_cast<f32x4*>(p) = h;
+    }
+};
+
+static inline int grid_for(long work, int block = 256, int cap = 256 * 16) {
+    long g = (work + block - 1) / block;
+    if (g < 1) g = 1;
+    return (int)(g < cap ? g : cap);
+}
+
+// ------------------------------------------------------------------------------------------
+// NCHW -> NHWC(Cpad): one lane per (pixel, chunk); pixel index fastest so plane reads coalesce.
+// ------------------------------------------------------------------------------------------
+template <typename TS, typename TD>
+__global__ void nchw_to_nhwc_kernel(const TS* __restrict__ src, TD* __restrict__ dst, int N, int C, int H, int W,
+                                    int Cpad) {
+    constexpr int V = Chunk<TD>::N;
+    const long HW = (long)H * W, P = (long)N * HW;
+    const int nch = Cpad / V;
+    const long total = P * nch;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long p = i % P;
+        const int cg = (int)(i / P);
+        const long n = p / HW, hw = p - n * HW;
+        float v[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const int c = cg * V + e;
+            v[e] = c < C ? (float)src[(n * C + c) * HW + hw] : 0.f;
+        }
+        Chunk<TD>::store(dst + p * Cpad + cg * V, v);
+    }
+}
+
+template <typename TS, typename TD>
+__global__ void nhwc_to_nchw_kernel(const TS* __restrict__ src, int ld, TD* __restrict__ dst, int N, int C, int H,
+                                    int W) {
+    const long HW = (long)H * W, total = (long)N * C * HW;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long hw = i % HW;
+        const long nc = i / HW;
+        const int c = (int)(nc % C);
+        const long n = nc / C;
+        dst[i] = (TD)(float)src[(n * HW + hw) * ld + c];
+    }
+}
+
+__global__ void fold_bn_kernel(const float* gamma, const float* beta, const float* mean, const float* var,
+                               const float* cbias, float eps, int C, float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f, m = mean ? mean[c] : 0.f,
+                v = var ? var[c] : 1.f;
+    // same operation order as the oracle's folded form: scale = g / sqrt(v + eps)
+    const float s = g / sqrtf(v + eps);
+    scale[c] = s;
+    shift[c] = b - m * s + (cbias ? cbias[c] * s : 0.f);
+}
+
+// ------------------------------------------------------------------------------------------
+// MaxPool2d, -inf padding.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void maxpool_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C, int x_ld,
+                               int y_ld, int R, int S, int sh, int sw, int ph, int pw, int Ho, int Wo) {
+    constexpr int V = Chunk<T>::N;
+    const int nch = C / V;
+    const long total = (long)N * Ho * Wo * nch;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % nch);
+        long p = i / nch;
+        const int wo = (int)(p % Wo);
+        p /= Wo;
+        const int ho = (int)(p % Ho);
+        const long n = p / Ho;
+        float m[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) m[e] = -INFINITY;
+        for (int r = 0; r < R; ++r) {
+            const int hi = ho * sh - ph + r;
+            if ((unsigned)hi >= (unsigned)H) continue;
+            for (int s = 0; s < S; ++s) {
+                const int wi = wo * sw - pw + s;
+                if ((unsigned)wi >= (unsigned)W) continue;
+                float v[V];
+                Chunk<T>::load(x + ((n * H + hi) * W + wi) * x_ld + cg * V, v);
+#pragma unroll
+                for (int e = 0; e < V; ++e) m[e] = fmaxf(m[e], v[e]);
+            }
+        }
+        Chunk<T>::store(y + ((n * Ho + ho) * Wo + wo) * y_ld + cg * V, m);
+    }
+}
+
+template <typename T>
+__global__ void global_avgpool_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int HW, int C, int x_ld,
+                                      int y_ld) {
+    constexpr int V = Chunk<T>::N;
+    const int nch = C / V;
+    const long total = (long)N * nch;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % nch);
+        const long n = i / nch;
+        float acc[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] = 0.f;
+        const T* p = x + n * HW * x_ld + cg * V;
+        for (int k = 0; k < HW; ++k) {
+            float v[V];
+            Chunk<T>::load(p + (long)k * x_ld, v);
+#pragma unroll
+            for (int e = 0; e < V; ++e) acc[e] += v[e];
+        }
+        const float inv = 1.f / (float)HW;
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] *= inv;
+        Chunk<T>::store(y + n * y_ld + cg * V, acc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// y = act(x*scale + shift (+res)) (+res)
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void affine_act_kernel(const T* __restrict__ x, const float* __restrict__ scale,
+                                  const float* __restrict__ shift, const T* __restrict__ res, T* __restrict__ y,
+                                  long rows, int C, int x_ld, int res_ld, int y_ld, int act, float ap,
+                                  unsigned flags) {
+    constexpr int V = Chunk<T>::N;
+    const int nch = C / V;
+    const long total = rows * nch;
+    const bool res_after = (flags & TLXMI_EPI_RES_AFTER_ACT) != 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % nch);
+        const long row = i / nch;
+        float v[V], rv[V];
+        Chunk<T>::load(x + row * x_ld + cg * V, v);
+        if (res) Chunk<T>::load(res + row * res_ld + cg * V, rv);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            float t = v[e];
+            if (scale) t *= scale[cg * V + e];
+            if (shift) t += shift[cg * V + e];
+            if (res && !res_after) t += rv[e];
+            t = apply_act(t, act, ap);
+            if (res && res_after) t += rv[e];
+            v[e] = t;
+        }
+        Chunk<T>::store(y + row * y_ld + cg * V, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Depthwise conv: one lane per (output pixel, channel chunk); taps re-read through L1/L2.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void dwconv_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ scale,
+                              const float* __restrict__ shift, T* __restrict__ y, tlxmi_dwconv2d_desc d) {
+    constexpr int V = Chunk<T>::N;
+    const int nch = d.C / V;
+    const long total = (long)d.N * d.Ho * d.Wo * nch;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % nch);
+        long p = i / nch;
+        const int wo = (int)(p % d.Wo);
+        p /= d.Wo;
+        const int ho = (int)(p % d.Ho);
+        const long n = p / d.Ho;
+        float acc[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] = 0.f;
+        for (int r = 0; r < d.R; ++r) {
+            const int hi = ho * d.stride_h - d.pad_h + r * d.dil_h;
+            if ((unsigned)hi >= (unsigned)d.H) continue;
+            for (int s = 0; s < d.S; ++s) {
+                const int wi = wo * d.stride_w - d.pad_w + s * d.dil_w;
+                if ((unsigned)wi >= (unsigned)d.W) continue;
+                float xv[V], wv[V];
+                Chunk<T>::load(x + ((n * d.H + hi) * d.W + wi) * d.x_ld + cg * V, xv);
+                Chunk<T>::load(w + (long)(r * d.S + s) * d.C + cg * V, wv);
+#pragma unroll
+                for (int e = 0; e < V; ++e) acc[e] = fmaf(xv[e], wv[e], acc[e]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            float t = acc[e];
+            if (scale) t *= scale[cg * V + e];
+            if (shift) t += shift[cg * V + e];
+            acc[e] = apply_act(t, d.act, d.act_param);
+        }
+        Chunk<T>::store(y + ((n * d.Ho + ho) * d.Wo + wo) * d.y_ld + cg * V, acc);
+    }
+}
+
+// nearest x2 upsample into a channel window of a wider buffer
+template <typename T>
+__global__ void upsample2x_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C, int x_ld,
+                                  int y_ld, int c_off) {
+    constexpr int V = Chunk<T>::N;
+    const int nch = C / V, Ho = 2 * H, Wo = 2 * W;
+    const long total = (long)N * Ho * Wo * nch;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % nch);
+        long p = i / nch;
+        const int wo = (int)(p % Wo);
+        p /= Wo;
+        const int ho = (int)(p % Ho);
+        const long n = p / Ho;
+        u32x4 v = *reinterpret_cast<const u32x4*>(x + ((n * H + (ho >> 1)) * W + (wo >> 1)) * x_ld + cg * V);
+        *reinterpret_cast<u32x4*>(y + ((n * Ho + ho) * Wo + wo) * y_ld + c_off + cg * V) = v;
+    }
+}
+
+template <typename T>
+__global__ void copy_channels_kernel(const T* __restrict__ x, T* __restrict__ y, long rows, int C, int x_ld,
+                                     int y_ld) {
+    constexpr int V = Chunk<T>::N;
+    const int nch = C / V;
+    const long total = rows * nch;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % nch);
+        const long row = i / nch;
+        *reinterpret_cast<u32x4*>(y + row * y_ld + cg * V) = *reinterpret_cast<const u32x4*>(x + row * x_ld + cg * V);
+    }
+}
+
+// argmax over last dim, one wave per row, ties -> lowest index (torch CPU behaviour)
+template <typename T>
+__global__ void argmax_kernel(const T* __restrict__ x, long rows, int C, int x_ld, int64_t* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    bool nan_seen = false;
+    for (int c = lane; c < C; c += 64) {
+        const float v = (float)x[row * x_ld + c];
+        if (v != v) { if (!nan_seen) { nan_seen = true; best = v; bi = c; } continue; }
+        if (!nan_seen && (v > best || (v == best && c < bi))) { best = v; bi = c; }
+    }
+    // NaN rows follow torch: first NaN wins.  Encode as +inf for the reduction.
+    float key = nan_seen ? INFINITY : best;
+    int prio = nan_seen ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ok = __shfl_xor(key, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        const int op = __shfl_xor(prio, o, 64);
+        const bool take = (op > prio) || (op == prio && (ok > key || (ok == key && oi < bi)));
+        if (take) { key = ok; bi = oi; prio = op; }
+    }
+    if (lane == 0) out[row] = bi == 0x7fffffff ? 0 : bi;
+}
+
+}  // namespace tlxmi
+
+using namespace tlxmi;
+
+#define DT_OK(dt) ((dt) == TLXMI_F16 || (dt) == TLXMI_F32)
+#define VECN(dt) (16 / (int)elt_size(dt))
+
+extern "C" int tlxmi_nchw_to_nhwc(const void* src, int sdt, void* dst, int ddt, int N, int C, int H, int W, int Cpad,
+                                  void* stream) {
+    TLXMI_REQUIRE(src && dst, TLXMI_ERR_BAD_ARG, "nchw_to_nhwc: null buffer");
+    TLXMI_REQUIRE(DT_OK(sdt) && DT_OK(ddt), TLXMI_ERR_BAD_ARG, "nchw_to_nhwc: bad dtype");
+    TLXMI_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && Cpad >= C, TLXMI_ERR_BAD_ARG, "nchw_to_nhwc: bad extent");
+    TLXMI_REQUIRE(Cpad % VECN(ddt) == 0 && aligned16(dst), TLXMI_ERR_ALIGNMENT,
+                  "nchw_to_nhwc: Cpad=%d must be a whole number of 16-byte chunks", Cpad);
+    const long work = (long)N * H * W * (Cpad / VECN(ddt));
+    dim3 g(grid_for(work)), b(256);
+    hipStream_t st = as_stream(stream);
+    if (sdt == TLXMI_F32 && ddt == TLXMI_F16)
+        hipLaunchKernelGGL((nchw_to_nhwc_kernel<float, half_t>), g, b, 0, st, (const float*)src, (half_t*)dst, N, C, H, W, Cpad);
+    else if (sdt == TLXMI_F32 && ddt == TLXMI_F32)
+        hipLaunchKernelGGL((nchw_to_nhwc_kernel<float, float>), g, b, 0, st, (const float*)src, (float*)dst, N, C, H, W, Cpad);
+    else if (sdt == TLXMI_F16 && ddt == TLXMI_F16)
+        hipLaunchKernelGGL((nchw_to_nhwc_kernel<half_t, half_t>), g, b, 0, st, (const half_t*)src, (half_t*)dst, N, C, H, W, Cpad);
+    else
+        hipLaunchKernelGGL((nchw_to_nhwc_kernel<half_t, float>), g, b, 0, st, (const half_t*)src, (float*)dst, N, C, H, W, Cpad);
+    return check_launch("nchw_to_nhwc");
+}
+
+extern "C" int tlxmi_nhwc_to_nchw(const void* src, int sdt, int ld, void* dst, int ddt, int N, int C, int H, int W,
+                                  void* stream) {
+    TLXMI_REQUIRE(src && dst, TLXMI_ERR_BAD_ARG, "nhwc_to_nchw: null buffer");
+    TLXMI_REQUIRE(DT_OK(sdt) && DT_OK(ddt), TLXMI_ERR_BAD_ARG, "nhwc_to_nchw: bad dtype");
+    TLXMI_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && ld >= C, TLXMI_ERR_BAD_ARG, "nhwc_to_nchw: bad extent");
+    const long work = (long)N * C * H * W;
+    dim3 g(grid_for(work)), b(256);
+    hipStream_t st = as_stream(stream);
+    if (sdt == TLXMI_F16 && ddt == TLXMI_F32)
+        hipLaunchKernelGGL((nhwc_to_nchw_kernel<half_t, float>), g, b, 0, st, (const half_t*)src, ld, (float*)dst, N, C, H, W);
+    else if (sdt == TLXMI_F32 && ddt == TLXMI_F32)
+        hipLaunchKernelGGL((nhwc_to_nchw_kernel<float, float>), g, b, 0, st, (const float*)src, ld, (float*)dst, N, C, H, W);
+    else if (sdt == TLXMI_F16 && ddt == TLXMI_F16)
+        hipLaunchKernelGGL((nhwc_to_nchw_kernel<half_t, half_t>), g, b, 0, st, (const half_t*)src, ld, (half_t*)dst, N, C, H, W);
+    else
+        hipLaunchKernelGGL((nhwc_to_nchw_kernel<float, half_t>), g, b, 0, st, (const float*)src, ld, (half_t*)dst, N, C, H, W);
+    return check_launch("nhwc_to_nchw");
+}
+
+extern "C" int tlxmi_fold_bn(const float* gamma, const float* beta, const float* mean, const float* var,
+                             const float* cbias, float eps, int C, float* scale, float* shift, void* stream) {
+    TLXMI_REQUIRE(scale && shift && C > 0, TLXMI_ERR_BAD_ARG, "fold_bn: bad argument");
+    hipLaunchKernelGGL(fold_bn_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), gamma, beta, mean, var,
+                       cbias, eps, C, scale, shift);
+    return check_launch("fold_bn");
+}
+
+#define REQUIRE_CHUNKED(name, dt, C, ...)                                                             \
+    do {                                                                                              \
+        TLXMI_REQUIRE(DT_OK(dt), TLXMI_ERR_BAD_ARG, name ": bad dtype");                              \
+        TLXMI_REQUIRE((C) > 0 && (C) % VECN(dt) == 0, TLXMI_ERR_ALIGNMENT,                            \
+                      name ": C=%d must be a whole number of 16-byte chunks", (C));                   \
+        const int lds_[] = {__VA_ARGS__};                                                             \
+        for (int ld_ : lds_)                                                                          \
+            TLXMI_REQUIRE(ld_ >= (C) && ld_ % VECN(dt) == 0, TLXMI_ERR_ALIGNMENT, name ": bad pixel stride %d", ld_); \
+    } while (0)
+
+extern "C" int tlxmi_maxpool2d(const void* x, void* y, int dt, int N, int H, int W, int C, int x_ld, int y_ld, int R,
+                               int S, int sh, int sw, int ph, int pw, int Ho, int Wo, void* stream) {
+    TLXMI_REQUIRE(x && y, TLXMI_ERR_BAD_ARG, "maxpool2d: null buffer");
+    REQUIRE_CHUNKED("maxpool2d", dt, C, x_ld, y_ld);
+    TLXMI_REQUIRE(aligned16(x) && aligned16(y), TLXMI_ERR_ALIGNMENT, "maxpool2d: buffers must be 16-byte aligned");
+    TLXMI_REQUIRE(N > 0 && H > 0 && W > 0 && R > 0 && S > 0 && sh > 0 && sw > 0 && ph >= 0 && pw >= 0, TLXMI_ERR_BAD_ARG,
+                  "maxpool2d: bad extent");
+    TLXMI_REQUIRE(ph < R && pw < S, TLXMI_ERR_BAD_ARG, "maxpool2d: padding must be smaller than the window");
+    TLXMI_REQUIRE(Ho == (H + 2 * ph - R) / sh + 1 && Wo == (W + 2 * pw - S) / sw + 1, TLXMI_ERR_BAD_ARG,
+                  "maxpool2d: output extent mismatch");
+    const long work = (long)N * Ho * Wo * (C / VECN(dt));
+    dim3 g(grid_for(work)), b(256);
+    if (dt == TLXMI_F16)
+        hipLaunchKernelGGL((maxpool_kernel<half_t>), g, b, 0, as_stream(stream), (const half_t*)x, (half_t*)y, N, H, W, C, x_ld, y_ld, R, S, sh, sw, ph, pw, Ho, Wo);
+    else
+        hipLaunchKernelGGL((maxpool_kernel<float>), g, b, 0, as_stream(stream), (const float*)x, (float*)y, N, H, W, C, x_ld, y_ld, R, S, sh, sw, ph, pw, Ho, Wo);
+    return check_launch("maxpool2d");
+}
+
+extern "C" int tlxmi_global_avgpool(const void* x, void* y, int dt, int N, int HW, int C, int x_ld, int y_ld,
+                                    void* stream) {
+    TLXMI_REQUIRE(x && y && N > 0 && HW > 0, TLXMI_ERR_BAD_ARG, "global_avgpool: bad argument");
+    REQUIRE_CHUNKED("global_avgpool", dt, C, x_ld, y_ld);
+    TLXMI_REQUIRE(aligned16(x) && aligned16(y), TLXMI_ERR_ALIGNMENT, "global_avgpool: buffers must be 16-byte aligned");
+    const long work = (long)N * (C / VECN(dt));
+    dim3 g(grid_for(work, 64)), b(64);
+    if (dt == TLXMI_F16)
+        hipLaunchKernelGGL((global_avgpool_kernel<half_t>), g, b, 0, as_stream(stream), (const half_t*)x, (half_t*)y, N, HW, C, x_ld, y_ld);
+    else
+        hipLaunchKernelGGL((global_avgpool_kernel<float>), g, b, 0, as_stream(stream), (const float*)x, (float*)y, N, HW, C, x_ld, y_ld);
+    return check_launch("global_avgpool");
+}
+
+extern "C" int tlxmi_affine_act(const void* x, const float* scale, const float* shift, const void* res, void* y,
+                                int dt, int64_t rows, int C, int x_ld, int res_ld, int y_ld, int act, float ap,
+                                uint32_t flags, void* stream) {
+    TLXMI_REQUIRE(x && y && rows > 0, TLXMI_ERR_BAD_ARG, "affine_act: bad argument");
+    REQUIRE_CHUNKED("affine_act", dt, C, x_ld, y_ld);
+    TLXMI_REQUIRE(!res || (res_ld >= C && res_ld % VECN(dt) == 0 && aligned16(res)), TLXMI_ERR_ALIGNMENT, "affine_act: bad residual stride");
+    TLXMI_REQUIRE(aligned16(x) && aligned16(y), TLXMI_ERR_ALIGNMENT, "affine_act: buffers must be 16-byte aligned");
+    TLXMI_REQUIRE(act >= TLXMI_ACT_NONE && act <= TLXMI_ACT_SILU, TLXMI_ERR_BAD_ARG, "affine_act: bad act");
+    const long work = rows * (C / VECN(dt));
+    dim3 g(grid_for(work)), b(256);
+    if (dt == TLXMI_F16)
+        hipLaunchKernelGGL((affine_act_kernel<half_t>), g, b, 0, as_stream(stream), (const half_t*)x, scale, shift, (const half_t*)res, (half_t*)y, (long)rows, C, x_ld, res_ld, y_ld, act, ap, flags);
+    else
+        hipLaunchKernelGGL((affine_act_kernel<float>), g, b, 0, as_stream(stream), (const float*)x, scale, shift, (const float*)res, (float*)y, (long)rows, C, x_ld, res_ld, y_ld, act, ap, flags);
+    return check_launch("affine_act");
+}
+
+extern "C" int tlxmi_dwconv2d(const tlxmi_dwconv2d_desc* d, const void* x, const void* w, const float* scale,
+                              const float* shift, void* y, void* stream) {
+    TLXMI_REQUIRE(d && x && w && y, TLXMI_ERR_BAD_ARG, "dwconv2d: null argument");
+    REQUIRE_CHUNKED("dwconv2d", d->dtype, d->C, d->x_ld, d->y_ld);
+    TLXMI_REQUIRE(aligned16(x) && aligned16(y) && aligned16(w), TLXMI_ERR_ALIGNMENT, "dwconv2d: buffers must be 16-byte aligned");
+    TLXMI_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->R > 0 && d->S > 0 && d->stride_h > 0 && d->stride_w > 0 &&
+                      d->dil_h > 0 && d->dil_w > 0 && d->pad_h >= 0 && d->pad_w >= 0,
+                  TLXMI_ERR_BAD_ARG, "dwconv2d: bad extent");
+    const int Ho = (d->H + 2 * d->pad_h - d->dil_h * (d->R - 1) - 1) / d->stride_h + 1;
+    const int Wo = (d->W + 2 * d->pad_w - d->dil_w * (d->S - 1) - 1) / d->stride_w + 1;
+    TLXMI_REQUIRE(Ho == d->Ho && Wo == d->Wo && Ho > 0 && Wo > 0, TLXMI_ERR_BAD_ARG, "dwconv2d: output extent mismatch");
+    TLXMI_REQUIRE(d->act >= TLXMI_ACT_NONE && d->act <= TLXMI_ACT_SILU, TLXMI_ERR_BAD_ARG, "dwconv2d: bad act");
+    const long work = (long)d->N * Ho * Wo * (d->C / VECN(d->dtype));
+    dim3 g(grid_for(work)), b(256);
+    if (d->dtype == TLXMI_F16)
+        hipLaunchKernelGGL((dwconv_kernel<half_t>), g, b, 0, as_stream(stream), (const half_t*)x, (const half_t*)w, scale, shift, (half_t*)y, *d);
+    else
+        hipLaunchKernelGGL((dwconv_kernel<float>), g, b, 0, as_stream(stream), (const float*)x, (const float*)w, scale, shift, (float*)y, *d);
+    return check_launch("dwconv2d");
+}
+
+extern "C" int tlxmi_upsample2x_nearest(const void* x, void* y, int dt, int N, int H, int W, int C, int x_ld, int y_ld,
+                                        int c_off, void* stream) {
+    TLXMI_REQUIRE(x && y && N > 0 && H > 0 && W > 0, TLXMI_ERR_BAD_ARG, "upsample2x: bad argument");
+    REQUIRE_CHUNKED("upsample2x", dt, C, x_ld);
+    TLXMI_REQUIRE(c_off >= 0 && y_ld >= c_off + C && y_ld % VECN(dt) == 0 && c_off % VECN(dt) == 0, TLXMI_ERR_ALIGNMENT,
+                  "upsample2x: bad destination window");
+    TLXMI_REQUIRE(aligned16(x) && aligned16(y), TLXMI_ERR_ALIGNMENT, "upsample2x: buffers must be 16-byte aligned");
+    const long work = (long)N * 4 * H * W * (C / VECN(dt));
+    dim3 g(grid_for(work)), b(256);
+    if (dt == TLXMI_F16)
+        hipLaunchKernelGGL((upsample2x_kernel<half_t>), g, b, 0, as_stream(stream), (const half_t*)x, (half_t*)y, N, H, W, C, x_ld, y_ld, c_off);
+    else
+        hipLaunchKernelGGL((upsample2x_kernel<float>), g, b, 0, as_stream(stream), (const float*)x, (float*)y, N, H, W, C, x_ld, y_ld, c_off);
+    return check_launch("upsample2x");
+}
+
+extern "C" int tlxmi_copy_channels(const void* x, void* y, int dt, int64_t rows, int C, int x_ld, int y_ld,
+                                   void* stream) {
+    TLXMI_REQUIRE(x && y && rows > 0, TLXMI_ERR_BAD_ARG, "copy_channels: bad argument");
+    REQUIRE_CHUNKED("copy_channels", dt, C, x_ld, y_ld);
+    TLXMI_REQUIRE(aligned16(x) && aligned16(y), TLXMI_ERR_ALIGNMENT, "copy_channels: buffers must be 16-byte aligned");
+    const long work = rows * (C / VECN(dt));
+    dim3 g(grid_for(work)), b(256);
+    if (dt == TLXMI_F16)
+        hipLaunchKernelGGL((copy_channels_kernel<half_t>), g, b, 0, as_stream(stream), (const half_t*)x, (half_t*)y, (long)rows, C, x_ld, y_ld);
+    else
+        hipLaunchKernelGGL((copy_channels_kernel<float>), g, b, 0, as_stream(stream), (const float*)x, (float*)y, (long)rows, C, x_ld, y_ld);
+    return check_launch("copy_channels");
+}
+
+extern "C" int tlxmi_argmax_lastdim(const void* x, int dt, int64_t rows, int C, int x_ld, int64_t* out, void* stream) {
+    TLXMI_REQUIRE(x && out && rows > 0 && C > 0 && x_ld >= C, TLXMI_ERR_BAD_ARG, "argmax: bad argument");
+    TLXMI_REQUIRE(DT_OK(dt), TLXMI_ERR_BAD_ARG, "argmax: bad dtype");
+    dim3 g((unsigned)((rows + 3) / 4)), b(256);
+    if (dt == TLXMI_F16)
+        hipLaunchKernelGGL((argmax_kernel<half_t>), g, b, 0, as_stream(stream), (const half_t*)x, (long)rows, C, x_ld, out);
+    else
+        hipLaunchKernelGGL((argmax_kernel<float>), g, b, 0, as_stream(stream), (const float*)x, (long)rows, C, x_ld, out);
+    return check_launch("argmax");
+}

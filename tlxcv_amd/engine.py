@@ -1,0 +1,363 @@
+"""Functional host layer over the C-ABI: torch tensors in, torch tensors out, HIP kernels inside.
+
+PyTorch-ROCm is used here for device memory, streams and nothing else: every function below
+hands `tensor.data_ptr()` and the current HIP stream to libtlxmi.so.  Activations are NHWC
+(`(N, H, W, C)` contiguous, or `(rows, C)` token matrices); fp16 is the throughput dtype, fp32 the
+parity dtype.  There is deliberately no CPU branch: a CPU tensor raises.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_GELU, ACT_HARDSIGMOID, ACT_HARDSWISH, ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_RELU6,
+                   ACT_SIGMOID, ACT_SILU, EPI_RES_AFTER_ACT, F16, F32)
+
+EPI_RES_BCAST_N = 2
+
+_precision = torch.float16
+
+# Optional per-launch probe (bench.py): when a list is installed, every implicit-GEMM launch appends
+# (start_event, end_event, algorithmic_bytes, flops) recorded on the launch stream.
+_probe = None
+
+
+def set_probe(lst):
+    global _probe
+    _probe = lst
+
+
+def set_precision(p):
+    """'fp16' (throughput: fp16 storage, fp32 accumulate) or 'fp32' (parity: exact fp32)."""
+    global _precision
+    if p in ("fp16", "float16", torch.float16):
+        _precision = torch.float16
+
+# Optional per-launch probe (bench.py): when a list is installed, every implicit-GEMM launch appends
+# (start_event, end_event, algorithmic_bytes, flops) recorded on the launch stream.
+_probe = None
+
+
+def set_probe(lst):
+    global _probe
+    _probe = lst
+    elif p in ("fp32", "float32", torch.float32):
+        _precision = torch.float32
+    else:
+        raise ValueError(f"unknown precision {p!r}")
+
+
+def precision():
+    return _precision
+
+
+def dt_code(dtype):
+    if dtype == torch.float16:
+        return F16
+    if dtype == torch.float32:
+        return F32
+    raise RuntimeError(f"tlxcv_amd: unsupported dtype {dtype} (fp16 or fp32 only)")
+
+
+def vec(dtype):
+    return 8 if dtype == torch.float16 else 4
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def need_gpu(t, what="tensor"):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"tlxcv_amd: {what} must be a torch.Tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"tlxcv_amd: {what} lives on {t.device}; this engine only runs on an MI355X (HIP) device "
+            "and has no CPU path — move the model and inputs to 'cuda'.")
+    return t
+
+
+def _f32(t):
+    if t is None:
+        return None
+    need_gpu(t, "parameter")
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        t = t.detach().to(torch.float32).contiguous()
+    return t.detach()
+
+
+# ---------------------------------------------------------------------------------------------
+# layout
+# ---------------------------------------------------------------------------------------------
+def nchw_to_nhwc(x, dtype=None, cpad=None):
+    """(N,C,H,W) contiguous -> (N,H,W,Cpad) `dtype`; extra channels are zero."""
+    need_gpu(x, "input")
+    dtype = dtype or _precision
+    N, Cc, H, W = x.shape
+    v = vec(dtype)
+    cpad = cpad or (Cc + v - 1) // v * v
+    if x.dtype not in (torch.float16, torch.float32):
+        x = x.float()
+    x = x.contiguous()
+    y = torch.empty((N, H, W, cpad), dtype=dtype, device=x.device)
+    _lib.call("tlxmi_nchw_to_nhwc", _p(x), dt_code(x.dtype), _p(y), dt_code(dtype), N, Cc, H, W, cpad, _stream())
+    return y
+
+
+def nhwc_to_nchw(x, C_true=None, dtype=None):
+    """(N,H,W,ld) -> contiguous (N,C,H,W)."""
+    need_gpu(x)
+    N, H, W, ld = x.shape
+    Cc = C_true or ld
+    dtype = dtype or x.dtype
+    y = torch.empty((N, Cc, H, W), dtype=dtype, device=x.device)
+    _lib.call("tlxmi_nhwc_to_nchw", _p(x), dt_code(x.dtype), ld, _p(y), dt_code(dtype), N, Cc, H, W, _stream())
+    return y
+
+
+# ---------------------------------------------------------------------------------------------
+# filters / batch-norm folding
+# ---------------------------------------------------------------------------------------------
+class PackedFilter:
+    """A conv / linear weight in the K-contiguous, padded image tlxmi_conv2d reads."""
+
+    def __init__(self, w_oihw, dtype):
+        w = _f32(w_oihw)
+        if w.dim() == 2:  # Linear weight [out, in]
+            w = w.reshape(w.shape[0], w.shape[1], 1, 1)
+        self.Cout, self.Cin, self.R, self.S = w.shape
+        self.dtype = dtype
+        v = vec(dtype)
+        self.Cin_pad = (self.Cin + v - 1) // v * v
+        nbytes = _lib.load().tlxmi_packed_filter_bytes(self.Cout, self.Cin, self.R, self.S, dt_code(dtype))
+        self.buf = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+        _lib.call("tlxmi_pack_filter", _p(w), _p(self.buf), self.Cout, self.Cin, self.R, self.S, dt_code(dtype),
+                  _stream())
+
+
+def fold_bn(gamma, beta, mean, var, eps, conv_bias=None):
+    """Eval-mode BatchNorm (+ optional conv bias) -> per-channel fp32 (scale, shift)."""
+    ref = next(t for t in (gamma, beta, mean, var, conv_bias) if t is not None)
+    Cn = ref.numel()
+    g, b, m, v, cb = (_f32(t) for t in (gamma, beta, mean, var, conv_bias))
+    scale = torch.empty(Cn, dtype=torch.float32, device=ref.device)
+    shift = torch.empty(Cn, dtype=torch.float32, device=ref.device)
+    _lib.call("tlxmi_fold_bn", _p(g), _p(b), _p(m), _p(v), _p(cb), float(eps), Cn, _p(scale), _p(shift), _stream())
+    return scale, shift
+
+
+# ---------------------------------------------------------------------------------------------
+# conv / linear
+# ---------------------------------------------------------------------------------------------
+def _pair(v):
+    return (v, v) if isinstance(v, int) else (int(v[0]), int(v[1]))
+
+
+def conv2d(x, pk, stride=1, padding=0, dilation=1, scale=None, shift=None, res=None, act=ACT_NONE,
+           act_param=0.0, res_after_act=False, out=None, out_ld=None, y_nstride=0, res_nstride=0,
+           res_bcast=False, res_ld=None):
+    """x (N,H,W,C>=Cin_pad...) NHWC -> y (N,Ho,Wo,Cout).  `out` may be a wider/pre-offset buffer."""
+    need_gpu(x, "input")
+    N, H, W, ld = x.shape
+    if x.dtype != pk.dtype:
+        raise RuntimeError(f"conv2d: input dtype {x.dtype} != packed filter dtype {pk.dtype}")
+    if ld < pk.Cin_pad:
+        raise RuntimeError(f"conv2d: input has {ld} channels, filter expects {pk.Cin} (padded {pk.Cin_pad})")
+    sh, sw = _pair(stride)
+    ph, pw = _pair(padding)
+    dh, dw = _pair(dilation)
+    Ho = (H + 2 * ph - dh * (pk.R - 1) - 1) // sh + 1
+    Wo = (W + 2 * pw - dw * (pk.S - 1) - 1) // sw + 1
+    if Ho <= 0 or Wo <= 0:
+        raise RuntimeError(f"conv2d: empty output {Ho}x{Wo} for input {H}x{W}")
+    if out is None:
+        out = torch.empty((N, Ho, Wo, pk.Cout), dtype=x.dtype, device=x.device)
+        out_ld = pk.Cout
+    elif out_ld is None:
+        out_ld = out.shape[-1]
+    d = _lib.ConvDesc(dtype=dt_code(x.dtype), N=N, H=H, W=W, C=pk.Cin_pad, Cout=pk.Cout, R=pk.R, S=pk.S,
+                      stride_h=sh, stride_w=sw, pad_h=ph, pad_w=pw, dil_h=dh, dil_w=dw, Ho=Ho, Wo=Wo,
+                      x_ld=ld, y_ld=out_ld, res_ld=(res_ld if res_ld is not None else (res.shape[-1] if res is not None else 0)),
+                      y_nstride=y_nstride, res_nstride=res_nstride, act=act, act_param=float(act_param),
+                      flags=(EPI_RES_AFTER_ACT if res_after_act else 0) | (EPI_RES_BCAST_N if res_bcast else 0))
+    if res is not None and res.dtype != x.dtype:
+        raise RuntimeError("conv2d: residual dtype mismatch")
+    if _probe is None:
+        _lib.call("tlxmi_conv2d", C.byref(d), _p(x), _p(pk.buf), _p(scale), _p(shift), _p(res), _p(out), _stream())
+        return out
+    es = x.element_size()
+    M = N * Ho * Wo
+    alg_bytes = (N * H * W * pk.Cin + M * pk.Cout * (2 if res is not None else 1)
+                 + pk.Cout * pk.Cin * pk.R * pk.S) * es
+    flops = 2 * M * pk.Cout * pk.Cin * pk.R * pk.S
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    _lib.call("tlxmi_conv2d", C.byref(d), _p(x), _p(pk.buf), _p(scale), _p(shift), _p(res), _p(out), _stream())
+    e1.record()
+    _probe.append((e0, e1, alg_bytes, flops))
+    return out
+
+
+def linear(x, pk, bias=None, res=None, act=ACT_NONE, out=None):
+    """x (..., K) -> (..., Cout): the H=W=1 case of the implicit GEMM, bias as epilogue shift."""
+    need_gpu(x, "input")
+    shp = x.shape
+    if not x.is_contiguous():
+        x = x.contiguous()
+    rows = x.numel() // shp[-1]
+    x4 = x.view(rows, 1, 1, shp[-1])
+    r4 = None
+    if res is not None:
+        if not res.is_contiguous():
+            res = res.contiguous()
+        r4 = res.view(rows, 1, 1, pk.Cout)
+    o4 = None
+    if out is not None:
+        o4 = out.view(rows, 1, 1, pk.Cout)
+    y = conv2d(x4, pk, shift=bias, res=r4, act=act, out=o4)
+    return y.view(*shp[:-1], pk.Cout)
+
+
+def dwconv2d(x, w_rsc, stride=1, padding=0, dilation=1, scale=None, shift=None, act=ACT_NONE, act_param=0.0):
+    need_gpu(x, "input")
+    N, H, W, Cc = x.shape
+    R, S, Cw = w_rsc.shape
+    sh, sw = _pair(stride)
+    ph, pw = _pair(padding)
+    dh, dw = _pair(dilation)
+    Ho = (H + 2 * ph - dh * (R - 1) - 1) // sh + 1
+    Wo = (W + 2 * pw - dw * (S - 1) - 1) // sw + 1
+    y = torch.empty((N, Ho, Wo, Cc), dtype=x.dtype, device=x.device)
+    d = _lib.DwConvDesc(dtype=dt_code(x.dtype), N=N, H=H, W=W, C=Cw, R=R, S=S, stride_h=sh, stride_w=sw, pad_h=ph,
+                        pad_w=pw, dil_h=dh, dil_w=dw, Ho=Ho, Wo=Wo, x_ld=Cc, y_ld=Cc, act=act,
+                        act_param=float(act_param))
+    _lib.call("tlxmi_dwconv2d", C.byref(d), _p(x), _p(w_rsc), _p(scale), _p(shift), _p(y), _stream())
+    return y
+
+
+# ---------------------------------------------------------------------------------------------
+# pooling / elementwise / norm
+# ---------------------------------------------------------------------------------------------
+def maxpool2d(x, kernel, stride, padding):
+    need_gpu(x, "input")
+    N, H, W, Cc = x.shape
+    R, S = _pair(kernel)
+    sh, sw = _pair(stride)
+    ph, pw = _pair(padding)
+    Ho = (H + 2 * ph - R) // sh + 1
+    Wo = (W + 2 * pw - S) // sw + 1
+    y = torch.empty((N, Ho, Wo, Cc), dtype=x.dtype, device=x.device)
+    _lib.call("tlxmi_maxpool2d", _p(x), _p(y), dt_code(x.dtype), N, H, W, Cc, Cc, Cc, R, S, sh, sw, ph, pw, Ho, Wo,
+              _stream())
+    return y
+
+
+def global_avgpool(x):
+    """(N,H,W,C) or (N,L,C) -> (N,C) mean over the middle axes."""
+    need_gpu(x, "input")
+    N, Cc = x.shape[0], x.shape[-1]
+    HW = x.numel() // (N * Cc)
+    y = torch.empty((N, Cc), dtype=x.dtype, device=x.device)
+    _lib.call("tlxmi_global_avgpool", _p(x), _p(y), dt_code(x.dtype), N, HW, Cc, Cc, Cc, _stream())
+    return y
+
+
+def affine_act(x, scale=None, shift=None, res=None, act=ACT_NONE, act_param=0.0, res_after_act=False, out=None):
+    """y = act(x*scale[c] + shift[c] (+res)) over the last axis."""
+    need_gpu(x, "input")
+    if not x.is_contiguous():
+        x = x.contiguous()
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    y = out if out is not None else torch.empty_like(x)
+    if res is not None and not res.is_contiguous():
+        res = res.contiguous()
+    _lib.call("tlxmi_affine_act", _p(x), _p(scale), _p(shift), _p(res), _p(y), dt_code(x.dtype), rows, Cc, Cc,
+              Cc if res is not None else 0, Cc, act, float(act_param), EPI_RES_AFTER_ACT if res_after_act else 0,
+              _stream())
+    return y
+
+
+def layernorm(x, gamma, beta, eps):
+    need_gpu(x, "input")
+    if not x.is_contiguous():
+        x = x.contiguous()
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    y = torch.empty_like(x)
+    _lib.call("tlxmi_layernorm", _p(x), _p(gamma), _p(beta), _p(y), dt_code(x.dtype), rows, Cc, Cc, Cc, float(eps),
+              _stream())
+    return y
+
+
+def attention(qkv, heads, scale, bias=None, mask=None):
+    """qkv (B, N, 3*heads*hd) packed as [3][heads][hd] -> (B, N, heads*hd)."""
+    need_gpu(qkv, "qkv")
+    if not qkv.is_contiguous():
+        qkv = qkv.contiguous()
+    B, N, C3 = qkv.shape
+    hd = C3 // (3 * heads)
+    out = torch.empty((B, N, heads * hd), dtype=qkv.dtype, device=qkv.device)
+    nW = mask.shape[0] if mask is not None else 0
+    d = _lib.AttnDesc(dtype=dt_code(qkv.dtype), B=B, Ntok=N, heads=heads, hd=hd, scale=float(scale), nW=nW)
+    _lib.call("tlxmi_attention", C.byref(d), _p(qkv), _p(bias), _p(mask), _p(out), _stream())
+    return out
+
+
+def window_partition(x, ws, shift):
+    """(B,H,W,C) -> (B*nW, ws*ws, C) with the cyclic shift folded in."""
+    need_gpu(x, "input")
+    B, H, W, Cc = x.shape
+    y = torch.empty((B * (H // ws) * (W // ws), ws * ws, Cc), dtype=x.dtype, device=x.device)
+    _lib.call("tlxmi_window_partition", _p(x), _p(y), dt_code(x.dtype), B, H, W, Cc, ws, shift, _stream())
+    return y
+
+
+def window_reverse(win, B, H, W, ws, shift, res=None):
+    need_gpu(win, "input")
+    Cc = win.shape[-1]
+    y = torch.empty((B, H, W, Cc), dtype=win.dtype, device=win.device)
+    _lib.call("tlxmi_window_reverse", _p(win), _p(res), _p(y), dt_code(win.dtype), B, H, W, Cc, ws, shift, _stream())
+    return y
+
+
+def patch_merge_gather(x):
+    need_gpu(x, "input")
+    B, H, W, Cc = x.shape
+    y = torch.empty((B, H // 2, W // 2, 4 * Cc), dtype=x.dtype, device=x.device)
+    _lib.call("tlxmi_patch_merge_gather", _p(x), _p(y), dt_code(x.dtype), B, H, W, Cc, _stream())
+    return y
+
+
+def upsample2x_into(x, out, c_off):
+    need_gpu(x, "input")
+    N, H, W, Cc = x.shape
+    _lib.call("tlxmi_upsample2x_nearest", _p(x), _p(out), dt_code(x.dtype), N, H, W, Cc, Cc, out.shape[-1], c_off,
+              _stream())
+    return out
+
+
+def copy_channels_into(x, out, c_off):
+    """out[..., c_off:c_off+C] = x   (tlx.concat along channels, one pass per source)."""
+    need_gpu(x, "input")
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    es = x.element_size()
+    dst = C.c_void_p(out.data_ptr() + c_off * es)
+    _lib.call("tlxmi_copy_channels", _p(x), dst, dt_code(x.dtype), rows, Cc, Cc, out.shape[-1], _stream())
+    return out
+
+
+def argmax_lastdim(x):
+    need_gpu(x, "input")
+    if not x.is_contiguous():
+        x = x.contiguous()
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    out = torch.empty(x.shape[:-1], dtype=torch.int64, device=x.device)
+    _lib.call("tlxmi_argmax_lastdim", _p(x), dt_code(x.dtype), rows, Cc, Cc, _p(out), _stream())
+    return out

@@ -1,0 +1,555 @@
+"""`tensorlayerx.nn`-compatible layer classes whose forward runs on libtlxmi.so (MI355X only).
+
+Constructor signatures, attribute names and error behaviour follow the way the reference model
+files use TensorLayerX (call sites are cited per class).  TensorLayerX itself is
+not vendored by the reference, so its *internal* semantics are restated from its public
+documentation and marked [TLX-recalled] where they cannot be checked here:
+  - `b_init` falsy ((), False, None) => no bias; anything else => bias, zero-initialised;
+  - integer `padding` = symmetric explicit zero padding; MaxPool2d pads with -inf;
+  - BatchNorm2d epsilon 1e-5, LayerNorm epsilon 1e-5 unless given; GELU is the exact erf form;
+  - conv filters are kept OIHW, Linear weights (in_features, out_features).
+Tensors are real `torch.Tensor`s (reference model code calls torch methods on them directly,
+e.g. vision_transformer.py:113-120).  With data_format='channels_first' a layer accepts and
+returns logical NCHW tensors; physically they are NHWC (torch channels_last strides), which is
+what the HIP kernels read, so chained layers never transpose.
+Eval-mode forward only: training (batch statistics, dropout masks, autograd) is out of scope.
+"""
+import math
+
+import numpy as np
+import torch
+
+from ... import engine as E
+from . import initializers  # noqa: F401  (re-exported as nn.initializers)
+from .initializers import Constant, TruncatedNormal, xavier_uniform, he_normal, str_to_init  # noqa: F401
+
+__all__ = [
+    "Module", "Sequential", "ModuleList", "Parameter", "GroupConv2d", "Conv2d", "BatchNorm2d", "BatchNorm",
+    "LayerNorm", "Linear", "MaxPool2d", "AdaptiveAvgPool2d", "AdaptiveAvgPool1d", "Dropout", "ReLU", "ReLU6",
+    "LeakyReLU", "Hardswish", "HardSigmoid", "Sigmoid", "Softmax", "GELU", "Flatten", "UpSampling2d", "Identity",
+]
+
+
+def Parameter(data=None, name=None, requires_grad=False):
+    """nn.Parameter(data=...) as used at vision_transformer.py:295."""
+    if not isinstance(data, torch.Tensor):
+        data = torch.as_tensor(np.asarray(data), dtype=torch.float32)
+    return torch.nn.Parameter(data.detach().to(torch.float32), requires_grad=False)
+
+
+class Module(torch.nn.Module):
+    """TensorLayerX-style module: `name`, `is_train`, set_eval()/set_train(), all_weights,
+    load_weights/save_weights, sub-modules kept in plain Python lists are adopted
+    (darknet.py:270-297, yolov3.py:210,306)."""
+
+    def __init__(self, name=None, act=None, *args, **kwargs):
+        super().__init__()
+        self.name = name
+        self.is_train = True
+        self._engine_cache = {}
+
+    # -- TLX surface -------------------------------------------------------------------------
+    def _adopt_lists(self):
+        for m in list(self.modules_shallow()):
+            for k, v in list(vars(m).items()):
+                if isinstance(v, (list, tuple)) and v and all(isinstance(e, torch.nn.Module) for e in v):
+                    for i, e in enumerate(v):
+                        key = f"{k}_{i}"
+                        if key not in m._modules:
+                            m.add_module(key, e)
+
+    def modules_shallow(self):
+        seen, stack = set(), [self]
+        while stack:
+            m = stack.pop()
+            if id(m) in seen:
+                continue
+            seen.add(id(m))
+            yield m
+            stack.extend(m._modules.values())
+            for v in vars(m).values():
+                if isinstance(v, (list, tuple)):
+                    stack.extend(e for e in v if isinstance(e, torch.nn.Module))
+
+    def set_eval(self):
+        self._adopt_lists()
+        for m in self.modules():
+            m.training = False
+            if isinstance(m, Module):
+                m.is_train = False
+        return self
+
+    def set_train(self):
+        self._adopt_lists()
+        for m in self.modules():
+            m.training = True
+            if isinstance(m, Module):
+                m.is_train = True
+                m._engine_cache.clear()
+        return self
+
+    def eval(self):
+        return self.set_eval()
+
+    def train(self, mode=True):
+        return self.set_train() if mode else self.set_eval()
+
+    def _apply(self, fn, *a, **k):
+        self._adopt_lists()
+        for m in self.modules():
+            if isinstance(m, Module):
+                m._engine_cache.clear()
+        return super()._apply(fn, *a, **k)
+
+    @property
+    def all_weights(self):
+        self._adopt_lists()
+        return list(self.parameters()) + [b for b in self.buffers()]
+
+    @property
+    def trainable_weights(self):
+        self._adopt_lists()
+        return list(self.parameters())
+
+    def _get_weights(self, var_name, shape, init=None, trainable=True, order=False):
+        init = str_to_init(init) if isinstance(init, str) else (init or Constant(0.0))
+        p = Parameter(data=init(shape=tuple(shape)))
+        if trainable:
+            self.register_parameter(var_name, p)
+        else:
+            self.register_buffer(var_name, p.data)
+            p = getattr(self, var_name)
+        return p
+
+    def str_to_init(self, s):
+        return str_to_init(s)
+
+    def register_parameter(self, name=None, param=None):  # keyword form: vision_transformer.py:296
+        return super().register_parameter(name, param)
+
+    def save_weights(self, file_path, format=None):
+        """npz_dict-style checkpoint: {dotted name: array} for parameters and buffers."""
+        self._adopt_lists()
+        np.savez(file_path, **{k: v.detach().float().cpu().numpy() for k, v in self.state_dict().items()})
+
+    def load_weights(self, file_path, format=None, in_order=True, skip=False):
+        self._adopt_lists()
+        data = np.load(file_path, allow_pickle=False)
+        sd = self.state_dict()
+        missing = [k for k in sd if k not in data.files]
+        if missing and not skip:
+            raise KeyError(f"load_weights: {len(missing)} entries missing from {file_path}, e.g. {missing[:3]}")
+        with torch.no_grad():
+            for k, t in sd.items():
+                if k in data.files:
+                    a = torch.as_tensor(data[k])
+                    if tuple(a.shape) != tuple(t.shape):
+                        raise ValueError(f"load_weights: {k} has shape {tuple(a.shape)}, expected {tuple(t.shape)}")
+                    t.copy_(a.to(t.dtype))
+        for m in self.modules():
+            if isinstance(m, Module):
+                m._engine_cache.clear()
+
+    def load_dict(self, named, strict=True):
+        """Assign {dotted name: numpy/torch array}; used by tests and benches with seeded recipes."""
+        self._adopt_lists()
+        sd = self.state_dict()
+        unknown = [k for k in named if k not in sd]
+        missing = [k for k in sd if k not in named]
+        if strict and (unknown or missing):
+            raise KeyError(f"load_dict: unknown={unknown[:4]} missing={missing[:4]}")
+        with torch.no_grad():
+            for k, v in named.items():
+                if k in sd:
+                    a = torch.as_tensor(np.asarray(v)) if not isinstance(v, torch.Tensor) else v
+                    if tuple(a.shape) != tuple(sd[k].shape):
+                        raise ValueError(f"load_dict: {k} shape {tuple(a.shape)} != {tuple(sd[k].shape)}")
+                    sd[k].copy_(a.to(sd[k].dtype))
+        for m in self.modules():
+            if isinstance(m, Module):
+                m._engine_cache.clear()
+
+    def _require_eval(self):
+        if self.is_train:
+            raise NotImplementedError(
+                f"{type(self).__name__}: training-mode forward is out of scope for the MI355X inference "
+                "engine — call model.set_eval() first (tasks/image_classification.py:21 does).")
+
+    def _cached(self, key, build):
+        k = (key, E.precision())
+        v = self._engine_cache.get(k)
+        if v is None:
+            v = build()
+            self._engine_cache[k] = v
+        return v
+
+
+class Identity(Module):
+    def forward(self, x):
+        return x
+
+
+class Sequential(Module):
+    """Accepts a list (resnet.py:247,284) or varargs (mobilenetv1.py:65,245)."""
+
+    def __init__(self, *layers, name=None):
+        super().__init__(name=name)
+        if len(layers) == 1 and isinstance(layers[0], (list, tuple)):
+            layers = layers[0]
+        for i, l in enumerate(layers):
+            self.add_module(str(i), l)
+
+    def __len__(self):
+        return len(self._modules)
+
+    def __iter__(self):
+        return iter(self._modules.values())
+
+    def __getitem__(self, i):
+        return list(self._modules.values())[i]
+
+    def append(self, layer):
+        self.add_module(str(len(self._modules)), layer)
+
+    def forward(self, x):
+        for l in self._modules.values():
+            x = l(x)
+        return x
+
+
+class ModuleList(torch.nn.ModuleList):
+    def __init__(self, modules=None, name=None):
+        super().__init__(modules)
+
+
+# ---------------------------------------------------------------------------------------------
+# layout helpers: logical NCHW (channels_first) <-> physical NHWC
+# ---------------------------------------------------------------------------------------------
+def as_nhwc(x, data_format="channels_first"):
+    E.need_gpu(x, "input")
+    dt = E.precision()
+    if data_format == "channels_last":
+        if x.dtype == dt and x.is_contiguous() and x.shape[-1] % E.vec(dt) == 0:
+            return x
+        return E.nchw_to_nhwc(x.permute(0, 3, 1, 2), dt)
+    v = x.permute(0, 2, 3, 1)
+    if x.dtype == dt and v.is_contiguous() and v.shape[-1] % E.vec(dt) == 0:
+        return v
+    return E.nchw_to_nhwc(x, dt)
+
+
+def from_nhwc(y, data_format="channels_first"):
+    return y if data_format == "channels_last" else y.permute(0, 3, 1, 2)
+
+
+def _tup2(v):
+    return (v, v) if isinstance(v, int) else tuple(int(a) for a in v)
+
+
+_ACTS = {}
+
+
+class _Act(Module):
+    ACT = E.ACT_NONE
+    PARAM = 0.0
+
+    def forward(self, x):
+        E.need_gpu(x, "input")
+        if x.dtype != E.precision():
+            x = x.to(E.precision())
+        if x.dim() == 4:  # keep the physical layout, run over the flat buffer
+            v = x.permute(0, 2, 3, 1)
+            if v.is_contiguous():
+                return E.affine_act(v, act=self.ACT, act_param=self.PARAM).permute(0, 3, 1, 2)
+        return E.affine_act(x.contiguous(), act=self.ACT, act_param=self.PARAM)
+
+
+class ReLU(_Act):  # resnet.py:50,138,212
+    ACT = E.ACT_RELU
+
+
+class ReLU6(_Act):
+    ACT = E.ACT_RELU6
+
+
+class Hardswish(_Act):
+    ACT = E.ACT_HARDSWISH
+
+
+class HardSigmoid(_Act):
+    ACT = E.ACT_HARDSIGMOID
+
+
+class Sigmoid(_Act):
+    ACT = E.ACT_SIGMOID
+
+
+class GELU(_Act):  # tlx.ops.GeLU, vision_transformer.py:70 — exact erf form [TLX-recalled]
+    ACT = E.ACT_GELU
+
+
+class LeakyReLU(_Act):  # darknet.py:50
+    ACT = E.ACT_LEAKY
+
+    def __init__(self, negative_slope=0.01, name=None):
+        super().__init__(name=name)
+        self.PARAM = float(negative_slope)
+
+
+class Softmax(Module):
+    def __init__(self, axis=-1, name=None):
+        super().__init__(name=name)
+        self.axis = axis
+
+    def forward(self, x):
+        E.need_gpu(x)
+        return torch.softmax(x, dim=self.axis)
+
+
+class Dropout(Module):
+    """Identity in eval mode (vision_transformer.py:80,109,111)."""
+
+    def __init__(self, p=0.5, seed=0, name=None):
+        super().__init__(name=name)
+        self.p = p
+
+    def forward(self, x):
+        if self.is_train and self.p > 0:
+            self._require_eval()
+        return x
+
+
+class Flatten(Module):  # tlx.FlattenReshape, resnet.py:232
+    def forward(self, x):
+        return x.reshape(x.shape[0], -1)
+
+
+# ---------------------------------------------------------------------------------------------
+# GroupConv2d / Conv2d
+# ---------------------------------------------------------------------------------------------
+class GroupConv2d(Module):
+    """nn.GroupConv2d(in_channels, out_channels, kernel_size, stride, padding, dilation, n_group,
+    b_init, W_init, data_format, act, name) — call sites resnet.py:37,99,111,126,199,248;
+    vision_transformer.py:197; mobilenetv1.py:47; darknet.py:38; yolov3.py:313."""
+
+    def __init__(self, out_channels=32, kernel_size=(1, 1), stride=(1, 1), n_group=1, act=None, padding="SAME",
+                 data_format="channels_last", dilation=(1, 1), W_init="truncated_normal", b_init="constant",
+                 in_channels=None, name=None):
+        super().__init__(name=name)
+        if in_channels is None:
+            raise ValueError("GroupConv2d: in_channels must be given (deferred build is not supported)")
+        self.in_channels, self.out_channels = int(in_channels), int(out_channels)
+        self.kernel_size, self.stride, self.dilation = _tup2(kernel_size), _tup2(stride), _tup2(dilation)
+        self.n_group = int(n_group)
+        if self.in_channels % self.n_group or self.out_channels % self.n_group:
+            raise ValueError("The number of input/output channels must be divisible by n_group")
+        if isinstance(padding, str):
+            p = padding.upper()
+            if p == "VALID":
+                self.padding = (0, 0)
+            elif p == "SAME":
+                self.padding = tuple(d * (k - 1) // 2 for k, d in zip(self.kernel_size, self.dilation))
+            else:
+                raise ValueError(f"unsupported padding {padding!r}")
+        else:
+            self.padding = _tup2(padding)
+        self.data_format = data_format
+        self.act = act
+        w_init = str_to_init(W_init) if isinstance(W_init, str) else W_init
+        shape = (self.out_channels, self.in_channels // self.n_group) + self.kernel_size
+        self.filters = Parameter(data=w_init(shape=shape))
+        if b_init is None or b_init is False or (isinstance(b_init, (tuple, list)) and len(b_init) == 0):
+            self.biases = None
+        else:
+            bi = str_to_init(b_init) if isinstance(b_init, str) else (b_init if callable(b_init) else Constant(0.0))
+            self.biases = Parameter(data=bi(shape=(self.out_channels,)))
+
+    # fused entry point used by the model graphs: conv (+bn) (+act) (+residual) in one launch
+    def run_nhwc(self, x, bn=None, act=E.ACT_NONE, act_param=0.0, res=None, res_after_act=False, **kw):
+        self._require_eval()
+        dt = E.precision()
+        if self.n_group == 1:
+            pk = self._cached("pk", lambda: E.PackedFilter(self.filters, dt))
+        elif self.n_group == self.in_channels == self.out_channels:
+            pk = self._cached("dw", lambda: self.filters.detach()[:, 0].permute(1, 2, 0).contiguous().to(dt))
+        else:
+            raise NotImplementedError(f"GroupConv2d: n_group={self.n_group} (only 1 or depthwise) — SURVEY §8f")
+        if bn is not None:
+            scale, shift = self._cached(("bn", id(bn)), lambda: bn.folded(self.biases))
+        else:
+            scale, shift = None, (self._cached("bias", lambda: E._f32(self.biases)) if self.biases is not None else None)
+        if self.n_group == 1:
+            return E.conv2d(x, pk, self.stride, self.padding, self.dilation, scale, shift, res, act, act_param,
+                            res_after_act, **kw)
+        if res is not None:
+            raise NotImplementedError("depthwise conv with fused residual")
+        return E.dwconv2d(x, pk, self.stride, self.padding, self.dilation, scale, shift, act, act_param)
+
+    def forward(self, x):
+        y = self.run_nhwc(as_nhwc(x, self.data_format))
+        y = from_nhwc(y, self.data_format)
+        return self.act(y) if self.act is not None else y
+
+
+class Conv2d(GroupConv2d):
+    def __init__(self, out_channels=32, kernel_size=(3, 3), stride=(1, 1), act=None, padding="SAME",
+                 data_format="channels_last", dilation=(1, 1), W_init="truncated_normal", b_init="constant",
+                 in_channels=None, name=None):
+        super().__init__(out_channels=out_channels, kernel_size=kernel_size, stride=stride, n_group=1, act=act,
+                         padding=padding, data_format=data_format, dilation=dilation, W_init=W_init, b_init=b_init,
+                         in_channels=in_channels, name=name)
+
+
+# ---------------------------------------------------------------------------------------------
+# BatchNorm2d
+# ---------------------------------------------------------------------------------------------
+class BatchNorm2d(Module):
+    """nn.BatchNorm2d(num_features=, data_format=, epsilon=, momentum=) — resnet.py:46,107,122,134,208,257;
+    mobilenetv1.py:61; darknet.py:48; mobilenetv3.py:148 (eps 1e-3)."""
+
+    def __init__(self, momentum=0.9, epsilon=1e-5, act=None, is_train=True, beta_init="zeros", gamma_init="ones",
+                 moving_mean_init="zeros", moving_var_init="ones", num_features=None, data_format="channels_last",
+                 name=None):
+        super().__init__(name=name)
+        if num_features is None:
+            raise ValueError("BatchNorm2d: num_features must be given")
+        self.num_features, self.epsilon, self.momentum = int(num_features), float(epsilon), momentum
+        self.data_format, self.act = data_format, act
+        n = (self.num_features,)
+        self.gamma = Parameter(data=str_to_init(gamma_init)(shape=n))
+        self.beta = Parameter(data=str_to_init(beta_init)(shape=n))
+        self.register_buffer("moving_mean", str_to_init(moving_mean_init)(shape=n))
+        self.register_buffer("moving_var", str_to_init(moving_var_init)(shape=n))
+
+    def folded(self, conv_bias=None):
+        return E.fold_bn(self.gamma, self.beta, self.moving_mean, self.moving_var, self.epsilon, conv_bias)
+
+    def forward(self, x):
+        self._require_eval()
+        scale, shift = self._cached("fold", self.folded)
+        v = as_nhwc(x, self.data_format)
+        y = from_nhwc(E.affine_act(v, scale, shift), self.data_format)
+        return self.act(y) if self.act is not None else y
+
+
+BatchNorm = BatchNorm2d
+
+
+class LayerNorm(Module):
+    """nn.LayerNorm(normalized_shape, epsilon=) — vision_transformer.py:144,159,283; swin :258,279."""
+
+    def __init__(self, normalized_shape, epsilon=1e-5, gamma_init="ones", beta_init="zeros", act=None, name=None):
+        super().__init__(name=name)
+        if isinstance(normalized_shape, int):
+            normalized_shape = (normalized_shape,)
+        self.normalized_shape, self.epsilon = tuple(normalized_shape), float(epsilon)
+        if len(self.normalized_shape) != 1:
+            raise NotImplementedError("LayerNorm over more than the last axis")
+        self.gamma = Parameter(data=str_to_init(gamma_init)(shape=self.normalized_shape))
+        self.beta = Parameter(data=str_to_init(beta_init)(shape=self.normalized_shape))
+
+    def forward(self, x):
+        E.need_gpu(x, "input")
+        if x.dtype != E.precision():
+            x = x.to(E.precision())
+        return E.layernorm(x, self.gamma.detach(), self.beta.detach(), self.epsilon)
+
+
+class Linear(Module):
+    """nn.Linear(in_features=, out_features=, b_init=) — resnet.py:234; vision_transformer.py:77,79,105-110,
+    284; `b_init=False/None` => no bias (:107)."""
+
+    def __init__(self, out_features=None, act=None, W_init="truncated_normal", b_init="constant", in_features=None,
+                 name=None):
+        super().__init__(name=name)
+        if in_features is None or out_features is None:
+            raise ValueError("Linear: in_features and out_features must be given")
+        self.in_features, self.out_features, self.act = int(in_features), int(out_features), act
+        w_init = str_to_init(W_init) if isinstance(W_init, str) else W_init
+        self.weights = Parameter(data=w_init(shape=(self.in_features, self.out_features)))
+        if b_init is None or b_init is False or (isinstance(b_init, (tuple, list)) and len(b_init) == 0):
+            self.biases = None
+        else:
+            bi = str_to_init(b_init) if isinstance(b_init, str) else (b_init if callable(b_init) else Constant(0.0))
+            self.biases = Parameter(data=bi(shape=(self.out_features,)))
+
+    def run(self, x, act=E.ACT_NONE, res=None, out=None):
+        dt = E.precision()
+        pk = self._cached("pk", lambda: E.PackedFilter(self.weights.detach().t().contiguous(), dt))
+        b = self._cached("bias", lambda: E._f32(self.biases)) if self.biases is not None else None
+        if x.dtype != dt:
+            x = x.to(dt)
+        return E.linear(x, pk, b, res, act, out)
+
+    def forward(self, x):
+        y = self.run(x)
+        return self.act(y) if self.act is not None else y
+
+
+class MaxPool2d(Module):
+    """nn.MaxPool2d(kernel_size, stride, padding, data_format) — resnet.py:213-218."""
+
+    def __init__(self, kernel_size, stride=None, padding="SAME", return_mask=False, data_format="channels_last",
+                 name=None):
+        super().__init__(name=name)
+        self.kernel_size = _tup2(kernel_size)
+        self.stride = _tup2(stride if stride is not None else kernel_size)
+        if isinstance(padding, str):
+            self.padding = (0, 0) if padding.upper() == "VALID" else tuple((k - 1) // 2 for k in self.kernel_size)
+        else:
+            self.padding = _tup2(padding)
+        self.data_format = data_format
+
+    def run_nhwc(self, x):
+        return E.maxpool2d(x, self.kernel_size, self.stride, self.padding)
+
+    def forward(self, x):
+        return from_nhwc(self.run_nhwc(as_nhwc(x, self.data_format)), self.data_format)
+
+
+class AdaptiveAvgPool2d(Module):
+    """Only output_size (1,1) occurs on the hot path (resnet.py:228-231, mobilenetv1.py:246)."""
+
+    def __init__(self, output_size, data_format="channels_last", name=None):
+        super().__init__(name=name)
+        self.output_size = _tup2(output_size)
+        if self.output_size != (1, 1):
+            raise NotImplementedError("AdaptiveAvgPool2d: only output_size (1,1)")
+        self.data_format = data_format
+
+    def forward(self, x):
+        v = as_nhwc(x, self.data_format)
+        y = E.global_avgpool(v)
+        N, Cc = y.shape
+        return y.view(N, 1, 1, Cc) if self.data_format == "channels_last" else y.view(N, Cc, 1, 1)
+
+
+class AdaptiveAvgPool1d(Module):
+    """swin_transformer.py:593,609: mean over tokens of a (B, C, L) tensor."""
+
+    def __init__(self, output_size, data_format="channels_first", name=None):
+        super().__init__(name=name)
+        if output_size != 1:
+            raise NotImplementedError("AdaptiveAvgPool1d: only output_size 1")
+        self.data_format = data_format
+
+    def forward(self, x):
+        E.need_gpu(x, "input")
+        if self.data_format == "channels_first":  # (B, C, L)
+            y = E.global_avgpool(x.transpose(1, 2).contiguous())
+            return y.unsqueeze(-1)
+        return E.global_avgpool(x.contiguous()).unsqueeze(1)
+
+
+class UpSampling2d(Module):
+    def __init__(self, scale=2, method="nearest", data_format="channels_first", name=None):
+        super().__init__(name=name)
+        if _tup2(scale) != (2, 2) or method != "nearest":
+            raise NotImplementedError("UpSampling2d: only nearest x2 (yolov3.py:250)")
+        self.data_format = data_format
+
+    def forward(self, x):
+        v = as_nhwc(x, self.data_format)
+        N, H, W, Cc = v.shape
+        out = torch.empty((N, 2 * H, 2 * W, Cc), dtype=v.dtype, device=v.device)
+        return from_nhwc(E.upsample2x_into(v, out, 0), self.data_format)
