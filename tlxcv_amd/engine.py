@@ -32,15 +32,6 @@ def set_precision(p):
     global _precision
     if p in ("fp16", "float16", torch.float16):
         _precision = torch.float16
-
-# Optional per-launch probe (bench.py): when a list is installed, every implicit-GEMM launch appends
-# (start_event, end_event, algorithmic_bytes, flops) recorded on the launch stream.
-_probe = None
-
-
-def set_probe(lst):
-    global _probe
-    _probe = lst
     elif p in ("fp32", "float32", torch.float32):
         _precision = torch.float32
     else:
