@@ -39,11 +39,15 @@ def build_model(workload, dev):
     return m.to(dev).set_eval(), params
 
 
-def cpu_baseline(workload, params, batch=32, warm=1, iters=4):
+def cpu_baseline(workload, params, batch=16, warm=1, iters=3):
     """Oracle restatement timed on the host cores (rank 0, N=1 only)."""
     from oracle import functional as OF
     from tlxcv_amd import seeded
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = min(cores, 16)     # the GPU box gives one GPU's share of the host: 16 cores
     torch.set_num_threads(cores)
     p = {k: torch.from_numpy(v) for k, v in params.items()}
     x = torch.from_numpy(seeded.image_batch(batch, 0))
@@ -131,10 +135,10 @@ def main():
             model(x)
         torch.cuda.synchronize()
         E.set_probe(None)
-        ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in probe)
+        ms = sum(e[0].elapsed_time(e[1]) for e in probe)
         nl = len(probe)
-        alg_bytes = sum(b for _, _, b, _ in probe)
-        flops = sum(f for _, _, _, f in probe)
+        alg_bytes = sum(e[2] for e in probe)
+        flops = sum(e[3] for e in probe)
         per_launch_us = 1e3 * ms / nl
         achieved = alg_bytes / (ms * 1e-3) / 1e9
         line["roofline"] = {

@@ -204,7 +204,8 @@ int tlxmi_patch_merge_gather(const void* x, void* y, int dtype, int B, int H, in
  * interpolate(scale_factor=2) + concat).  y has pixel stride y_ld; channels [c_off, c_off+C). */
 int tlxmi_upsample2x_nearest(const void* x, void* y, int dtype, int N, int H, int W, int C, int x_ld,
                              int y_ld, int c_off, void* stream);
-/* strided copy of an NHWC tensor into a channel window of another (tlx.concat along channels) */
+/* strided copy of an NHWC tensor into a channel window of another (tlx.concat along channels);
+ * x_ld == 0 broadcasts one source row to every destination row (cls token, vision_transformer.py:321) */
 int tlxmi_copy_channels(const void* x, void* y, int dtype, int64_t rows, int C, int x_ld, int y_ld,
                         void* stream);
 

@@ -131,3 +131,50 @@ def fold_bn(gamma, beta, mean, var, eps, conv_bias=None):
     if conv_bias is not None:
         shift = shift + conv_bias * scale
     return scale, shift
+
+
+# ---------------------------------------------------------------------------------------------
+# Vision Transformer — models/classification/vision_transformer.py
+# ---------------------------------------------------------------------------------------------
+VIT_CFG = {  # _vision_transformer, vision_transformer.py:336-416
+    "vit_small_patch16_224": dict(img=224, patch=16, dim=768, depth=8, heads=8, qk_scale=768 ** -0.5, eps=1e-5),
+    "vit_base_patch16_224": dict(img=224, patch=16, dim=768, depth=12, heads=12, qk_scale=None, eps=1e-6),
+    "vit_base_patch16_384": dict(img=384, patch=16, dim=768, depth=12, heads=12, qk_scale=None, eps=1e-6),
+    "vit_base_patch32_384": dict(img=384, patch=32, dim=768, depth=12, heads=12, qk_scale=None, eps=1e-6),
+    "vit_large_patch16_224": dict(img=224, patch=16, dim=1024, depth=24, heads=16, qk_scale=None, eps=1e-6),
+}
+
+
+def vit_attention(p, pre, x, heads, scale):
+    """Attention.forward, vision_transformer.py:112-123."""
+    N, C = x.shape[1:]
+    qkv = linear(p, pre + ".qkv", x).reshape((-1, N, 3, heads, C // heads))        # :114
+    qkv = qkv.permute(2, 0, 3, 1, 4)                                                 # :115
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    attn = q.matmul(k.permute(0, 1, 3, 2)) * scale                                   # :117 (scale AFTER q k^T)
+    attn = torch.softmax(attn, dim=-1)                                               # :118
+    x = attn.matmul(v).permute(0, 2, 1, 3).reshape((-1, N, C))                       # :120
+    return linear(p, pre + ".proj", x)                                               # :121
+
+
+def vit_block(p, pre, x, heads, scale, eps):
+    """Block.forward, vision_transformer.py:172-175 (drop_path = Identity at rate 0, :157)."""
+    x = x + vit_attention(p, pre + ".attn", layernorm(p, pre + ".norm1", x, eps), heads, scale)
+    h = linear(p, pre + ".mlp.fc1", layernorm(p, pre + ".norm2", x, eps))            # Mlp.forward :81-87
+    h = F.gelu(h, approximate="none")
+    return x + linear(p, pre + ".mlp.fc2", h)
+
+
+def vit(p, x, arch="vit_base_patch16_224"):
+    """VisionTransformer.forward, vision_transformer.py:318-333."""
+    c = VIT_CFG[arch]
+    B = x.shape[0]
+    assert x.shape[2] == c["img"] and x.shape[3] == c["img"]                         # :217-219
+    t = conv(p, "patch_embed.proj", x, c["patch"], 0).flatten(2, 3).permute(0, 2, 1)  # PatchEmbed.forward :206-211
+    cls = _t(p, "cls_token").expand((B, -1, -1))                                     # :321
+    t = torch.cat((cls, t), dim=1) + _t(p, "pos_embed")                              # :322-323
+    scale = c["qk_scale"] or (c["dim"] // c["heads"]) ** -0.5                        # :103
+    for i in range(c["depth"]):
+        t = vit_block(p, f"blocks.{i}", t, c["heads"], scale, c["eps"])
+    t = layernorm(p, "norm", t, c["eps"])                                            # :327
+    return linear(p, "head", t[:, 0])                                                # :328, :332

@@ -77,11 +77,32 @@ def gen_resnet(depth, batch, wseed, xseed, fname):
         param_names=np.array(list(shapes.keys())), torch_version=torch.__version__)
 
 
+def gen_vit(arch, batch, wseed, xseed, fname):
+    ref = import_reference("tlxcv/models/classification/vision_transformer.py", "ref_vit")
+    model = getattr(ref, arch)()
+    shapes = seeded.shapes_of(model)
+    params = seeded.fill(shapes, wseed)
+    model.load_dict(params)
+    model.set_eval()
+    x = torch.from_numpy(seeded.image_batch(batch, xseed))
+    with torch.no_grad():
+        ref_out = model(x)
+        re_out = OF.vit({k: torch.from_numpy(v) for k, v in params.items()}, x, arch)
+    d = _check(arch, ref_out, re_out)
+    np.savez_compressed(
+        os.path.join(OUT, fname), arch=arch, weight_seed=wseed, input_seed=xseed, batch=batch,
+        logits=ref_out.numpy().astype(np.float32), argmax=ref_out.argmax(-1).numpy().astype(np.int64),
+        restatement_max_abs_diff=np.float64(d), pinned_by="reference-file-on-tlx_cpu",
+        param_names=np.array(list(shapes.keys())), torch_version=torch.__version__)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(os.cpu_count() or 1)
     gen_resnet(50, 4, 1, 0, "resnet50_b4.npz")      # BASELINE.json configs[0]
     gen_resnet(18, 2, 11, 10, "resnet18_b2.npz")
+    gen_vit("vit_base_patch16_224", 2, 2, 0, "vit_b16_b2.npz")       # BASELINE.json configs[2] graph
+    gen_vit("vit_small_patch16_224", 1, 12, 3, "vit_small_b1.npz")   # no qkv bias, qk_scale override, hd=96
     for extra in EXTRA:
         extra()
 

@@ -18,6 +18,13 @@ def test_resnet50_parameter_tree_matches_reference_fixture():
     assert sum(p.numel() for p in m.parameters()) == 25557032
 
 
+def test_vit_parameter_tree_matches_reference_fixture():
+    from tlxcv_amd.models import vit_base_patch16_224
+    from tlxcv_amd import seeded
+    names = list(np.load(os.path.join(GOLDEN, "vit_b16_b2.npz"))["param_names"])
+    assert list(seeded.shapes_of(vit_base_patch16_224()).keys()) == names
+
+
 def test_cpu_tensor_is_refused():
     from tlxcv_amd.models import resnet18
     m = resnet18()

@@ -39,3 +39,16 @@ def test_fold_bn_equals_batch_norm():
     s, sh = OF.fold_bn(g, b, m, v, 1e-5)
     ref = torch.nn.functional.batch_norm(x, m, v, g, b, False, 0.0, 1e-5)
     assert (x * s.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1) - ref).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize("fname", ["vit_b16_b2.npz", "vit_small_b1.npz"])
+def test_vit_restatement_reproduces_golden(fname):
+    from tlxcv_amd import models
+    g = np.load(os.path.join(GOLDEN, fname))
+    arch = str(g["arch"])
+    p = _params(getattr(models, arch), int(g["weight_seed"]))
+    x = torch.from_numpy(seeded.image_batch(int(g["batch"]), int(g["input_seed"])))
+    with torch.no_grad():
+        y = OF.vit(p, x, arch)
+    assert np.abs(y.numpy() - g["logits"]).max() <= 1e-4
+    assert (y.argmax(-1).numpy() == g["argmax"]).all()

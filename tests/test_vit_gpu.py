@@ -1,0 +1,50 @@
+"""ViT parity on the MI355X against golden logits produced by the reference's own
+vision_transformer.py (oracle/gen_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from tlxcv_amd import seeded
+
+pytestmark = pytest.mark.gpu
+
+
+def build(arch, seed, dev):
+    from tlxcv_amd import models
+    m = getattr(models, arch)()
+    m.load_dict(seeded.fill(seeded.shapes_of(m), seed))
+    return m.to(dev).set_eval()
+
+
+@pytest.mark.parametrize("fname", ["vit_b16_b2.npz", "vit_small_b1.npz"])
+def test_fp32_matches_golden_1e4_and_argmax_exact(dev, fp32_mode, fname):
+    g = np.load(os.path.join(GOLDEN, fname))
+    m = build(str(g["arch"]), int(g["weight_seed"]), dev)
+    x = torch.from_numpy(seeded.image_batch(int(g["batch"]), int(g["input_seed"]))).to(dev)
+    y = m(x)
+    err = np.abs(y.cpu().numpy() - g["logits"]).max()
+    assert err <= 1e-4, err
+    from tlxcv_amd.tasks import ImageClassification
+    assert (ImageClassification(m).predict(x).cpu().numpy() == g["argmax"]).all()
+
+
+def test_fp16_tracks_golden(dev, fp16_mode):
+    g = np.load(os.path.join(GOLDEN, "vit_b16_b2.npz"))
+    m = build("vit_base_patch16_224", int(g["weight_seed"]), dev)
+    x = torch.from_numpy(seeded.image_batch(2, int(g["input_seed"]))).to(dev)
+    y = m(x).float().cpu().numpy()
+    ref = g["logits"]
+    err = np.abs(y - ref).max()
+    assert err <= 0.02 * (ref.max() - ref.min()), err
+    s = np.sort(ref, axis=1)
+    safe = (s[:, -1] - s[:, -2]) > 2 * err
+    assert safe.any() and (y.argmax(1)[safe] == g["argmax"][safe]).all()
+
+
+def test_wrong_image_size_asserts(dev, fp16_mode):
+    m = build("vit_base_patch16_224", 2, dev)
+    with pytest.raises(AssertionError, match="doesn't match"):      # vision_transformer.py:217-219
+        m(torch.zeros(1, 3, 192, 192, device=dev))

@@ -107,8 +107,7 @@ template <typename T> static int launch_rows(const AttnArgs& a, hipStream_t st) 
     return check_launch("attention(rows)");
 }
 
-// TEMPORARY: MFMA path not written yet -> generic rows kernel
-int launch_attn_mfma(const AttnArgs& a, hipStream_t st) { return launch_rows<half_t>(a, st); }
+int launch_attn_mfma(const AttnArgs& a, hipStream_t st);  // attention_mfma.hip
 
 }  // namespace tlxmi
 

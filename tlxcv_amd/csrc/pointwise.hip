@@ -441,7 +441,9 @@ extern "C" int tlxmi_upsample2x_nearest(const void* x, void* y, int dt, int N, i
 extern "C" int tlxmi_copy_channels(const void* x, void* y, int dt, int64_t rows, int C, int x_ld, int y_ld,
                                    void* stream) {
     TLXMI_REQUIRE(x && y && rows > 0, TLXMI_ERR_BAD_ARG, "copy_channels: bad argument");
-    REQUIRE_CHUNKED("copy_channels", dt, C, x_ld, y_ld);
+    REQUIRE_CHUNKED("copy_channels", dt, C, y_ld);
+    TLXMI_REQUIRE(x_ld == 0 || (x_ld >= C && x_ld % VECN(dt) == 0), TLXMI_ERR_ALIGNMENT,
+                  "copy_channels: bad source stride %d (0 = broadcast one row)", x_ld);
     TLXMI_REQUIRE(aligned16(x) && aligned16(y), TLXMI_ERR_ALIGNMENT, "copy_channels: buffers must be 16-byte aligned");
     const long work = rows * (C / VECN(dt));
     dim3 g(grid_for(work)), b(256);

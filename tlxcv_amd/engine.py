@@ -189,7 +189,7 @@ def conv2d(x, pk, stride=1, padding=0, dilation=1, scale=None, shift=None, res=N
     e0.record()
     _lib.call("tlxmi_conv2d", C.byref(d), _p(x), _p(pk.buf), _p(scale), _p(shift), _p(res), _p(out), _stream())
     e1.record()
-    _probe.append((e0, e1, alg_bytes, flops))
+    _probe.append((e0, e1, alg_bytes, flops, (N, H, W, pk.Cin, pk.Cout, pk.R, sh, res is not None)))
     return out
 
 
@@ -283,6 +283,23 @@ def layernorm(x, gamma, beta, eps):
     _lib.call("tlxmi_layernorm", _p(x), _p(gamma), _p(beta), _p(y), dt_code(x.dtype), rows, Cc, Cc, Cc, float(eps),
               _stream())
     return y
+
+
+def layernorm_rows(x, rows, Cc, x_ld, gamma, beta, eps):
+    """LayerNorm of `rows` rows of width Cc that sit x_ld elements apart in `x` -> dense (rows, Cc)."""
+    need_gpu(x, "input")
+    y = torch.empty((rows, Cc), dtype=x.dtype, device=x.device)
+    _lib.call("tlxmi_layernorm", _p(x), _p(gamma), _p(beta), _p(y), dt_code(x.dtype), rows, Cc, x_ld, Cc,
+              float(eps), _stream())
+    return y
+
+
+def broadcast_rows_into(vec_, out, rows, out_ld):
+    """out[r*out_ld : r*out_ld + len(vec)] = vec for r < rows (cls-token row of every image)."""
+    need_gpu(out, "output")
+    Cc = vec_.numel()
+    _lib.call("tlxmi_copy_channels", _p(vec_), _p(out), dt_code(out.dtype), rows, Cc, 0, out_ld, _stream())
+    return out
 
 
 def attention(qkv, heads, scale, bias=None, mask=None):

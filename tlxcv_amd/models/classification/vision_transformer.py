@@ -1,0 +1,244 @@
+"""Vision Transformer forward graph on the MI355X engine.
+
+Same factories / constructor arguments / parameter tree as the reference
+(tlxcv/models/classification/vision_transformer.py:64-447).  Forward differences (all fusions, no
+change of arithmetic):
+  * PatchEmbed conv (k=s=patch, bias) writes straight into rows 1..P of the (B, 1+P, D) token
+    matrix with `+ pos_embed[1:]` in its epilogue (reference: conv -> flatten -> transpose ->
+    concat cls -> add pos_embed, :206-220, :321-323); row 0 is the constant cls_token+pos_embed[0].
+  * Attention (:112-123) = qkv GEMM(+bias) -> one fused softmax(q k^T * scale) v kernel on the
+    packed qkv matrix -> proj GEMM with bias and the residual add of Block.forward (:173) fused.
+  * Mlp (:81-87) = fc1 GEMM with bias+exact-erf GELU epilogue -> fc2 GEMM with bias + residual (:174).
+  * final LayerNorm only on the cls rows (x[:, 0] commutes with a per-row norm, :327-328).
+"""
+import numpy as np
+import torch
+
+from ... import engine as E
+from ...tlx import nn
+from ...tlx.nn import as_nhwc
+
+__all__ = ["VisionTransformer", "vit_small_patch16_224", "vit_base_patch16_224", "vit_base_patch16_384",
+           "vit_base_patch32_384", "vit_large_patch16_224", "vit_large_patch16_384", "vit_large_patch32_384"]
+
+trunc_normal_ = nn.initializers.TruncatedNormal(stddev=0.02)
+zeros_ = nn.initializers.Constant(value=0.0)
+ones_ = nn.initializers.Constant(value=1.0)
+
+
+def to_2tuple(x):
+    return (x, x)
+
+
+class Identity(nn.Module):
+    def forward(self, x):
+        return x
+
+
+class DropPath(nn.Module):
+    """Stochastic depth: identity in eval (vision_transformer.py:36-61)."""
+
+    def __init__(self, drop_prob=None):
+        super().__init__()
+        self.drop_prob = drop_prob
+
+    def forward(self, x):
+        if self.drop_prob and self.is_train:
+            self._require_eval()
+        return x
+
+
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.0):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.fc1 = nn.Linear(in_features=in_features, out_features=hidden_features)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(in_features=hidden_features, out_features=out_features)
+        self.drop = nn.Dropout(drop)
+
+    def run(self, x, res=None):
+        h = self.fc1.run(x, act=self.act.ACT)          # bias + GELU in the GEMM epilogue
+        return self.fc2.run(h, res=res, out=res)       # bias + residual, written in place
+
+    def forward(self, x):
+        return self.run(x)
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None, attn_drop=0.0, proj_drop=0.0):
+        super().__init__()
+        self.num_heads = num_heads
+        head_dim = dim // num_heads
+        self.scale = qk_scale or head_dim ** -0.5
+        if qkv_bias:
+            self.qkv = nn.Linear(in_features=dim, out_features=dim * 3)
+        else:
+            self.qkv = nn.Linear(in_features=dim, out_features=dim * 3, b_init=qkv_bias)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = nn.Linear(in_features=dim, out_features=dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+
+    def run(self, x, res=None):
+        qkv = self.qkv.run(x)                                          # (B, N, 3*C), packed [3][heads][hd]
+        a = E.attention(qkv, self.num_heads, self.scale)               # softmax(q k^T * scale) v, heads merged
+        return self.proj.run(a, res=res, out=res)
+
+    def forward(self, x):
+        return self.run(x)
+
+
+class Block(nn.Module):
+    def __init__(self, dim, num_heads, mlp_ratio=4.0, qkv_bias=False, qk_scale=None, drop=0.0, attn_drop=0.0,
+                 drop_path=0.0, act_layer=nn.GELU, layer_norm="nn.LayerNorm", epsilon=1e-05,
+                 data_format="channels_first"):
+        super().__init__()
+        if isinstance(layer_norm, str):
+            self.norm1 = eval(layer_norm)(dim, epsilon=epsilon)
+        elif callable(layer_norm):
+            self.norm1 = layer_norm(dim)
+        else:
+            raise TypeError("The layer_norm must be str or paddle.nn.layer.Layer class")
+        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop,
+                              proj_drop=drop)
+        self.drop_path = DropPath(drop_path) if drop_path > 0.0 else Identity()
+        if isinstance(layer_norm, str):
+            self.norm2 = eval(layer_norm)(dim, epsilon=epsilon)
+        else:
+            self.norm2 = layer_norm(dim)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+
+    def run_inplace(self, x):
+        """x (B, N, C) engine dtype, updated in place: x += attn(norm1(x)); x += mlp(norm2(x))."""
+        self.attn.run(self.norm1(x), res=x)
+        self.mlp.run(self.norm2(x), res=x)
+        return x
+
+    def forward(self, x):
+        E.need_gpu(x, "input")
+        x = x.to(E.precision()).contiguous().clone()
+        return self.run_inplace(x)
+
+
+class PatchEmbed(nn.Module):
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768, data_format="channels_first"):
+        super().__init__()
+        img_size = to_2tuple(img_size)
+        patch_size = to_2tuple(patch_size)
+        self.num_patches = img_size[1] // patch_size[1] * (img_size[0] // patch_size[0])
+        self.img_size, self.patch_size, self.data_format = img_size, patch_size, data_format
+        self.proj = nn.GroupConv2d(kernel_size=patch_size, stride=patch_size, in_channels=in_chans,
+                                   out_channels=embed_dim, padding=0, data_format=data_format)
+
+    def check(self, x):
+        H, W = (x.shape[2], x.shape[3]) if self.data_format == "channels_first" else (x.shape[1], x.shape[2])
+        assert H == self.img_size[0] and W == self.img_size[1], \
+            f"Input image size ({H}*{W}) doesn't match model ({self.img_size[0]}*{self.img_size[1]})."
+
+    def forward(self, x):
+        self.check(x)
+        y = self.proj.run_nhwc(as_nhwc(x, self.data_format))
+        return y.reshape(y.shape[0], -1, y.shape[-1])
+
+
+class VisionTransformer(nn.Module):
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=1000, embed_dim=768, depth=12,
+                 num_heads=12, mlp_ratio=4, qkv_bias=False, qk_scale=None, drop_rate=0.0, attn_drop_rate=0.0,
+                 drop_path_rate=0.0, layer_norm="nn.LayerNorm", epsilon=1e-05, data_format="channels_first",
+                 name=None):
+        super().__init__(name=name)
+        self.num_classes = num_classes
+        self.num_features = self.embed_dim = embed_dim
+        self.data_format = data_format
+        self.patch_embed = PatchEmbed(img_size=img_size, patch_size=patch_size, in_chans=in_chans,
+                                      embed_dim=embed_dim, data_format=data_format)
+        num_patches = self.patch_embed.num_patches
+        self.pos_embed = self.add_parameter("pos_embed", shape=(1, num_patches + 1, embed_dim),
+                                            initializer=trunc_normal_)
+        self.cls_token = self.add_parameter("cls_token", shape=(1, 1, embed_dim), initializer=trunc_normal_)
+        self.pos_drop = nn.Dropout(p=drop_rate)
+        self.blocks = nn.ModuleList([
+            Block(dim=embed_dim, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale,
+                  drop=drop_rate, attn_drop=attn_drop_rate, drop_path=dpr, layer_norm=layer_norm, epsilon=epsilon)
+            for dpr in np.linspace(0, drop_path_rate, depth)])
+        self.norm = eval(layer_norm)(embed_dim, epsilon=epsilon)
+        self.head = nn.Linear(in_features=embed_dim, out_features=num_classes) if num_classes > 0 else Identity()
+
+    def add_parameter(self, name, shape, initializer=None):
+        initializer = initializer or zeros_
+        param = nn.Parameter(data=initializer(shape=shape))
+        self.register_parameter(name=name, param=param)
+        return param
+
+    def forward_features(self, x):
+        self._require_eval()
+        pe = self.patch_embed
+        pe.check(x)
+        dt = E.precision()
+        v = as_nhwc(x, self.data_format)
+        B, P, D = v.shape[0], pe.num_patches, self.embed_dim
+        pos = self._cached("pos", lambda: self.pos_embed.detach()[0, 1:].to(dt).contiguous())            # (P, D)
+        row0 = self._cached("row0", lambda: (self.cls_token.detach()[0, 0] + self.pos_embed.detach()[0, 0])
+                            .to(dt).contiguous())                                                         # (D,)
+        tok = torch.empty((B, P + 1, D), dtype=dt, device=v.device)
+        # rows 1..P: conv + bias + pos_embed[1:]   (vision_transformer.py:206-220, 321-323)
+        pe.proj.run_nhwc(v, res=pos, out=tok[:, 1:], out_ld=D, y_nstride=(P + 1) * D, res_bcast=True, res_ld=D)
+        # row 0: cls_token + pos_embed[0]
+        E.broadcast_rows_into(row0, tok, B, (P + 1) * D)
+        for blk in self.blocks:
+            blk.run_inplace(tok)
+        cls = E.layernorm_rows(tok, B, D, (P + 1) * D, self.norm.gamma.detach(), self.norm.beta.detach(),
+                               self.norm.epsilon)                                                         # :327-328
+        return cls
+
+    def forward(self, x):
+        x = self.forward_features(x)
+        if isinstance(self.head, nn.Linear):
+            return self.head.run(x)
+        return x
+
+
+_CFG = {
+    "vit_small_patch16_224": dict(patch_size=16, embed_dim=768, depth=8, num_heads=8, mlp_ratio=3, qk_scale=768 ** -0.5),
+    "vit_base_patch16_224": dict(patch_size=16, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4, qkv_bias=True, epsilon=1e-06),
+    "vit_base_patch16_384": dict(img_size=384, patch_size=16, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4, qkv_bias=True, epsilon=1e-06),
+    "vit_base_patch32_384": dict(img_size=384, patch_size=32, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4, qkv_bias=True, epsilon=1e-06),
+    "vit_large_patch16_224": dict(patch_size=16, embed_dim=1024, depth=24, num_heads=16, mlp_ratio=4, qkv_bias=True, epsilon=1e-06),
+    "vit_large_patch16_384": dict(img_size=384, patch_size=16, embed_dim=1024, depth=24, num_heads=16, mlp_ratio=4, qkv_bias=True, epsilon=1e-06),
+    "vit_large_patch32_384": dict(img_size=384, patch_size=32, embed_dim=1024, depth=24, num_heads=16, mlp_ratio=4, qkv_bias=True, epsilon=1e-06),
+}
+
+
+def _vision_transformer(arch, pretrained, **kwargs):
+    if pretrained:
+        print("Warn: NotImplemented")
+    return VisionTransformer(**{**_CFG[arch], **kwargs})
+
+
+def vit_small_patch16_224(pretrained=False, **kwargs):
+    return _vision_transformer("vit_small_patch16_224", pretrained, **kwargs)
+
+
+def vit_base_patch16_224(pretrained=False, use_ssld=False, **kwargs):
+    return _vision_transformer("vit_base_patch16_224", pretrained, **kwargs)
+
+
+def vit_base_patch16_384(pretrained=False, use_ssld=False, **kwargs):
+    return _vision_transformer("vit_base_patch16_384", pretrained, **kwargs)
+
+
+def vit_base_patch32_384(pretrained=False, use_ssld=False, **kwargs):
+    return _vision_transformer("vit_base_patch32_384", pretrained, **kwargs)
+
+
+def vit_large_patch16_224(pretrained=False, use_ssld=False, **kwargs):
+    return _vision_transformer("vit_large_patch16_224", pretrained, **kwargs)
+
+
+def vit_large_patch16_384(pretrained=False, use_ssld=False, **kwargs):
+    return _vision_transformer("vit_large_patch16_384", pretrained, **kwargs)
+
+
+def vit_large_patch32_384(pretrained=False, use_ssld=False, **kwargs):
+    return _vision_transformer("vit_large_patch32_384", pretrained, **kwargs)
