@@ -85,7 +85,7 @@ int tlxmi_nhwc_to_nchw(const void* src, int src_dtype, int ld, void* dst, int ds
  * Filter packing (once, at set_eval()).
  *   src: OIHW fp32 [Cout][Cin/groups][R][S] (the layout TensorLayerX's torch backend keeps)
  *   dst: [Cout_pad][Kpad] dtype, K index = (r*S + s)*Cin_pad + c, zero padded;
- *        Cin_pad*sizeof(dtype) % 16 == 0, Cout_pad % 128 == 0, Kpad*sizeof(dtype) % 64 == 0.
+ *        Cin_pad*sizeof(dtype) % 16 == 0, Cout_pad % 128 == 0, Kpad*sizeof(dtype) % 128 == 0.
  * ---------------------------------------------------------------------------------------- */
 size_t tlxmi_packed_filter_bytes(int Cout, int Cin, int R, int S, int dtype);
 int tlxmi_pack_filter(const float* src_oihw, void* dst, int Cout, int Cin, int R, int S, int dtype,

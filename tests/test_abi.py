@@ -61,8 +61,8 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     d = _lib.ConvDesc(dtype=7)
     rc = lib.tlxmi_conv2d(ctypes.byref(d), None, None, None, None, None, None, None)
     assert rc == -1 and b"null" in lib.tlxmi_last_error()
-    assert lib.tlxmi_packed_filter_bytes(64, 3, 7, 7, 0) == 128 * 416 * 2   # Cin 3->8, K 392->416 halves (13 x 64 B)
-    assert lib.tlxmi_packed_filter_bytes(64, 3, 7, 7, 1) == 128 * 208 * 4   # Cin 3->4, K 196->208 floats
+    assert lib.tlxmi_packed_filter_bytes(64, 3, 7, 7, 0) == 128 * 448 * 2   # Cin 3->8, K 392->448 halves (7 x 128 B)
+    assert lib.tlxmi_packed_filter_bytes(64, 3, 7, 7, 1) == 128 * 224 * 4   # Cin 3->4, K 196->224 floats
     assert lib.tlxmi_packed_filter_bytes(0, 3, 7, 7, 0) == 0
 
 

@@ -10,16 +10,22 @@
 // of one pixel, i.e. one 16-byte NHWC store):
 //     D[ch][pix] = sum_k Wp[ch][k] * X[pix][k],   k = (r*S + s)*C + c
 //   "A" operand = filter rows (K contiguous, packed once by tlxmi_pack_filter)
-//   "B" operand = input pixels gathered on the fly (16-byte chunks of C, zero for padding taps)
+//   "B" operand = input pixels gathered on the fly (16-byte chunks of C; padding taps read a
+//                 16-byte zero page)
 // Everything is expressed in 16-byte chunks so the same kernel body serves fp16 (8 elements per
 // chunk, v_mfma_f32_16x16x32_f16) and fp32 (4 elements per chunk, 4 x v_mfma_f32_16x16x4_f32,
 // exact fp32 FMA chain: the parity mode).
 //
-// Tile: BM pixels x BN channels x 64 bytes of K per step, 256 threads = 4 waves in a 2x2 grid,
-// double-buffered LDS, register-staged global loads issued one K-step ahead.
-// LDS image: rows of 64 B (4 chunks), chunk index XOR-swizzled with (-(row>>2))&3 so that both the
-// ds_write_b128 staging stores and the ds_read_b128 fragment reads are bank-conflict free under
-// gfx950's b128 lane grouping (MI355X_MICROARCH "LDS" table).
+// Tile: BM pixels x BN channels x 128 bytes of K per step, 256 threads = 4 waves in a 2x2 grid.
+// Staging is LDS-DMA (global_load_lds_dwordx4, no VGPR round trip, no ds_write): each wave
+// instruction fills one 1-KiB piece = 8 tile rows x 128 B; the per-lane SOURCE address does the
+// im2col gather.  Two LDS stages (one when K fits a single step): the loads of step k+1 are in
+// flight while step k's MFMAs run, one barrier per step.
+// LDS image: rows of 128 B (8 chunks); chunk c of row r sits in slot c ^ ((r>>1)&7), which makes
+// the ds_read_b128 fragment reads conflict-free under gfx950's b128 lane grouping.  Because the
+// DMA destination is lane-linear, the swizzle is applied to the source: lane l of a piece fetches
+// chunk (l&7) ^ ((r>>1)&7) of its row.  Pieces are dealt to waves so that this chunk index is
+// the same for every piece a lane loads (one im2col position per lane per step).
 #include "common.h"
 
 namespace tlxmi {
@@ -41,12 +47,15 @@ struct ConvArgs {
     int M;        // N*Ho*Wo output pixels
     int HoWo;
     int kchunks;  // R*S*cpt true 16-byte chunks along K
-    int ktiles;   // ceil(kchunks/4)
+    int ktiles;   // ceil(kchunks/8)
     int cpt;      // chunks per filter tap = C*sizeof(T)/16
-    int Kp_bytes; // packed filter row pitch in bytes (= ktiles*64)
+    int Kp_bytes; // packed filter row pitch in bytes (= ktiles*128)
     int mtiles, ntiles;
     int vec_io;   // 1: y (and res) rows allow 16-byte vector access
+    unsigned x_bytes, w_bytes;  // extents for the buffer descriptors
 };
+
+__device__ __attribute__((aligned(16))) unsigned g_zero_page[4];  // source of padding / tail chunks
 
 template <typename T> struct Mma;
 template <> struct Mma<half_t> {
@@ -65,7 +74,7 @@ template <> struct Mma<float> {
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {
-    return row * 64 + ((chunk ^ ((0 - (row >> 2)) & 3)) << 4);
+    return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
 
 // load / store 8 consecutive elements of T as fp32
@@ -95,17 +104,29 @@ template <> __device__ __forceinline__ void store8<float>(char* p, const float* 
     reinterpret_cast<f32x4*>(p)[1] = b;
 }
 
-template <typename T, int BM, int BN>
+// One LDS-DMA wave instruction: 64 lanes x 16 B from buffer offsets `voff` to the 1-KiB piece at `lds`
+// (wave-uniform).  Kept out of the kernel template: the builtin must not see template-dependent
+// operands (the host pass of hipcc cannot re-check it at instantiation time).
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+static __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds, int voff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)lds, 16, voff, 0, 0, 0);
+}
+static __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const char* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p), 0, bytes, 0x00020000);
+}
+
+template <typename T, int BM, int BN, bool IS_1X1>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     constexpr int ES = (int)sizeof(T);
-    constexpr int VEC = 16 / ES;
     constexpr int WM = BM / 2, WN = BN / 2;  // wave tile (pixels x channels)
     constexpr int PI = WM / 16, CI = WN / 16;
-    constexpr int XR = BM / 64, WR = BN / 64;
-    constexpr int BUF = (BM + BN) * 64;
-    __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+    constexpr int XP = BM / 32, WP = BN / 32;  // 1-KiB pieces per wave per K-step
+    constexpr int BUF = (BM + BN) * 128;
+    constexpr int OOB = (int)0x80000000;       // any offset >= 2^31 fails the descriptor range check -> zeros
+    extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
 
     // ---- block -> tile, XCD-aware: blocks that share an XCD (id % 8) walk consecutive tiles,
     // N-tiles fastest, so the activation rows of one M-tile are re-read from that XCD's L2.
@@ -119,84 +140,100 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     }
     const int bm0 = tile_m * BM, bn0 = tile_n * BN;
 
-    // ---- loader state: this thread stages chunk column (t&3) of rows (t>>2)+64i
-    const int lrow = t >> 2, lchunk = t & 3;
-    const char* xbase[XR];
-    int hi0[XR], wi0[XR];
-#pragma unroll
-    for (int i = 0; i < XR; ++i) {
-        const int m = bm0 + lrow + 64 * i;
-        const int mm = m < a.M ? m : 0;
-        const int n = mm / a.HoWo, rem = mm - n * a.HoWo;
-        const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
-        hi0[i] = m < a.M ? ho * a.sh - a.ph : -(1 << 28);
-        wi0[i] = wo * a.sw - a.pw;
-        xbase[i] = a.x + (size_t)n * a.H * a.W * a.x_ld * ES;
-    }
-    const char* wrow[WR];
-#pragma unroll
-    for (int j = 0; j < WR; ++j) wrow[j] = a.w + (size_t)(bn0 + lrow + 64 * j) * a.Kp_bytes;
+    // Buffer descriptors: 32-bit per-lane byte offsets, and the hardware range check supplies the
+    // zeros of padding taps / tail rows / tail K chunks (offset OOB) with no select on the data path.
+    const __amdgpu_buffer_rsrc_t xsrd = make_srd(a.x, a.x_bytes);
+    const __amdgpu_buffer_rsrc_t wsrd = make_srd(a.w, a.w_bytes);
 
-    // LDS staging offsets.  Filter rows are permuted inside each group of 32 channels:
-    // channel n = 32c + 8g + 4e + b is written to row 32c + 16e + 4g + b, so that MFMA sub-tile
-    // (2c+e), accumulator register b of lane group g is channel 32c + 8g + 4e + b: one lane then
-    // owns channels 32c+8g .. +7 (8 consecutive) across the sub-tile pair.
-    int xst[XR], wst[WR];
+    // ---- loader state.  Wave `wid` fills pieces wid, wid+4, ... ; inside a piece lane l owns tile row
+    // 8*piece + (l>>3), LDS slot (l&7).  (row>>1)&7 = (4*(wid&1) + (l>>4)) & 7 for all of them, so the
+    // logical K chunk a lane fetches is the same for every piece it loads.
+    const int lr = lane >> 3;
+    const int lchunk = (lane & 7) ^ ((((wid & 1) << 2) + (lane >> 4)) & 7);
+    int xo[XP];             // byte offset of (pixel row i, tap (0,0), chunk 0); OOB for tail rows (1x1 path)
+    int hi0[XP], wi0[XP];   // top-left input coordinate of the pixel's receptive field (general path)
 #pragma unroll
-    for (int i = 0; i < XR; ++i) xst[i] = lds_off(lrow + 64 * i, lchunk);
+    for (int i = 0; i < XP; ++i) {
+        const int m = bm0 + 8 * (wid + 4 * i) + lr;
+        if constexpr (IS_1X1) {
+            if (a.sh == 1 && a.sw == 1) {
+                xo[i] = m < a.M ? m * a.x_ld * ES : OOB;
+            } else {
+                const int mm = m < a.M ? m : 0;
+                const int n = mm / a.HoWo, rem = mm - n * a.HoWo;
+                const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+                xo[i] = m < a.M ? ((n * a.H + ho * a.sh) * a.W + wo * a.sw) * a.x_ld * ES : OOB;
+            }
+            hi0[i] = wi0[i] = 0;
+        } else {
+            const int mm = m < a.M ? m : 0;
+            const int n = mm / a.HoWo, rem = mm - n * a.HoWo;
+            const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+            hi0[i] = m < a.M ? ho * a.sh - a.ph : -(1 << 28);
+            wi0[i] = wo * a.sw - a.pw;
+            xo[i] = ((n * a.H + hi0[i]) * a.W + wi0[i]) * a.x_ld * ES;   // may be "negative" under padding
+        }
+    }
+    // Filter rows are permuted inside each group of 32 channels: LDS row 32c + 16e + 4g + b holds
+    // channel 32c + 8g + 4e + b, so that MFMA sub-tile (2c+e), accumulator register b of lane group g
+    // is channel 32c + 8g + 4e + b: one lane then owns channels 32c+8g .. +7 across the sub-tile pair.
+    int wo_[WP];
 #pragma unroll
-    for (int j = 0; j < WR; ++j) {
-        const int n = lrow + 64 * j;
-        const int p = (n & ~31) | (((n >> 2) & 1) << 4) | (((n >> 3) & 3) << 2) | (n & 3);
-        wst[j] = BM * 64 + lds_off(p, lchunk);
+    for (int j = 0; j < WP; ++j) {
+        const int rho = 8 * (wid + 4 * j) + lr;
+        const int n = (rho & ~31) | (((rho >> 2) & 3) << 3) | (((rho >> 4) & 1) << 2) | (rho & 3);
+        wo_[j] = (bn0 + n) * a.Kp_bytes;
     }
 
-    // K position of this thread's chunk: q-th chunk -> (tap r,s ; chunk cc inside the tap)
+    // K position of this lane's chunk: q-th chunk -> (tap r,s ; chunk cc inside the tap)
     int q = lchunk;
-    int r, s, cc;
-    {
+    int r = 0, s = 0, cc = 0;
+    if constexpr (!IS_1X1) {
         const int tap = q / a.cpt;
         cc = q - tap * a.cpt;
         r = tap / a.S;
         s = tap - r * a.S;
     }
-
-    u32x4 xa[XR], wa[WR];
-    auto gload = [&]() {
+    auto stage = [&](int buf) {
+        char* b = smem + buf * BUF;
         const bool kv = q < a.kchunks;
-        const int hoff = r * a.dh, woff = s * a.dw;
+        if constexpr (IS_1X1) {
+            const int d = kv ? q * 16 : OOB;
 #pragma unroll
-        for (int i = 0; i < XR; ++i) {
-            const int hi = hi0[i] + hoff, wi = wi0[i] + woff;
-            const bool ok = kv && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-            const char* p = xbase[i] + ((size_t)(hi * a.W + wi) * a.x_ld + cc * VEC) * ES;
-            u32x4 z = {0u, 0u, 0u, 0u};
-            xa[i] = ok ? *reinterpret_cast<const u32x4*>(p) : z;
+            for (int i = 0; i < XP; ++i)
+                lds_dma16(xsrd, b + (wid + 4 * i) * 1024, xo[i] + d);
+        } else {
+            const int hoff = r * a.dh, woff = s * a.dw;
+            const int d = (hoff * a.W + woff) * a.x_ld * ES + cc * 16;
+#pragma unroll
+            for (int i = 0; i < XP; ++i) {
+                const bool ok = kv && (unsigned)(hi0[i] + hoff) < (unsigned)a.H && (unsigned)(wi0[i] + woff) < (unsigned)a.W;
+                lds_dma16(xsrd, b + (wid + 4 * i) * 1024, ok ? xo[i] + d : OOB);
+            }
         }
 #pragma unroll
-        for (int j = 0; j < WR; ++j) wa[j] = *reinterpret_cast<const u32x4*>(wrow[j] + (size_t)q * 16);
+        for (int j = 0; j < WP; ++j)
+            lds_dma16(wsrd, b + BM * 128 + (wid + 4 * j) * 1024, wo_[j] + q * 16);
     };
     auto advance = [&]() {
-        q += 4;
-        cc += 4;
-        while (cc >= a.cpt) {
-            cc -= a.cpt;
-            if (++s == a.S) { s = 0; ++r; }
+        q += 8;
+        if constexpr (!IS_1X1) {
+            cc += 8;
+            while (cc >= a.cpt) {
+                cc -= a.cpt;
+                if (++s == a.S) { s = 0; ++r; }
+            }
         }
     };
-    auto lstore = [&](int buf) {
-        char* b = smem + buf * BUF;
-#pragma unroll
-        for (int i = 0; i < XR; ++i) *reinterpret_cast<u32x4*>(b + xst[i]) = xa[i];
-#pragma unroll
-        for (int j = 0; j < WR; ++j) *reinterpret_cast<u32x4*>(b + wst[j]) = wa[j];
-    };
 
-    // ---- fragment read offsets (per lane constants)
+    // ---- fragment read offsets (per lane constants); sub-tile bases are multiples of 16 rows
     const int wave_m0 = (wid & 1) * WM, wave_n0 = (wid >> 1) * WN;
-    const int frag = lds_off(lane & 15, lane >> 4);  // row (lane&15) of a 16-row sub-tile
-    const int xfrag = wave_m0 * 64 + frag;
-    const int wfrag = BM * 64 + wave_n0 * 64 + frag;
+    const int frow = lane & 15, fg = lane >> 4;
+    int foff[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) foff[ks] = lds_off(frow, 4 * ks + fg);
+    const int xfrag = wave_m0 * 128;
+    const int wfrag = BM * 128 + wave_n0 * 128;
 
     f32x4 acc[CI][PI];
 #pragma unroll
@@ -204,119 +241,200 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
         for (int pi = 0; pi < PI; ++pi) acc[ci][pi] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    gload();
-    lstore(0);
-    __syncthreads();
-
+    stage(0);
     for (int kt = 0; kt < a.ktiles; ++kt) {
-        const bool more = kt + 1 < a.ktiles;
-        if (more) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces of step kt have landed
+        __syncthreads();                                   // ... and everybody's; step kt-1 fully consumed
+        if (kt + 1 < a.ktiles) {
             advance();
-            gload();
+            stage((kt + 1) & 1);
         }
         const char* b = smem + (kt & 1) * BUF;
-        u32x4 wf[CI], xf[PI];
 #pragma unroll
-        for (int ci = 0; ci < CI; ++ci) wf[ci] = *reinterpret_cast<const u32x4*>(b + wfrag + ci * 1024);
+        for (int ks = 0; ks < 2; ++ks) {
+            u32x4 wf[CI], xf[PI];
 #pragma unroll
-        for (int pi = 0; pi < PI; ++pi) xf[pi] = *reinterpret_cast<const u32x4*>(b + xfrag + pi * 1024);
+            for (int ci = 0; ci < CI; ++ci)
+                wf[ci] = *reinterpret_cast<const u32x4*>(b + wfrag + ci * 2048 + foff[ks]);
 #pragma unroll
-        for (int ci = 0; ci < CI; ++ci)
+            for (int pi = 0; pi < PI; ++pi)
+                xf[pi] = *reinterpret_cast<const u32x4*>(b + xfrag + pi * 2048 + foff[ks]);
 #pragma unroll
-            for (int pi = 0; pi < PI; ++pi) acc[ci][pi] = Mma<T>::run(wf[ci], xf[pi], acc[ci][pi]);
-        if (more) lstore((kt + 1) & 1);
-        __syncthreads();
+            for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+                for (int pi = 0; pi < PI; ++pi) acc[ci][pi] = Mma<T>::run(wf[ci], xf[pi], acc[ci][pi]);
+        }
     }
 
-    // ---- epilogue: y = act(acc*scale + shift (+res)) (+res), 8 consecutive channels per lane
-    const int g = lane >> 4, px = lane & 15;
-    constexpr int CP = CI / 2;
-    float sc[CP][8], sf[CP][8];
-#pragma unroll
-    for (int cp = 0; cp < CP; ++cp) {
-        const int ch0 = bn0 + wave_n0 + 32 * cp + 8 * g;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int ch = ch0 + e;
-            const bool in = ch < a.Cout;
-            sc[cp][e] = (a.scale && in) ? a.scale[ch] : 1.f;
-            sf[cp][e] = (a.shift && in) ? a.shift[ch] : 0.f;
-        }
-    }
-    const bool res_after = (a.flags & TLXMI_EPI_RES_AFTER_ACT) != 0;
-#pragma unroll
-    for (int pi = 0; pi < PI; ++pi) {
-        const int m = bm0 + wave_m0 + pi * 16 + px;
-        if (m >= a.M) continue;
-        size_t yrow = (size_t)m * a.y_ld, rrow = (size_t)m * a.res_ld;
-        if (a.strided_n) {
-            const int n = m / a.HoWo, p = m - n * a.HoWo;
-            yrow = (size_t)n * a.y_nstride + (size_t)p * a.y_ld;
-            rrow = (size_t)n * a.res_nstride + (size_t)p * a.res_ld;
-        }
+    // ---- epilogue, phase 1: acc*scale + shift -> fp32 tile in LDS (re-using the stage buffers).
+    // Row = pixel, BN floats per row; 16-byte chunk j of row r is stored at chunk j ^ (r & 7) so the
+    // eight lanes a ds_write_b128 serves at a time (eight pixels, same channels) hit distinct banks.
+    __syncthreads();  // every wave is done reading the stage buffers
+    float* Ct = reinterpret_cast<float*>(smem);
+    {
+        const int g = lane >> 4, px = lane & 15;
+        constexpr int CP = CI / 2;
 #pragma unroll
         for (int cp = 0; cp < CP; ++cp) {
-            const int ch0 = bn0 + wave_n0 + 32 * cp + 8 * g;
-            if (ch0 >= a.Cout) continue;
-            float v[8];
+            const int col = wave_n0 + 32 * cp + 8 * g;  // tile-local first channel of this lane's 8
+            const int ch0 = bn0 + col;
+            float sc[8], sf[8];
 #pragma unroll
-            for (int e = 0; e < 2; ++e)
+            for (int e = 0; e < 8; ++e) {
+                const int ch = ch0 + e < a.Cout ? ch0 + e : a.Cout - 1;
+                sc[e] = a.scale ? a.scale[ch] : 1.f;
+                sf[e] = a.shift ? a.shift[ch] : 0.f;
+            }
 #pragma unroll
-                for (int bb = 0; bb < 4; ++bb)
-                    v[e * 4 + bb] = acc[2 * cp + e][pi][bb] * sc[cp][e * 4 + bb] + sf[cp][e * 4 + bb];
-            const bool full = a.vec_io && (ch0 + 8 <= a.Cout);
-            float rv[8];
-            if (a.res) {
-                const char* rp = a.res + (rrow + ch0) * ES;
-                if (full) {
-                    load8<T>(rp, rv);
-                } else {
+            for (int pi = 0; pi < PI; ++pi) {
+                const int row = wave_m0 + pi * 16 + px;
+                f32x4 lo, hi;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        rv[e] = (ch0 + e < a.Cout) ? (float)reinterpret_cast<const T*>(rp)[e] : 0.f;
+                for (int bb = 0; bb < 4; ++bb) {
+                    lo[bb] = acc[2 * cp][pi][bb] * sc[bb] + sf[bb];
+                    hi[bb] = acc[2 * cp + 1][pi][bb] * sc[4 + bb] + sf[4 + bb];
                 }
-                if (!res_after) {
+                const int c16 = col >> 2;
+                *reinterpret_cast<f32x4*>(Ct + row * BN + (((c16) ^ (row & 7)) << 2)) = lo;
+                *reinterpret_cast<f32x4*>(Ct + row * BN + (((c16 + 1) ^ (row & 7)) << 2)) = hi;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- epilogue, phase 2: whole rows leave the block: BN/8 consecutive lanes cover one pixel's BN
+    // channels (full 128-byte lines); the residual is read the same way.
+    {
+        constexpr int CPR = BN / 8;          // 8-channel chunks per row
+        constexpr int RPP = 256 / CPR;       // rows per pass
+        constexpr int NIT = BM / RPP;
+        const int chunk = t % CPR;
+        const int ch0 = bn0 + 8 * chunk;
+        const bool res_after = (a.flags & TLXMI_EPI_RES_AFTER_ACT) != 0;
+        const bool full = a.vec_io && (ch0 + 8 <= a.Cout);
+        if (ch0 < a.Cout) {
+            const int row0 = t / CPR;
+            const char* rp = a.res ? a.res + ((size_t)(bm0 + row0) * a.res_ld + ch0) * ES : nullptr;
+            char* yp = a.y + ((size_t)(bm0 + row0) * a.y_ld + ch0) * ES;
+            const size_t ystep = (size_t)RPP * a.y_ld * ES, rstep = (size_t)RPP * a.res_ld * ES;
+#pragma unroll 4
+            for (int it = 0; it < NIT; ++it) {
+                const int row = row0 + it * RPP;
+                const int m = bm0 + row;
+                if (m >= a.M) break;
+                if (a.strided_n) {
+                    const int n = m / a.HoWo, p = m - n * a.HoWo;
+                    yp = a.y + ((size_t)n * a.y_nstride + (size_t)p * a.y_ld + ch0) * ES;
+                    if (a.res) rp = a.res + ((size_t)n * a.res_nstride + (size_t)p * a.res_ld + ch0) * ES;
+                }
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(Ct + row * BN + (((2 * chunk) ^ (row & 7)) << 2));
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(Ct + row * BN + (((2 * chunk + 1) ^ (row & 7)) << 2));
+                float v[8];
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) { v[bb] = lo[bb]; v[4 + bb] = hi[bb]; }
+                float rv[8];
+                if (a.res) {
+                    if (full) {
+                        load8<T>(rp, rv);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            rv[e] = (ch0 + e < a.Cout) ? (float)reinterpret_cast<const T*>(rp)[e] : 0.f;
+                    }
+                    if (!res_after) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += rv[e];
+                    }
+                }
+                if (a.act == TLXMI_ACT_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                } else if (a.act != TLXMI_ACT_NONE) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e], a.act, a.act_param);
+                }
+                if (a.res && res_after) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += rv[e];
                 }
-            }
-            if (a.act != TLXMI_ACT_NONE) {
+                if (full) {
+                    store8<T>(yp, v);
+                } else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e], a.act, a.act_param);
-            }
-            if (a.res && res_after) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += rv[e];
-            }
-            char* yp = a.y + (yrow + ch0) * ES;
-            if (full) {
-                store8<T>(yp, v);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    if (ch0 + e < a.Cout) reinterpret_cast<T*>(yp)[e] = (T)v[e];
+                    for (int e = 0; e < 8; ++e)
+                        if (ch0 + e < a.Cout) reinterpret_cast<T*>(yp)[e] = (T)v[e];
+                }
+                yp += ystep;
+                rp += rstep;
             }
         }
     }
+}
+
+// resident blocks per CU for a tile shape: LDS bound (160 KiB) and the register allocation hipcc
+// reports for this kernel (128x128: 156 -> 3 waves/SIMD, others <= 128 -> 4)
+template <int BM, int BN> static inline size_t lds_bytes(int ktiles) {
+    size_t lds = (size_t)(ktiles > 1 ? 2 : 1) * (BM + BN) * 128;
+    if (lds < (size_t)BM * BN * 4) lds = (size_t)BM * BN * 4;
+    return lds;
 }
 
 template <typename T, int BM, int BN> static void launch(const ConvArgs& a, hipStream_t st) {
     ConvArgs b = a;
     b.mtiles = (a.M + BM - 1) / BM;
     b.ntiles = (a.Cout + BN - 1) / BN;
-    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN>), dim3(b.mtiles * b.ntiles), dim3(256), 0, st, b);
+    const size_t lds = lds_bytes<BM, BN>(a.ktiles);
+    const long grid = (long)b.mtiles * b.ntiles;
+    const bool is1x1 = a.R == 1 && a.S == 1 && a.ph == 0 && a.pw == 0;
+    if (is1x1)
+        hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, true>), dim3((unsigned)grid), dim3(256), lds, st, b);
+    else
+        hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, false>), dim3((unsigned)grid), dim3(256), lds, st, b);
+}
+
+static int g_num_cus = 0;
+static int num_cus() {
+    if (g_num_cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess)
+            g_num_cus = p.multiProcessorCount;
+        if (g_num_cus <= 0) g_num_cus = 256;
+    }
+    return g_num_cus;
 }
 
 template <typename T> static void dispatch(const ConvArgs& a, hipStream_t st) {
-    // Tile choice: narrow N tile for Cout <= 64; halve the pixel tile when the 128-pixel grid
-    // would leave most of the 256 CUs (x ~3 resident blocks) without work.
-    const bool n64 = a.Cout <= 64;
-    const long tiles128 = (long)((a.M + 127) / 128) * ((a.Cout + (n64 ? 63 : 127)) / (n64 ? 64 : 128));
-    const bool m64 = tiles128 < 512;
-    if (n64) {
-        if (m64) launch<T, 64, 64>(a, st); else launch<T, 128, 64>(a, st);
-    } else {
-        if (m64) launch<T, 64, 128>(a, st); else launch<T, 128, 128>(a, st);
+    // Tile choice = max over the four shapes of (grid quantisation efficiency) x (shape efficiency):
+    // a launch of B blocks on S = CUs x resident-blocks-per-CU slots runs ceil(B/S) rounds, so B/(rounds*S)
+    // of the machine does useful work; bigger tiles re-use operands better (fewer LDS bytes per MFMA).
+    struct Cand { int bm, bn; float eff; };
+    const Cand cands[4] = {{128, 128, 1.00f}, {64, 128, 0.88f}, {128, 64, 0.88f}, {64, 64, 0.75f}};
+    const int cus = num_cus();
+    int best = 0;
+    float best_score = -1.f;
+    for (int i = 0; i < 4; ++i) {
+        const int bm = cands[i].bm, bn = cands[i].bn;
+        if (bn == 128 && a.Cout <= 64) continue;
+        size_t lds = (size_t)(a.ktiles > 1 ? 2 : 1) * (bm + bn) * 128;
+        if (lds < (size_t)bm * bn * 4) lds = (size_t)bm * bn * 4;
+        int per_cu = (int)((160 * 1024) / lds);
+        const int reg_cap = (bm == 128 && bn == 128) ? 3 : ((bm == 64 && bn == 64) ? 8 : 5);
+        if (per_cu > reg_cap) per_cu = reg_cap;
+        const long blocks = (long)((a.M + bm - 1) / bm) * ((a.Cout + bn - 1) / bn);
+        const long slots = (long)cus * per_cu;
+        const long rounds = (blocks + slots - 1) / slots;
+        const float quant = (float)blocks / (float)(rounds * slots);
+        // wasted work inside partial tiles
+        const float fill = ((float)a.M * a.Cout) / ((float)blocks * bm * bn);
+        const float score = quant * fill * cands[i].eff;
+        if (score > best_score) { best_score = score; best = i; }
+    }
+    switch (best) {
+        case 0: launch<T, 128, 128>(a, st); break;
+        case 1: launch<T, 64, 128>(a, st); break;
+        case 2: launch<T, 128, 64>(a, st); break;
+        default: launch<T, 64, 64>(a, st); break;
     }
 }
 
@@ -346,8 +464,9 @@ extern "C" int tlxmi_conv2d(const tlxmi_conv2d_desc* d, const void* x, const voi
     TLXMI_REQUIRE(d->act >= TLXMI_ACT_NONE && d->act <= TLXMI_ACT_SILU, TLXMI_ERR_BAD_ARG, "conv2d: bad act %d", d->act);
     TLXMI_REQUIRE(!res || d->res_ld >= d->Cout, TLXMI_ERR_BAD_ARG, "conv2d: res_ld=%d < Cout", d->res_ld);
     const long long M = (long long)d->N * Ho * Wo;
-    TLXMI_REQUIRE(M < (1ll << 31) && (long long)d->H * d->W * d->x_ld < (1ll << 31), TLXMI_ERR_UNSUPPORTED,
-                  "conv2d: extent exceeds 32-bit pixel indexing");
+    const long long x_bytes = (long long)d->N * d->H * d->W * d->x_ld * es;
+    TLXMI_REQUIRE(M < (1ll << 31) && x_bytes < (1ll << 31) && M * (long long)d->y_ld * es < (1ll << 40), TLXMI_ERR_UNSUPPORTED,
+                  "conv2d: input of %lld bytes exceeds the 2 GiB the 32-bit buffer offsets address", x_bytes);
 
     ConvArgs a;
     a.x = (const char*)x; a.w = (const char*)w_packed; a.y = (char*)y;
@@ -359,9 +478,11 @@ extern "C" int tlxmi_conv2d(const tlxmi_conv2d_desc* d, const void* x, const voi
     a.M = (int)M; a.HoWo = Ho * Wo;
     a.cpt = d->C * es / 16;
     a.kchunks = d->R * d->S * a.cpt;
-    a.ktiles = (a.kchunks + 3) / 4;
-    a.Kp_bytes = a.ktiles * 64;
+    a.ktiles = (a.kchunks + 7) / 8;
+    a.Kp_bytes = a.ktiles * 128;
     a.mtiles = a.ntiles = 0;
+    a.x_bytes = (unsigned)x_bytes;
+    a.w_bytes = (unsigned)(((size_t)(d->Cout + 127) / 128 * 128) * (size_t)a.Kp_bytes);
     const int vecn = 16 / es;  // elements per 16 bytes
     const bool bcast = res && (d->flags & TLXMI_EPI_RES_BCAST_N);
     TLXMI_REQUIRE(d->y_nstride >= 0 && d->res_nstride >= 0, TLXMI_ERR_BAD_ARG, "conv2d: negative batch stride");
@@ -383,7 +504,7 @@ static inline int cin_pad(int Cin, int dtype) { const int v = 16 / (int)elt_size
 static inline int kpad_elems(int Cin, int R, int S, int dtype) {
     const int es = (int)elt_size(dtype);
     const int kbytes = R * S * cin_pad(Cin, dtype) * es;
-    return ((kbytes + 63) / 64 * 64) / es;
+    return ((kbytes + 127) / 128 * 128) / es;
 }
 template <typename T>
 __global__ void pack_filter_kernel(const float* __restrict__ src, T* __restrict__ dst, int Cout, int Cin, int R,
