@@ -48,6 +48,17 @@ __device__ __forceinline__ float apply_act(float x, int act, float p) {
     }
 }
 
+// GELU for the fp16 throughput path: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far inside
+// fp16 resolution) = one v_rcp + one v_exp + a 5-term Horner chain instead of libm's erff.
+__device__ __forceinline__ float gelu_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __frcp_rn(1.f + 0.3275911f * z);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float erf_abs = 1.f - poly * __expf(-z * z);
+    const float erf = x < 0.f ? -erf_abs : erf_abs;
+    return 0.5f * x * (1.f + erf);
+}
+
 // ---- wave64 reductions --------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

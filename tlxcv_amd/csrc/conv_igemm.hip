@@ -27,6 +27,7 @@
 // chunk (l&7) ^ ((r>>1)&7) of its row.  Pieces are dealt to waves so that this chunk index is
 // the same for every piece a lane loads (one im2col position per lane per step).
 #include "common.h"
+#include <stdlib.h>
 
 namespace tlxmi {
 
@@ -115,12 +116,14 @@ static __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const char* p,
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p), 0, bytes, 0x00020000);
 }
 
-template <typename T, int BM, int BN, bool IS_1X1>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
+// WGM = waves along the pixel axis (2 or 4; always 2 along channels), STAGES = LDS-DMA ring depth.
+template <typename T, int BM, int BN, bool IS_1X1, int WGM, int STAGES>
+__global__ __launch_bounds__(WGM * 128) void conv_igemm_kernel(const ConvArgs a) {
     constexpr int ES = (int)sizeof(T);
-    constexpr int WM = BM / 2, WN = BN / 2;  // wave tile (pixels x channels)
+    constexpr int NW = WGM * 2, NT = NW * 64;     // waves, threads
+    constexpr int WM = BM / WGM, WN = BN / 2;     // wave tile (pixels x channels)
     constexpr int PI = WM / 16, CI = WN / 16;
-    constexpr int XP = BM / 32, WP = BN / 32;  // 1-KiB pieces per wave per K-step
+    constexpr int XP = BM / 8 / NW, WP = BN / 8 / NW;  // 1-KiB pieces per wave per K-step
     constexpr int BUF = (BM + BN) * 128;
     constexpr int OOB = (int)0x80000000;       // any offset >= 2^31 fails the descriptor range check -> zeros
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     int hi0[XP], wi0[XP];   // top-left input coordinate of the pixel's receptive field (general path)
 #pragma unroll
     for (int i = 0; i < XP; ++i) {
-        const int m = bm0 + 8 * (wid + 4 * i) + lr;
+        const int m = bm0 + 8 * (wid + NW * i) + lr;
         if constexpr (IS_1X1) {
             if (a.sh == 1 && a.sw == 1) {
                 xo[i] = m < a.M ? m * a.x_ld * ES : OOB;
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     int wo_[WP];
 #pragma unroll
     for (int j = 0; j < WP; ++j) {
-        const int rho = 8 * (wid + 4 * j) + lr;
+        const int rho = 8 * (wid + NW * j) + lr;
         const int n = (rho & ~31) | (((rho >> 2) & 3) << 3) | (((rho >> 4) & 1) << 2) | (rho & 3);
         wo_[j] = (bn0 + n) * a.Kp_bytes;
     }
@@ -201,19 +204,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
             const int d = kv ? q * 16 : OOB;
 #pragma unroll
             for (int i = 0; i < XP; ++i)
-                lds_dma16(xsrd, b + (wid + 4 * i) * 1024, xo[i] + d);
+                lds_dma16(xsrd, b + (wid + NW * i) * 1024, xo[i] + d);
         } else {
             const int hoff = r * a.dh, woff = s * a.dw;
             const int d = (hoff * a.W + woff) * a.x_ld * ES + cc * 16;
 #pragma unroll
             for (int i = 0; i < XP; ++i) {
                 const bool ok = kv && (unsigned)(hi0[i] + hoff) < (unsigned)a.H && (unsigned)(wi0[i] + woff) < (unsigned)a.W;
-                lds_dma16(xsrd, b + (wid + 4 * i) * 1024, ok ? xo[i] + d : OOB);
+                lds_dma16(xsrd, b + (wid + NW * i) * 1024, ok ? xo[i] + d : OOB);
             }
         }
 #pragma unroll
         for (int j = 0; j < WP; ++j)
-            lds_dma16(wsrd, b + BM * 128 + (wid + 4 * j) * 1024, wo_[j] + q * 16);
+            lds_dma16(wsrd, b + BM * 128 + (wid + NW * j) * 1024, wo_[j] + q * 16);
     };
     auto advance = [&]() {
         q += 8;
@@ -227,7 +230,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     };
 
     // ---- fragment read offsets (per lane constants); sub-tile bases are multiples of 16 rows
-    const int wave_m0 = (wid & 1) * WM, wave_n0 = (wid >> 1) * WN;
+    const int wave_m0 = (wid % WGM) * WM, wave_n0 = (wid / WGM) * WN;
     const int frow = lane & 15, fg = lane >> 4;
     int foff[2];
 #pragma unroll
@@ -241,15 +244,32 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
         for (int pi = 0; pi < PI; ++pi) acc[ci][pi] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // ---- K loop.  The DMA ring runs STAGES-1 steps ahead of the MFMAs; one barrier per step:
+    //   wait (counted vmcnt) until this wave's pieces of step kt have landed, barrier (everyone's have,
+    //   and everyone is done reading the buffer of step kt-1), re-fill that buffer with step kt+STAGES-1.
     stage(0);
+    if constexpr (STAGES == 3) {
+        if (a.ktiles > 1) { advance(); stage(1); }
+    }
+    int buf = 0;
     for (int kt = 0; kt < a.ktiles; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces of step kt have landed
-        __syncthreads();                                   // ... and everybody's; step kt-1 fully consumed
-        if (kt + 1 < a.ktiles) {
-            advance();
-            stage((kt + 1) & 1);
+        if constexpr (STAGES == 3) {
+            if (kt + 1 < a.ktiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XP + WP) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + 2 < a.ktiles) {
+                advance();
+                stage(buf >= 1 ? buf - 1 : 2);   // (kt + 2) % 3
+            }
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + 1 < a.ktiles) {
+                advance();
+                stage(buf ^ 1);
+            }
         }
-        const char* b = smem + (kt & 1) * BUF;
+        const char* b = smem + buf * BUF;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             u32x4 wf[CI], xf[PI];
@@ -264,6 +284,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int pi = 0; pi < PI; ++pi) acc[ci][pi] = Mma<T>::run(wf[ci], xf[pi], acc[ci][pi]);
         }
+        buf = (buf + 1 == STAGES) ? 0 : buf + 1;
     }
 
     // ---- epilogue, phase 1: acc*scale + shift -> fp32 tile in LDS (re-using the stage buffers).
@@ -306,7 +327,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     // channels (full 128-byte lines); the residual is read the same way.
     {
         constexpr int CPR = BN / 8;          // 8-channel chunks per row
-        constexpr int RPP = 256 / CPR;       // rows per pass
+        constexpr int RPP = NT / CPR;        // rows per pass
         constexpr int NIT = BM / RPP;
         const int chunk = t % CPR;
         const int ch0 = bn0 + 8 * chunk;
@@ -349,6 +370,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
                 if (a.act == TLXMI_ACT_RELU) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                } else if (sizeof(T) == 2 && a.act == TLXMI_ACT_GELU) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
                 } else if (a.act != TLXMI_ACT_NONE) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e], a.act, a.act_param);
@@ -373,23 +397,30 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 
 // resident blocks per CU for a tile shape: LDS bound (160 KiB) and the register allocation hipcc
 // reports for this kernel (128x128: 156 -> 3 waves/SIMD, others <= 128 -> 4)
-template <int BM, int BN> static inline size_t lds_bytes(int ktiles) {
-    size_t lds = (size_t)(ktiles > 1 ? 2 : 1) * (BM + BN) * 128;
-    if (lds < (size_t)BM * BN * 4) lds = (size_t)BM * BN * 4;
-    return lds;
-}
-
-template <typename T, int BM, int BN> static void launch(const ConvArgs& a, hipStream_t st) {
+template <typename T, int BM, int BN, int WGM, int STAGES> static int launch(const ConvArgs& a, hipStream_t st) {
     ConvArgs b = a;
     b.mtiles = (a.M + BM - 1) / BM;
     b.ntiles = (a.Cout + BN - 1) / BN;
-    const size_t lds = lds_bytes<BM, BN>(a.ktiles);
+    // LDS: the DMA ring (one buffer is enough when K fits a single step), re-used by the fp32 epilogue tile
+    size_t lds = (size_t)(a.ktiles > 1 ? STAGES : 1) * (BM + BN) * 128;
+    if (lds < (size_t)BM * BN * 4) lds = (size_t)BM * BN * 4;
     const long grid = (long)b.mtiles * b.ntiles;
     const bool is1x1 = a.R == 1 && a.S == 1 && a.ph == 0 && a.pw == 0;
+    if (lds > 64 * 1024) {
+        static bool raised[2] = {false, false};
+        if (!raised[is1x1]) {
+            const void* fn = is1x1 ? reinterpret_cast<const void*>(&conv_igemm_kernel<T, BM, BN, true, WGM, STAGES>)
+                                   : reinterpret_cast<const void*>(&conv_igemm_kernel<T, BM, BN, false, WGM, STAGES>);
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return fail(TLXMI_ERR_LAUNCH, "conv2d: cannot raise LDS limit: %s", hipGetErrorString(e));
+            raised[is1x1] = true;
+        }
+    }
     if (is1x1)
-        hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, true>), dim3((unsigned)grid), dim3(256), lds, st, b);
+        hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, true, WGM, STAGES>), dim3((unsigned)grid), dim3(WGM * 128), lds, st, b);
     else
-        hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, false>), dim3((unsigned)grid), dim3(256), lds, st, b);
+        hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, false, WGM, STAGES>), dim3((unsigned)grid), dim3(WGM * 128), lds, st, b);
+    return TLXMI_OK;
 }
 
 static int g_num_cus = 0;
@@ -404,22 +435,33 @@ static int num_cus() {
     return g_num_cus;
 }
 
-template <typename T> static void dispatch(const ConvArgs& a, hipStream_t st) {
+template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st) {
     // Tile choice = max over the four shapes of (grid quantisation efficiency) x (shape efficiency):
     // a launch of B blocks on S = CUs x resident-blocks-per-CU slots runs ceil(B/S) rounds, so B/(rounds*S)
     // of the machine does useful work; bigger tiles re-use operands better (fewer LDS bytes per MFMA).
+    // The shape efficiency depends on the regime (measured on MI355X, tools/conv_micro.py sweep): layers
+    // that move many output/residual bytes per FLOP (the 1x1 "expand" convs with a skip connection) are
+    // latency/HBM-bound and want many small resident blocks; MFMA-bound layers want the 128x128 tile.
     struct Cand { int bm, bn; float eff; };
-    const Cand cands[4] = {{128, 128, 1.00f}, {64, 128, 0.88f}, {128, 64, 0.88f}, {64, 64, 0.75f}};
+    const double flops = 2.0 * a.M * (double)a.Cout * a.kchunks * (16 / (int)sizeof(T));
+    const double obytes = (double)a.M * a.Cout * sizeof(T) * (a.res ? 2.0 : 1.0);
+    const double obi = obytes / flops;
+    // candidate 4 = 256x128 pixels x channels, 8 waves, 3-deep DMA ring (one block per CU): MFMA-bound layers
+    Cand cands[5] = {{128, 128, 1.00f}, {64, 128, 0.85f}, {128, 64, 0.85f}, {64, 64, 0.70f}, {256, 128, 1.10f}};
+    if (obi >= 0.0015 || a.ktiles < 4) cands[4].eff = 0.f;
+    if (obi >= 0.012) { cands[0].eff = 0.65f; cands[1].eff = 0.80f; cands[2].eff = 0.85f; cands[3].eff = 1.00f; }
+    else if (obi >= 0.0015) { cands[0].eff = 0.85f; cands[1].eff = 0.90f; cands[2].eff = 1.00f; cands[3].eff = 0.90f; }
     const int cus = num_cus();
     int best = 0;
     float best_score = -1.f;
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 5; ++i) {
         const int bm = cands[i].bm, bn = cands[i].bn;
+        if (cands[i].eff <= 0.f) continue;
         if (bn == 128 && a.Cout <= 64) continue;
-        size_t lds = (size_t)(a.ktiles > 1 ? 2 : 1) * (bm + bn) * 128;
+        size_t lds = (size_t)(a.ktiles > 1 ? (i == 4 ? 3 : 2) : 1) * (bm + bn) * 128;
         if (lds < (size_t)bm * bn * 4) lds = (size_t)bm * bn * 4;
         int per_cu = (int)((160 * 1024) / lds);
-        const int reg_cap = (bm == 128 && bn == 128) ? 3 : ((bm == 64 && bn == 64) ? 8 : 5);
+        const int reg_cap = i == 4 ? 1 : (bm == 128 && bn == 128) ? 3 : ((bm == 64 && bn == 64) ? 8 : 5);
         if (per_cu > reg_cap) per_cu = reg_cap;
         const long blocks = (long)((a.M + bm - 1) / bm) * ((a.Cout + bn - 1) / bn);
         const long slots = (long)cus * per_cu;
@@ -430,11 +472,14 @@ template <typename T> static void dispatch(const ConvArgs& a, hipStream_t st) {
         const float score = quant * fill * cands[i].eff;
         if (score > best_score) { best_score = score; best = i; }
     }
+    static const int forced = [] { const char* e = getenv("TLXMI_TILE"); return e ? atoi(e) : -1; }();  // tuning aid
+    if (forced >= 0 && forced < 5 && !(cands[forced].bn == 128 && a.Cout <= 64)) best = forced;
     switch (best) {
-        case 0: launch<T, 128, 128>(a, st); break;
-        case 1: launch<T, 64, 128>(a, st); break;
-        case 2: launch<T, 128, 64>(a, st); break;
-        default: launch<T, 64, 64>(a, st); break;
+        case 0: return launch<T, 128, 128, 2, 2>(a, st);
+        case 1: return launch<T, 64, 128, 2, 2>(a, st);
+        case 2: return launch<T, 128, 64, 2, 2>(a, st);
+        case 4: return launch<T, 256, 128, 4, 3>(a, st);
+        default: return launch<T, 64, 64, 2, 2>(a, st);
     }
 }
 
@@ -491,8 +536,8 @@ extern "C" int tlxmi_conv2d(const tlxmi_conv2d_desc* d, const void* x, const voi
     a.strided_n = (d->y_nstride != 0) || (res && (d->res_nstride != 0 || bcast));
     a.vec_io = aligned16(y) && (d->y_ld % vecn == 0) && (a.y_nstride % vecn == 0) &&
                (!res || (aligned16(res) && d->res_ld % vecn == 0 && a.res_nstride % vecn == 0));
-    if (d->dtype == TLXMI_F16) dispatch<half_t>(a, as_stream(stream));
-    else dispatch<float>(a, as_stream(stream));
+    const int rc = d->dtype == TLXMI_F16 ? dispatch<half_t>(a, as_stream(stream)) : dispatch<float>(a, as_stream(stream));
+    if (rc != TLXMI_OK) return rc;
     return check_launch("conv2d");
 }
 

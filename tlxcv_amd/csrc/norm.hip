@@ -7,72 +7,81 @@
 
 namespace tlxmi {
 
-template <typename T, int NCH>  // NCH = 16-byte chunks per lane
+template <typename T, int NCH, int RW>  // NCH = 16-byte chunks per lane and row, RW = rows per wave
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, T* __restrict__ y, long rows,
                                                         int C, int x_ld, int y_ld, float eps) {
     constexpr int V = 16 / (int)sizeof(T);
     const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RW;
+    if (row0 >= rows) return;
     const int nch = C / V;
-    float v[NCH][V];
-    float sum = 0.f;
+    // all RW x NCH 16-byte loads of this wave are issued before the first reduction: the kernel is a
+    // pure HBM stream and needs the bytes in flight, not the arithmetic
+    u32x4 raw[RW][NCH];
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        const int ch = lane + 64 * i;
-        if (ch < nch) {
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int ch = lane + 64 * i;
+            raw[r][i] = u32x4{0u, 0u, 0u, 0u};
+            if (ch < nch && row0 + r < rows)
+                raw[r][i] = *reinterpret_cast<const u32x4*>(x + (row0 + r) * x_ld + ch * V);
+        }
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        if (row0 + r >= rows) break;
+        float v[NCH][V];
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
             if constexpr (sizeof(T) == 2) {
-                half8v h = *reinterpret_cast<const half8v*>(x + row * x_ld + ch * V);
+                const half8v h = __builtin_bit_cast(half8v, raw[r][i]);
 #pragma unroll
                 for (int e = 0; e < V; ++e) v[i][e] = (float)h[e];
             } else {
-                f32x4 h = *reinterpret_cast<const f32x4*>(x + row * x_ld + ch * V);
+                const f32x4 h = __builtin_bit_cast(f32x4, raw[r][i]);
 #pragma unroll
                 for (int e = 0; e < V; ++e) v[i][e] = h[e];
             }
 #pragma unroll
-            for (int e = 0; e < V; ++e) sum += v[i][e];
-        } else {
-#pragma unroll
-            for (int e = 0; e < V; ++e) v[i][e] = 0.f;
+            for (int e = 0; e < V; ++e) sum += v[i][e];   // lanes past the row hold zeros
         }
-    }
-    const float mean = wave_sum(sum) / (float)C;
-    float sq = 0.f;
+        const float mean = wave_sum(sum) / (float)C;
+        float sq = 0.f;
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        const int ch = lane + 64 * i;
-        if (ch < nch) {
+        for (int i = 0; i < NCH; ++i) {
+            if (lane + 64 * i < nch) {
 #pragma unroll
-            for (int e = 0; e < V; ++e) {
-                const float d = v[i][e] - mean;
-                sq += d * d;
+                for (int e = 0; e < V; ++e) {
+                    const float d = v[i][e] - mean;
+                    sq += d * d;
+                }
             }
         }
-    }
-    const float rstd = 1.f / sqrtf(wave_sum(sq) / (float)C + eps);
+        const float rstd = 1.f / sqrtf(wave_sum(sq) / (float)C + eps);
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        const int ch = lane + 64 * i;
-        if (ch < nch) {
-            float o[V];
+        for (int i = 0; i < NCH; ++i) {
+            const int ch = lane + 64 * i;
+            if (ch < nch) {
+                float o[V];
 #pragma unroll
-            for (int e = 0; e < V; ++e) {
-                const int c = ch * V + e;
-                const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-                o[e] = (v[i][e] - mean) * rstd * g + b;
-            }
-            if constexpr (sizeof(T) == 2) {
-                half8v h;
+                for (int e = 0; e < V; ++e) {
+                    const int c = ch * V + e;
+                    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+                    o[e] = (v[i][e] - mean) * rstd * g + b;
+                }
+                if constexpr (sizeof(T) == 2) {
+                    half8v h;
 #pragma unroll
-                for (int e = 0; e < V; ++e) h[e] = (half_t)o[e];
-                *reinterpret_cast<half8v*>(y + row * y_ld + ch * V) = h;
-            } else {
-                f32x4 h;
+                    for (int e = 0; e < V; ++e) h[e] = (half_t)o[e];
+                    *reinterpret_cast<half8v*>(y + (row0 + r) * y_ld + ch * V) = h;
+                } else {
+                    f32x4 h;
 #pragma unroll
-                for (int e = 0; e < V; ++e) h[e] = o[e];
-                *reinterpret_cast<f32x4*>(y + row * y_ld + ch * V) = h;
+                    for (int e = 0; e < V; ++e) h[e] = o[e];
+                    *reinterpret_cast<f32x4*>(y + (row0 + r) * y_ld + ch * V) = h;
+                }
             }
         }
     }
@@ -83,15 +92,14 @@ static int launch_ln(const void* x, const float* gamma, const float* beta, void*
                      int y_ld, float eps, hipStream_t st) {
     constexpr int V = 16 / (int)sizeof(T);
     const int per_lane = (C / V + 63) / 64;
-    dim3 g((unsigned)((rows + 3) / 4)), b(256);
-#define LN_CASE(n)                                                                                              \
-    hipLaunchKernelGGL((layernorm_kernel<T, n>), g, b, 0, st, (const T*)x, gamma, beta, (T*)y, rows, C, x_ld, \
-                       y_ld, eps)
-    if (per_lane <= 1) LN_CASE(1);
-    else if (per_lane <= 2) LN_CASE(2);
-    else if (per_lane <= 4) LN_CASE(4);
-    else if (per_lane <= 8) LN_CASE(8);
-    else if (per_lane <= 16) LN_CASE(16);
+#define LN_CASE(n, rw)                                                                                            \
+    hipLaunchKernelGGL((layernorm_kernel<T, n, rw>), dim3((unsigned)((rows + 4 * rw - 1) / (4 * rw))), dim3(256), 0, \
+                       st, (const T*)x, gamma, beta, (T*)y, rows, C, x_ld, y_ld, eps)
+    if (per_lane <= 1) LN_CASE(1, 4);
+    else if (per_lane <= 2) LN_CASE(2, 4);
+    else if (per_lane <= 4) LN_CASE(4, 2);
+    else if (per_lane <= 8) LN_CASE(8, 1);
+    else if (per_lane <= 16) LN_CASE(16, 1);
     else return fail(TLXMI_ERR_UNSUPPORTED, "layernorm: C=%d too wide for the in-register row kernel", C);
 #undef LN_CASE
     return check_launch("layernorm");
