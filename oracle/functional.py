@@ -178,3 +178,202 @@ def vit(p, x, arch="vit_base_patch16_224"):
         t = vit_block(p, f"blocks.{i}", t, c["heads"], scale, c["eps"])
     t = layernorm(p, "norm", t, c["eps"])                                            # :327
     return linear(p, "head", t[:, 0])                                                # :328, :332
+
+
+# ---------------------------------------------------------------------------------------------
+# Swin Transformer — models/classification/swin_transformer.py (Paddle-only file in the reference:
+# restated from the text, cannot be imported here)
+# ---------------------------------------------------------------------------------------------
+SWIN_CFG = {  # _swin_transformer, swin_transformer.py:628-650
+    "swintransformer_tiny_patch4_window7_224": dict(img=224, dim=96, depths=[2, 2, 6, 2], heads=[3, 6, 12, 24], ws=7),
+    "swintransformer_small_patch4_window7_224": dict(img=224, dim=96, depths=[2, 2, 18, 2], heads=[3, 6, 12, 24], ws=7),
+    "swintransformer_base_patch4_window7_224": dict(img=224, dim=128, depths=[2, 2, 18, 2], heads=[4, 8, 16, 32], ws=7),
+}
+LN_EPS = 1e-5  # nn.LayerNorm default [TLX-recalled]; swin passes no epsilon (swin_transformer.py:258,279)
+
+
+def swin_window_partition(x, ws):
+    """window_partition, swin_transformer.py:85-99."""
+    B, H, W, C = x.shape
+    x = x.reshape([B, H // ws, ws, W // ws, ws, C])
+    return x.permute(0, 1, 3, 2, 4, 5).reshape([-1, ws, ws, C])
+
+
+def swin_window_reverse(windows, ws, H, W, C):
+    """window_reverse, swin_transformer.py:102-116."""
+    x = windows.reshape([-1, H // ws, W // ws, ws, ws, C])
+    return x.permute(0, 1, 3, 2, 4, 5).reshape([-1, H, W, C])
+
+
+def swin_relative_position_index(ws):
+    """WindowAttention.__init__, swin_transformer.py:146-158."""
+    coords = torch.stack(torch.meshgrid(torch.arange(ws), torch.arange(ws), indexing="ij"))
+    cf = torch.flatten(coords, 1)
+    rel = (cf.unsqueeze(2) - cf.unsqueeze(1)).permute(1, 2, 0).contiguous()
+    rel[:, :, 0] += ws - 1
+    rel[:, :, 1] += ws - 1
+    rel[:, :, 0] *= 2 * ws - 1
+    return rel.sum(-1)
+
+
+def swin_attn_mask(H, W, ws, shift):
+    """SwinTransformerBlock.__init__, swin_transformer.py:288-305 (0 / -100.0, not -inf)."""
+    img_mask = torch.zeros((1, H, W, 1))
+    cnt = 0
+    for h in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+        for w in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+            img_mask[:, h, w, :] = cnt
+            cnt += 1
+    mw = swin_window_partition(img_mask, ws).reshape([-1, ws * ws])
+    am = mw.unsqueeze(1) - mw.unsqueeze(2)
+    return -100.0 * (am != 0).float()
+
+
+def swin_window_attention(p, pre, x, heads, ws, mask):
+    """WindowAttention.forward, swin_transformer.py:192-229."""
+    B_, N, C = x.shape
+    qkv = linear(p, pre + ".qkv", x).reshape([B_, N, 3, heads, C // heads]).permute(2, 0, 3, 1, 4)  # :194-196
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    q = q * ((C // heads) ** -0.5)                                                   # :202 scale BEFORE q k^T
+    attn = torch.matmul(q, k.permute(0, 1, 3, 2))                                    # :203
+    index = swin_relative_position_index(ws).reshape([-1])                           # :205
+    bias = torch.index_select(_t(p, pre + ".relative_position_bias_table"), 0, index)
+    bias = bias.reshape([ws * ws, ws * ws, -1]).permute(2, 0, 1)                     # :208-212
+    attn = attn + bias.unsqueeze(0)                                                  # :213
+    if mask is not None:                                                             # :216-220
+        nW = mask.shape[0]
+        attn = attn.reshape([B_ // nW, nW, heads, N, N]) + mask.unsqueeze(1).unsqueeze(0)
+        attn = attn.reshape([-1, heads, N, N])
+    attn = torch.softmax(attn, dim=-1)
+    x = torch.matmul(attn, v).permute(0, 2, 1, 3).reshape([B_, N, C])               # :225-226
+    return linear(p, pre + ".proj", x)
+
+
+def swin_block(p, pre, x, H, W, heads, ws, shift):
+    """SwinTransformerBlock.forward, swin_transformer.py:310-337 (window/shift clamp :274-276)."""
+    if min(H, W) <= ws:
+        shift, ws = 0, min(H, W)
+    B, L, C = x.shape
+    assert L == H * W, "input feature has wrong size"
+    shortcut = x
+    x = layernorm(p, pre + ".norm1", x, LN_EPS).reshape([B, H, W, C])
+    if shift > 0:
+        x = torch.roll(x, shifts=(-shift, -shift), dims=(1, 2))
+    xw = swin_window_partition(x, ws).reshape([-1, ws * ws, C])
+    mask = swin_attn_mask(H, W, ws, shift) if shift > 0 else None
+    aw = swin_window_attention(p, pre + ".attn", xw, heads, ws, mask).reshape([-1, ws, ws, C])
+    x = swin_window_reverse(aw, ws, H, W, C)
+    if shift > 0:
+        x = torch.roll(x, shifts=(shift, shift), dims=(1, 2))
+    x = shortcut + x.reshape([B, H * W, C])                                          # :334
+    h = F.gelu(linear(p, pre + ".mlp.fc1", layernorm(p, pre + ".norm2", x, LN_EPS)), approximate="none")
+    return x + linear(p, pre + ".mlp.fc2", h)                                        # :335
+
+
+def swin_patch_merging(p, pre, x, H, W):
+    """PatchMerging.forward, swin_transformer.py:373-391 (the reduction Linear HAS a bias, :369-370)."""
+    B, L, C = x.shape
+    assert L == H * W, "input feature has wrong size"
+    assert H % 2 == 0 and W % 2 == 0, "x size ({}*{}) are not even.".format(H, W)
+    x = x.reshape([B, H, W, C])
+    x = torch.cat([x[:, 0::2, 0::2, :], x[:, 1::2, 0::2, :], x[:, 0::2, 1::2, :], x[:, 1::2, 1::2, :]], -1)
+    x = layernorm(p, pre + ".norm", x.reshape([B, H * W // 4, 4 * C]), LN_EPS)
+    return linear(p, pre + ".reduction", x)
+
+
+def swin(p, x, arch="swintransformer_base_patch4_window7_224"):
+    """SwinTransformer.forward, swin_transformer.py:601-616."""
+    c = SWIN_CFG[arch]
+    x = conv(p, "patch_embed.proj", x, 4, 0)                                         # PatchEmbed.forward :498-504
+    x = layernorm(p, "patch_embed.norm", x.flatten(2).permute(0, 2, 1), LN_EPS)
+    res = c["img"] // 4
+    for li, (depth, heads) in enumerate(zip(c["depths"], c["heads"])):
+        H = W = res // 2 ** li
+        for bi in range(depth):                                                      # BasicLayer :427-435, 446-451
+            x = swin_block(p, f"layers.{li}.blocks.{bi}", x, H, W, heads, c["ws"], 0 if bi % 2 == 0 else c["ws"] // 2)
+        if li < len(c["depths"]) - 1:
+            x = swin_patch_merging(p, f"layers.{li}.downsample", x, H, W)
+    x = layernorm(p, "norm", x, LN_EPS)                                              # :608
+    x = F.adaptive_avg_pool1d(x.permute(0, 2, 1), 1).flatten(1)                      # :609-610
+    return linear(p, "head", x)                                                      # :615
+
+
+# ---------------------------------------------------------------------------------------------
+# MobileNetV1 — models/classification/mobilenetv1.py
+# ---------------------------------------------------------------------------------------------
+MOBILENETV1_PLAN = [(32, 64, 1), (64, 128, 2), (128, 128, 1), (128, 256, 2), (256, 256, 1), (256, 512, 2)] + \
+                   [(512, 512, 1)] * 5 + [(512, 1024, 2), (1024, 1024, 1)]        # (c1, c2, stride), :136-244
+
+
+def _cna(p, pre, x, stride, padding, groups=1):
+    """ConvNormActivation = GroupConv2d (no bias) + BatchNorm2d + ReLU, mobilenetv1.py:45-65."""
+    return F.relu(bn(p, pre + ".1", conv(p, pre + ".0", x, stride, padding, 1, groups)))
+
+
+def mobilenetv1(p, x, scale=1.0, num_classes=1000, with_pool=True):
+    """MobileNetV1.forward, mobilenetv1.py:254-262; DepthwiseSeparable.forward :99-102."""
+    x = _cna(p, "conv1", x, 2, 1)                                                    # :128-135, :255
+    for i, (c1, c2, s) in enumerate(MOBILENETV1_PLAN):
+        x = _cna(p, f"dwsl.{i}._depthwise_conv", x, s, 1, groups=int(c1 * scale))     # :79-88
+        x = _cna(p, f"dwsl.{i}._pointwise_conv", x, 1, 0)                             # :89-97
+    if with_pool:
+        x = F.adaptive_avg_pool2d(x, 1)                                              # :258
+    if num_classes > 0:
+        x = linear(p, "fc", x.reshape(x.shape[0], -1))                               # :260-261
+    return x
+
+
+# ---------------------------------------------------------------------------------------------
+# DarkNet-53 / YOLOv3 neck + head — models/detection/backbones/darknet.py, models/detection/yolov3.py
+# ---------------------------------------------------------------------------------------------
+def _cbl(p, pre, x, stride=1, padding=0):
+    """ConvBNLayer.forward: conv (no bias) -> BatchNorm -> LeakyReLU(0.1), darknet.py:54-58."""
+    return F.leaky_relu(bn(p, pre + ".batch_norm", conv(p, pre + ".conv", x, stride, padding)), 0.1)
+
+
+def _dark_basic(p, pre, x):
+    """BasicBlock.forward, darknet.py:155-159: inputs + conv2(conv1(inputs))."""
+    return x + _cbl(p, pre + ".conv2", _cbl(p, pre + ".conv1", x), 1, 1)
+
+
+def darknet53(p, x, pre="", return_idx=(2, 3, 4)):
+    """DarkNet.forward, darknet.py:299-312; stages [1,2,8,8,4] :217; list children named <attr>_<i>."""
+    out = _cbl(p, pre + "conv0", x, 1, 1)
+    out = _cbl(p, pre + "downsample0.conv_bn_layer", out, 2, 1)
+    blocks = []
+    for i, n in enumerate([1, 2, 8, 8, 4]):
+        b = f"{pre}darknet_conv_block_list_{i}"
+        out = _dark_basic(p, b + ".basicblock0", out)                                 # Blocks.forward :208-211
+        for j in range(n - 1):
+            out = _dark_basic(p, f"{b}.res_blocks.{j}", out)
+        if i in return_idx:
+            blocks.append(out)
+        if i < 4:
+            out = _cbl(p, f"{pre}downsample_list_{i}.conv_bn_layer", out, 2, 1)
+    return blocks
+
+
+def yolov3_neck(p, feats, pre="neck."):
+    """YOLOv3FPN.forward, yolov3.py:239-258; YoloDetBlock.forward :180-183."""
+    X = feats[::-1]
+    outs, route = [], None
+    for i, x in enumerate(X):
+        if i > 0:
+            x = torch.cat([route, x], dim=1)                                         # :246
+        b = f"{pre}yolo_blocks_{i}"
+        for j, (fs) in enumerate([1, 3, 1, 3, 1]):                                    # conv_def :143-149
+            x = _cbl(p, f"{b}.conv_module.{j}", x, 1, (fs - 1) // 2)
+        route = x
+        outs.append(_cbl(p, f"{b}.tip", route, 1, 1))                                # :182
+        if i < len(X) - 1:
+            route = _cbl(p, f"{pre}routes_{i}", route, 1, 0)                          # :252-253
+            route = F.interpolate(route, scale_factor=2.0)                           # :254 (nearest)
+    return outs
+
+
+def yolov3(p, x):
+    """YOLOv3.forward up to the raw head maps, yolov3.py:51-68, 352."""
+    body = darknet53(p, x, "backbone.")
+    neck = yolov3_neck(p, body, "neck.")
+    head = [conv(p, f"yolo_head.yolo_outputs_{i}", f) for i, f in enumerate(neck)]
+    return body, neck, head

@@ -96,6 +96,80 @@ def gen_vit(arch, batch, wseed, xseed, fname):
         param_names=np.array(list(shapes.keys())), torch_version=torch.__version__)
 
 
+def gen_mobilenetv1(batch, wseed, xseed, fname):
+    ref = import_reference("tlxcv/models/classification/mobilenetv1.py", "ref_mobilenetv1")
+    model = ref.MobileNetV1()
+    shapes = seeded.shapes_of(model)
+    params = seeded.fill(shapes, wseed)
+    model.load_dict(params)
+    model.set_eval()
+    x = torch.from_numpy(seeded.image_batch(batch, xseed))
+    with torch.no_grad():
+        ref_out = model(x)
+        re_out = OF.mobilenetv1({k: torch.from_numpy(v) for k, v in params.items()}, x)
+    d = _check("mobilenetv1", ref_out, re_out)
+    np.savez_compressed(
+        os.path.join(OUT, fname), arch="MobileNetV1", weight_seed=wseed, input_seed=xseed, batch=batch,
+        logits=ref_out.numpy().astype(np.float32), argmax=ref_out.argmax(-1).numpy().astype(np.int64),
+        restatement_max_abs_diff=np.float64(d), pinned_by="reference-file-on-tlx_cpu",
+        param_names=np.array(list(shapes.keys())), torch_version=torch.__version__)
+
+
+def gen_darknet(batch, hw, wseed, xseed, fname):
+    ref = import_reference("tlxcv/models/detection/backbones/darknet.py", "ref_darknet")
+    model = ref.DarkNet()
+    shapes = seeded.shapes_of(model)
+    params = seeded.fill(shapes, wseed)
+    model.load_dict(params)
+    model.set_eval()
+    x = torch.from_numpy(seeded.image_batch(batch, xseed, hw=hw))
+    with torch.no_grad():
+        ref_out = model({"images": x})
+        re_out = OF.darknet53({k: torch.from_numpy(v) for k, v in params.items()}, x)
+    d = max(_check(f"darknet53 stage {i}", a, b) for i, (a, b) in enumerate(zip(ref_out, re_out)))
+    np.savez_compressed(
+        os.path.join(OUT, fname), arch="DarkNet53", weight_seed=wseed, input_seed=xseed, batch=batch, hw=hw,
+        feat0=ref_out[0].numpy(), feat1=ref_out[1].numpy(), feat2=ref_out[2].numpy(),
+        restatement_max_abs_diff=np.float64(d), pinned_by="reference-file-on-tlx_cpu",
+        param_names=np.array(list(shapes.keys())), torch_version=torch.__version__)
+
+
+def gen_yolov3(batch, hw, wseed, xseed, fname):
+    """yolov3.py cannot be imported by path (relative imports into utils/ops.py -> decorator, torchvision):
+    backbone pinned above, neck + head fixture is restatement-only."""
+    from tlxcv_amd import models
+    m = models.YOLOv3()
+    shapes = seeded.shapes_of(m)
+    params = seeded.fill(shapes, wseed)
+    x = torch.from_numpy(seeded.image_batch(batch, xseed, hw=hw))
+    with torch.no_grad():
+        body, neck, head = OF.yolov3({k: torch.from_numpy(v) for k, v in params.items()}, x)
+    print(f"[yolov3] restatement-only fixture, head shapes {[tuple(h.shape) for h in head]}")
+    np.savez_compressed(
+        os.path.join(OUT, fname), arch="YOLOv3", weight_seed=wseed, input_seed=xseed, batch=batch, hw=hw,
+        head0=head[0].numpy(), head1=head[1].numpy(), head2=head[2].numpy(), neck2=neck[2].numpy(),
+        pinned_by="restatement-only: yolov3.py imports utils/ops.py (decorator, torchvision, paddle); "
+                  "its DarkNet backbone is pinned by darknet53_b1.npz",
+        param_names=np.array(list(shapes.keys())), torch_version=torch.__version__)
+
+
+def gen_restatement_only(arch, ctor_name, fn, batch, wseed, xseed, fname, note, hw=224):
+    """Reference file is Paddle-only: fixture = oracle restatement output (reviewed against the cited lines)."""
+    from tlxcv_amd import models
+    m = getattr(models, ctor_name)()
+    shapes = seeded.shapes_of(m)
+    params = seeded.fill(shapes, wseed)
+    x = torch.from_numpy(seeded.image_batch(batch, xseed, hw=hw))
+    with torch.no_grad():
+        out = fn({k: torch.from_numpy(v) for k, v in params.items()}, x)
+    print(f"[{arch}] restatement-only fixture, logits std {out.std().item():.3f}")
+    np.savez_compressed(
+        os.path.join(OUT, fname), arch=arch, weight_seed=wseed, input_seed=xseed, batch=batch,
+        logits=out.numpy().astype(np.float32), argmax=out.argmax(-1).numpy().astype(np.int64),
+        pinned_by="restatement-only: " + note, param_names=np.array(list(shapes.keys())),
+        torch_version=torch.__version__)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(os.cpu_count() or 1)
@@ -103,6 +177,15 @@ def main():
     gen_resnet(18, 2, 11, 10, "resnet18_b2.npz")
     gen_vit("vit_base_patch16_224", 2, 2, 0, "vit_b16_b2.npz")       # BASELINE.json configs[2] graph
     gen_vit("vit_small_patch16_224", 1, 12, 3, "vit_small_b1.npz")   # no qkv bias, qk_scale override, hd=96
+    gen_restatement_only("swintransformer_base_patch4_window7_224", "swintransformer_base_patch4_window7_224",
+                         lambda p, x: OF.swin(p, x, "swintransformer_base_patch4_window7_224"), 2, 3, 0,
+                         "swin_b_b2.npz", "reference swin_transformer.py hard-imports paddle/paddle2tlx")
+    gen_restatement_only("swintransformer_tiny_patch4_window7_224", "swintransformer_tiny_patch4_window7_224",
+                         lambda p, x: OF.swin(p, x, "swintransformer_tiny_patch4_window7_224"), 1, 13, 4,
+                         "swin_t_b1.npz", "reference swin_transformer.py hard-imports paddle/paddle2tlx")
+    gen_mobilenetv1(2, 4, 1, "mobilenetv1_b2.npz")
+    gen_darknet(1, 64, 5, 2, "darknet53_b1.npz")
+    gen_yolov3(1, 64, 6, 3, "yolov3_b1.npz")
     for extra in EXTRA:
         extra()
 

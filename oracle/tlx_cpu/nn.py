@@ -38,6 +38,10 @@ class Module(torch.nn.Module):
                             m.add_module(f"{k}_{i}", e)
             stack.extend(m._modules.values())
 
+    def state_dict(self, *args, **kwargs):
+        self._adopt_lists()
+        return super().state_dict(*args, **kwargs)
+
     def set_eval(self):
         self._adopt_lists()
         for m in self.modules():

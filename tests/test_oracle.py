@@ -52,3 +52,47 @@ def test_vit_restatement_reproduces_golden(fname):
         y = OF.vit(p, x, arch)
     assert np.abs(y.numpy() - g["logits"]).max() <= 1e-4
     assert (y.argmax(-1).numpy() == g["argmax"]).all()
+
+
+def test_mobilenetv1_and_darknet_restatements_reproduce_golden():
+    from tlxcv_amd import models
+    g = np.load(os.path.join(GOLDEN, "mobilenetv1_b2.npz"))
+    p = _params(models.MobileNetV1, int(g["weight_seed"]))
+    x = torch.from_numpy(seeded.image_batch(int(g["batch"]), int(g["input_seed"])))
+    with torch.no_grad():
+        y = OF.mobilenetv1(p, x)
+    assert np.abs(y.numpy() - g["logits"]).max() <= 1e-4 and (y.argmax(-1).numpy() == g["argmax"]).all()
+    g = np.load(os.path.join(GOLDEN, "darknet53_b1.npz"))
+    p = _params(models.DarkNet, int(g["weight_seed"]))
+    x = torch.from_numpy(seeded.image_batch(1, int(g["input_seed"]), hw=int(g["hw"])))
+    with torch.no_grad():
+        feats = OF.darknet53(p, x)
+    for i, f in enumerate(feats):
+        assert np.abs(f.numpy() - g[f"feat{i}"]).max() <= 1e-3
+
+
+def test_swin_helpers_against_their_definitions():
+    """The restated index / mask helpers checked against independent brute-force definitions."""
+    ws = 7
+    idx = OF.swin_relative_position_index(ws)
+    for i in (0, 5, 24, 48):
+        for j in (0, 6, 30, 48):
+            dy, dx = i // ws - j // ws, i % ws - j % ws
+            assert idx[i, j] == (dy + ws - 1) * (2 * ws - 1) + (dx + ws - 1)
+    m = OF.swin_attn_mask(14, 14, 7, 3)
+    assert m.shape == (4, 49, 49) and set(m.unique().tolist()) == {-100.0, 0.0}
+    assert (m[0] == 0).all()                      # the top-left window never mixes regions
+    x = torch.arange(2 * 14 * 14 * 3, dtype=torch.float32).reshape(2, 14, 14, 3)
+    assert torch.equal(OF.swin_window_reverse(OF.swin_window_partition(x, 7), 7, 14, 14, 3), x)
+
+
+def test_swin_fixture_is_flagged_restatement_only():
+    g = np.load(os.path.join(GOLDEN, "swin_b_b2.npz"))
+    assert str(g["pinned_by"]).startswith("restatement-only")
+    from tlxcv_amd import models
+    p = _params(models.swintransformer_tiny_patch4_window7_224, 13)
+    gt = np.load(os.path.join(GOLDEN, "swin_t_b1.npz"))
+    x = torch.from_numpy(seeded.image_batch(1, int(gt["input_seed"])))
+    with torch.no_grad():
+        y = OF.swin(p, x, "swintransformer_tiny_patch4_window7_224")
+    assert np.abs(y.numpy() - gt["logits"]).max() <= 1e-4

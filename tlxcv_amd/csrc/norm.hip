@@ -28,6 +28,18 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
             if (ch < nch && row0 + r < rows)
                 raw[r][i] = *reinterpret_cast<const u32x4*>(x + (row0 + r) * x_ld + ch * V);
         }
+    // gamma / beta of this lane's channels: once per wave, not once per row
+    float gm[NCH][V], bt[NCH][V];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int ch = lane + 64 * i;
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const int c = ch < nch ? ch * V + e : 0;
+            gm[i][e] = gamma ? gamma[c] : 1.f;
+            bt[i][e] = beta ? beta[c] : 0.f;
+        }
+    }
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
         if (row0 + r >= rows) break;
@@ -66,11 +78,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
             if (ch < nch) {
                 float o[V];
 #pragma unroll
-                for (int e = 0; e < V; ++e) {
-                    const int c = ch * V + e;
-                    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-                    o[e] = (v[i][e] - mean) * rstd * g + b;
-                }
+                for (int e = 0; e < V; ++e) o[e] = (v[i][e] - mean) * rstd * gm[i][e] + bt[i][e];
                 if constexpr (sizeof(T) == 2) {
                     half8v h;
 #pragma unroll

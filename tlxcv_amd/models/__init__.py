@@ -1,1 +1,2 @@
 from .classification import *  # noqa: F401,F403
+from .detection import *  # noqa: F401,F403

@@ -3,3 +3,7 @@ from .resnet import (ResNet, resnet18, resnet34, resnet50, resnet101, resnet152,
 from .vision_transformer import (VisionTransformer, vit_small_patch16_224, vit_base_patch16_224,  # noqa: F401
                                  vit_base_patch16_384, vit_base_patch32_384, vit_large_patch16_224,
                                  vit_large_patch16_384, vit_large_patch32_384)
+from .swin_transformer import (SwinTransformer, swintransformer_tiny_patch4_window7_224,  # noqa: F401
+                               swintransformer_small_patch4_window7_224, swintransformer_base_patch4_window7_224,
+                               swintransformer_large_patch4_window7_224)
+from .mobilenetv1 import MobileNetV1  # noqa: F401

@@ -1,0 +1,272 @@
+"""Swin Transformer (tiny/small/base/large, window 7) forward graph on the MI355X engine.
+
+Same factories / constructor arguments / parameter tree as the reference
+(tlxcv/models/classification/swin_transformer.py:119-683; that file is a Paddle conversion that
+hard-imports `paddle`, so it is restated from its text).  Per block the reference does
+LayerNorm -> reshape -> roll -> window_partition -> qkv Linear -> scaled q k^T + relative position
+bias (+ shift mask) -> softmax -> @v -> proj -> window_reverse -> roll back -> residual -> LayerNorm
+-> Mlp -> residual (:310-337, :192-229).  Here:
+  * roll + window_partition are one index-mapping copy, window_reverse + roll back + the residual
+    add another (tlxmi_window_partition / tlxmi_window_reverse);
+  * the attention core is one fused MFMA kernel on the packed qkv matrix that adds the pre-gathered
+    (heads, 49, 49) bias table and the (nW, 49, 49) shift mask in registers;
+  * qkv / proj / fc1(+GELU) / fc2(+residual) are the implicit-GEMM kernel with fused epilogues;
+  * PatchMerging's strided 2x2 gather + concat is one copy kernel, then LayerNorm and the GEMM.
+Quirks kept on purpose: the -100.0 (not -inf) mask, and the PatchMerging reduction bias (:369-370).
+"""
+import numpy as np
+import torch
+
+from ... import engine as E
+from ...tlx import nn
+from ...tlx.nn import as_nhwc
+
+__all__ = ["SwinTransformer", "swintransformer_tiny_patch4_window7_224", "swintransformer_small_patch4_window7_224",
+           "swintransformer_base_patch4_window7_224", "swintransformer_large_patch4_window7_224"]
+
+trunc_normal_ = nn.initializers.TruncatedNormal(stddev=0.02)
+
+
+def to_2tuple(x):
+    return tuple([x] * 2)
+
+
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.0):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.fc1 = nn.Linear(in_features=in_features, out_features=hidden_features)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(in_features=hidden_features, out_features=out_features)
+        self.drop = nn.Dropout(drop)
+
+    def run(self, x, res=None):
+        return self.fc2.run(self.fc1.run(x, act=self.act.ACT), res=res, out=res)
+
+    def forward(self, x):
+        return self.run(x)
+
+
+def relative_position_index(ws):
+    """swin_transformer.py:146-158."""
+    coords = torch.stack(torch.meshgrid(torch.arange(ws[0]), torch.arange(ws[1]), indexing="ij"))
+    cf = torch.flatten(coords, 1)
+    rel = (cf.unsqueeze(2) - cf.unsqueeze(1)).permute(1, 2, 0).contiguous()
+    rel[:, :, 0] += ws[0] - 1
+    rel[:, :, 1] += ws[1] - 1
+    rel[:, :, 0] *= 2 * ws[1] - 1
+    return rel.sum(-1)
+
+
+class WindowAttention(nn.Module):
+    def __init__(self, dim, window_size, num_heads, qkv_bias=True, qk_scale=None, attn_drop=0.0, proj_drop=0.0):
+        super().__init__()
+        self.dim, self.window_size, self.num_heads = dim, window_size, num_heads
+        head_dim = dim // num_heads
+        self.scale = qk_scale or head_dim ** -0.5
+        self.relative_position_bias_table = nn.Parameter(
+            data=trunc_normal_(shape=((2 * window_size[0] - 1) * (2 * window_size[1] - 1), num_heads)))
+        self.register_buffer("relative_position_index", relative_position_index(window_size))
+        self.qkv = nn.Linear(in_features=dim, out_features=dim * 3, b_init="constant" if qkv_bias else None)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = nn.Linear(in_features=dim, out_features=dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+
+    def bias_table(self):
+        """(heads, N, N) fp32, gathered once (the reference caches the same tensor in eval(), :179-190)."""
+        def build():
+            n = self.window_size[0] * self.window_size[1]
+            idx = self.relative_position_index.reshape(-1)
+            b = torch.index_select(self.relative_position_bias_table.detach(), 0, idx)
+            return b.reshape(n, n, -1).permute(2, 0, 1).contiguous().float()
+        return self._cached("rpb", build)
+
+    def run(self, xw, mask=None):
+        qkv = self.qkv.run(xw)                                                     # (B_, N, 3C)
+        a = E.attention(qkv, self.num_heads, self.scale, self.bias_table(), mask)  # :202-226
+        return self.proj.run(a)
+
+    def forward(self, x, mask=None):
+        return self.run(x.to(E.precision()).contiguous(), mask)
+
+
+class SwinTransformerBlock(nn.Module):
+    def __init__(self, dim, input_resolution, num_heads, window_size=7, shift_size=0, mlp_ratio=4.0, qkv_bias=True,
+                 qk_scale=None, drop=0.0, attn_drop=0.0, drop_path=0.0, act_layer=nn.GELU, layer_norm=nn.LayerNorm):
+        super().__init__()
+        self.dim, self.input_resolution, self.num_heads = dim, input_resolution, num_heads
+        self.window_size, self.shift_size, self.mlp_ratio = window_size, shift_size, mlp_ratio
+        if min(self.input_resolution) <= self.window_size:                         # :274-276
+            self.shift_size = 0
+            self.window_size = min(self.input_resolution)
+        assert 0 <= self.shift_size < self.window_size, 'shift_size must in 0-window_size'
+        self.norm1 = layer_norm(dim)
+        self.attn = WindowAttention(dim, window_size=to_2tuple(self.window_size), num_heads=num_heads,
+                                    qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop, proj_drop=drop)
+        self.drop_path = nn.Identity()
+        self.norm2 = layer_norm(dim)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+        if self.shift_size > 0:                                                    # :288-305
+            H, W = self.input_resolution
+            ws, ss = self.window_size, self.shift_size
+            img_mask = torch.zeros((1, H, W, 1))
+            cnt = 0
+            for h in (slice(0, -ws), slice(-ws, -ss), slice(-ss, None)):
+                for w in (slice(0, -ws), slice(-ws, -ss), slice(-ss, None)):
+                    img_mask[:, h, w, :] = cnt
+                    cnt += 1
+            mw = img_mask.reshape(1, H // ws, ws, W // ws, ws, 1).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws)
+            am = mw.unsqueeze(1) - mw.unsqueeze(2)
+            attn_mask = -100.0 * (am != 0).float()
+        else:
+            attn_mask = None
+        self.register_buffer("attn_mask", attn_mask)
+
+    def run(self, x):
+        """x (B, L, C) engine dtype -> new (B, L, C)."""
+        H, W = self.input_resolution
+        B, L, C = x.shape
+        assert L == H * W, 'input feature has wrong size'
+        h = self.norm1(x)                                                          # :315
+        win = E.window_partition(h.view(B, H, W, C), self.window_size, self.shift_size)   # :316-324
+        aw = self.attn.run(win, self.attn_mask)                                    # :325
+        x = E.window_reverse(aw, B, H, W, self.window_size, self.shift_size, res=x.view(B, H, W, C)).view(B, L, C)
+        self.mlp.run(self.norm2(x), res=x)                                         # :335, in place
+        return x
+
+    def forward(self, x):
+        E.need_gpu(x, "input")
+        return self.run(x.to(E.precision()).contiguous())
+
+
+class PatchMerging(nn.Module):
+    def __init__(self, input_resolution, dim, layer_norm=nn.LayerNorm):
+        super().__init__()
+        self.input_resolution, self.dim = input_resolution, dim
+        self.reduction = nn.Linear(in_features=4 * dim, out_features=2 * dim, b_init=nn.initializers.xavier_uniform())
+        self.norm = layer_norm(4 * dim)
+
+    def run(self, x):
+        H, W = self.input_resolution
+        B, L, C = x.shape
+        assert L == H * W, 'input feature has wrong size'
+        assert H % 2 == 0 and W % 2 == 0, 'x size ({}*{}) are not even.'.format(H, W)
+        g = E.patch_merge_gather(x.view(B, H, W, C)).view(B, H * W // 4, 4 * C)    # :381-387
+        return self.reduction.run(self.norm(g))                                    # :388-389
+
+    def forward(self, x):
+        return self.run(x.to(E.precision()).contiguous())
+
+
+class BasicLayer(nn.Module):
+    def __init__(self, dim, input_resolution, depth, num_heads, window_size, mlp_ratio=4.0, qkv_bias=True,
+                 qk_scale=None, drop=0.0, attn_drop=0.0, drop_path=0.0, layer_norm=nn.LayerNorm, downsample=None,
+                 use_checkpoint=False):
+        super().__init__()
+        self.dim, self.input_resolution, self.depth = dim, input_resolution, depth
+        self.blocks = nn.ModuleList([
+            SwinTransformerBlock(dim=dim, input_resolution=input_resolution, num_heads=num_heads,
+                                 window_size=window_size, shift_size=0 if i % 2 == 0 else window_size // 2,
+                                 mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale, drop=drop,
+                                 attn_drop=attn_drop, layer_norm=layer_norm) for i in range(depth)])
+        self.downsample = downsample(input_resolution, dim=dim, layer_norm=layer_norm) if downsample is not None else None
+
+    def run(self, x):
+        for blk in self.blocks:
+            x = blk.run(x)
+        if self.downsample is not None:
+            x = self.downsample.run(x)
+        return x
+
+    def forward(self, x):
+        return self.run(x.to(E.precision()).contiguous())
+
+
+class PatchEmbed(nn.Module):
+    def __init__(self, img_size=224, patch_size=4, in_chans=3, embed_dim=96, layer_norm=None):
+        super().__init__()
+        img_size, patch_size = to_2tuple(img_size), to_2tuple(patch_size)
+        self.patches_resolution = [img_size[0] // patch_size[0], img_size[1] // patch_size[1]]
+        self.img_size, self.patch_size = img_size, patch_size
+        self.num_patches = self.patches_resolution[0] * self.patches_resolution[1]
+        self.in_chans, self.embed_dim = in_chans, embed_dim
+        self.proj = nn.GroupConv2d(kernel_size=patch_size, stride=patch_size, in_channels=in_chans,
+                                   out_channels=embed_dim, padding=0, data_format='channels_first')
+        self.norm = layer_norm(embed_dim) if layer_norm is not None else None
+
+    def forward(self, x):
+        y = self.proj.run_nhwc(as_nhwc(x, 'channels_first'))                       # (B, H/4, W/4, D): :500-501
+        y = y.view(y.shape[0], -1, y.shape[-1])
+        return self.norm(y) if self.norm is not None else y
+
+
+class SwinTransformer(nn.Module):
+    def __init__(self, img_size=224, patch_size=4, in_chans=3, class_num=1000, embed_dim=96, depths=[2, 2, 6, 2],
+                 num_heads=[3, 6, 12, 24], window_size=7, mlp_ratio=4.0, qkv_bias=True, qk_scale=None, drop_rate=0.0,
+                 attn_drop_rate=0.0, drop_path_rate=0.1, layer_norm=nn.LayerNorm, ape=False, patch_norm=True,
+                 use_checkpoint=False, **kwargs):
+        super().__init__()
+        self.num_classes = num_classes = class_num
+        self.num_layers = len(depths)
+        self.embed_dim, self.ape, self.patch_norm = embed_dim, ape, patch_norm
+        self.num_features = int(embed_dim * 2 ** (self.num_layers - 1))
+        self.mlp_ratio = mlp_ratio
+        self.patch_embed = PatchEmbed(img_size=img_size, patch_size=patch_size, in_chans=in_chans, embed_dim=embed_dim,
+                                      layer_norm=layer_norm if self.patch_norm else None)
+        pr = self.patches_resolution = self.patch_embed.patches_resolution
+        if self.ape:
+            raise NotImplementedError("absolute position embedding (ape=True) is not used by any reference config")
+        self.pos_drop = nn.Dropout(p=drop_rate)
+        self.layers = nn.ModuleList()
+        for i in range(self.num_layers):
+            self.layers.append(BasicLayer(
+                dim=int(embed_dim * 2 ** i), input_resolution=(pr[0] // 2 ** i, pr[1] // 2 ** i), depth=depths[i],
+                num_heads=num_heads[i], window_size=window_size, mlp_ratio=self.mlp_ratio, qkv_bias=qkv_bias,
+                qk_scale=qk_scale, drop=drop_rate, attn_drop=attn_drop_rate, layer_norm=layer_norm,
+                downsample=PatchMerging if i < self.num_layers - 1 else None))
+        self.norm = layer_norm(self.num_features)
+        self.avgpool = nn.AdaptiveAvgPool1d(1, data_format='channels_first')
+        self.head = nn.Linear(in_features=self.num_features, out_features=num_classes) if num_classes > 0 else nn.Identity()
+
+    def forward_features(self, x):
+        self._require_eval()
+        x = self.patch_embed(x)                        # :602
+        for layer in self.layers:                      # :606-607
+            x = layer.run(x)
+        x = self.norm(x)                               # :608
+        return E.global_avgpool(x)                     # mean over tokens == avgpool(x^T) + flatten, :609-610
+
+    def forward(self, x):
+        x = self.forward_features(x)
+        return self.head.run(x) if isinstance(self.head, nn.Linear) else x
+
+
+_CFG = {
+    'swintransformer_tiny_patch4_window7_224': dict(embed_dim=96, depths=[2, 2, 6, 2], num_heads=[3, 6, 12, 24], window_size=7, drop_path_rate=0.2),
+    'swintransformer_small_patch4_window7_224': dict(embed_dim=96, depths=[2, 2, 18, 2], num_heads=[3, 6, 12, 24], window_size=7),
+    'swintransformer_base_patch4_window7_224': dict(embed_dim=128, depths=[2, 2, 18, 2], num_heads=[4, 8, 16, 32], window_size=7, drop_path_rate=0.5),
+    'swintransformer_large_patch4_window7_224': dict(embed_dim=192, depths=[2, 2, 18, 2], num_heads=[6, 12, 24, 48], window_size=7),
+}
+
+
+def _swin(arch, pretrained=False, use_ssld=False, **kwargs):
+    if pretrained:
+        raise NotImplementedError("pretrained weights are not bundled; use model.load_weights(...)")
+    return SwinTransformer(**{**_CFG[arch], **kwargs})
+
+
+def swintransformer_tiny_patch4_window7_224(pretrained=False, use_ssld=False, **kwargs):
+    return _swin('swintransformer_tiny_patch4_window7_224', pretrained, use_ssld, **kwargs)
+
+
+def swintransformer_small_patch4_window7_224(pretrained=False, use_ssld=False, **kwargs):
+    return _swin('swintransformer_small_patch4_window7_224', pretrained, use_ssld, **kwargs)
+
+
+def swintransformer_base_patch4_window7_224(pretrained=False, use_ssld=False, **kwargs):
+    return _swin('swintransformer_base_patch4_window7_224', pretrained, use_ssld, **kwargs)
+
+
+def swintransformer_large_patch4_window7_224(pretrained=False, use_ssld=False, **kwargs):
+    return _swin('swintransformer_large_patch4_window7_224', pretrained, use_ssld, **kwargs)

@@ -30,8 +30,9 @@ def image_batch(n, seed=0, hw=224, c=3):
 
 
 def _is_last_bn_of_block(name):
-    # ResNet: bn3 of a bottleneck / bn2 of a basic block / the downsample BN feed the residual add.
-    return name.endswith(("bn3", "downsample.1")) or name.endswith(".bn2")
+    # ResNet: bn3 of a bottleneck / bn2 of a basic block / the downsample BN feed the residual add;
+    # DarkNet: the BatchNorm of BasicBlock.conv2 (darknet.py:142-153) does.
+    return name.endswith(("bn3", "downsample.1", "conv2.batch_norm")) or name.endswith(".bn2")
 
 
 def fill(shapes, seed):
@@ -75,4 +76,6 @@ def fill(shapes, seed):
 
 def shapes_of(module):
     """Ordered {name: shape} of a torch-style module's floating parameters and buffers."""
-    return {k: tuple(v.shape) for k, v in module.state_dict().items() if v.is_floating_point()}
+    derived = ("attn_mask", "relative_position_bias", "relative_position_index")   # computed, not learned
+    return {k: tuple(v.shape) for k, v in module.state_dict().items()
+            if v.is_floating_point() and k.rsplit(".", 1)[-1] not in derived}

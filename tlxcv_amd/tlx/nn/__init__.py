@@ -71,6 +71,10 @@ class Module(torch.nn.Module):
                 if isinstance(v, (list, tuple)):
                     stack.extend(e for e in v if isinstance(e, torch.nn.Module))
 
+    def state_dict(self, *args, **kwargs):
+        self._adopt_lists()
+        return super().state_dict(*args, **kwargs)
+
     def set_eval(self):
         self._adopt_lists()
         for m in self.modules():
@@ -154,8 +158,10 @@ class Module(torch.nn.Module):
         """Assign {dotted name: numpy/torch array}; used by tests and benches with seeded recipes."""
         self._adopt_lists()
         sd = self.state_dict()
+        derived = ("attn_mask", "relative_position_bias", "relative_position_index")   # computed buffers
         unknown = [k for k in named if k not in sd]
-        missing = [k for k in sd if k not in named]
+        missing = [k for k in sd if k not in named and sd[k].is_floating_point()
+                   and k.rsplit(".", 1)[-1] not in derived]
         if strict and (unknown or missing):
             raise KeyError(f"load_dict: unknown={unknown[:4]} missing={missing[:4]}")
         with torch.no_grad():
