@@ -162,6 +162,11 @@ int tlxmi_affine_act(const void* x, const float* scale, const float* shift, cons
                      int dtype, int64_t rows, int C, int x_ld, int res_ld, int y_ld, int act,
                      float act_param, uint32_t flags, void* stream);
 
+/* Squeeze-Excitation gating (mobilenetv3.py:54-56 `scale * input`): y[n][p][c] = x[n][p][c] * s[n][c],
+ * s is the (N, C) output of the SE bottleneck, same dtype as x. */
+int tlxmi_scale_channels(const void* x, const void* s, void* y, int dtype, int N, int HW, int C, int x_ld,
+                         int s_ld, int y_ld, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * LayerNorm over the last dimension (biased variance), nn.LayerNorm(dim, epsilon)
  * vision_transformer.py:144,159,283; swin_transformer.py:258,279,371,495,591.

@@ -377,3 +377,91 @@ def yolov3(p, x):
     neck = yolov3_neck(p, body, "neck.")
     head = [conv(p, f"yolo_head.yolo_outputs_{i}", f) for i, f in enumerate(neck)]
     return body, neck, head
+
+
+# ---------------------------------------------------------------------------------------------
+# MobileNetV2 / V3 — models/classification/mobilenetv2.py, mobilenetv3.py (Paddle-only files: restated
+# from the text), ops/ops_fusion.py:11-48, utils/common_func.py:1-16
+# ---------------------------------------------------------------------------------------------
+def make_divisible(v, divisor=8, min_value=None):
+    """_make_divisible, utils/common_func.py:1-16."""
+    if min_value is None:
+        min_value = divisor
+    new_v = max(min_value, int(v + divisor / 2) // divisor * divisor)
+    if new_v < 0.9 * v:
+        new_v += divisor
+    return new_v
+
+
+def _cna_act(p, pre, x, k, stride, groups, act, eps=BN_EPS):
+    """ConvNormActivation (ops/ops_fusion.py:31-48): conv(pad=(k-1)//2, no bias) + BN + optional activation."""
+    y = bn(p, pre + ".1", conv(p, pre + ".0", x, stride, (k - 1) // 2, 1, groups), eps)
+    return act(y) if act is not None else y
+
+
+def mobilenetv2(p, x, scale=1.0):
+    """MobileNetV2.forward, mobilenetv2.py:102-109; features built :76-93; InvertedResidual.forward :36-40."""
+    setting = [[1, 16, 1, 1], [6, 24, 2, 2], [6, 32, 3, 2], [6, 64, 4, 2], [6, 96, 3, 1], [6, 160, 3, 2], [6, 320, 1, 1]]
+    inp = make_divisible(32 * scale, 8)
+    x = _cna_act(p, "features.0", x, 3, 2, 1, F.relu6)
+    fi = 1
+    for t, c, n, s in setting:
+        oup = make_divisible(c * scale, 8)
+        for i in range(n):
+            stride = s if i == 0 else 1
+            hidden = int(round(inp * t))
+            pre = f"features.{fi}.conv"
+            h, li = x, 0
+            if t != 1:
+                h = _cna_act(p, f"{pre}.{li}", h, 1, 1, 1, F.relu6)
+                li += 1
+            h = _cna_act(p, f"{pre}.{li}", h, 3, stride, hidden, F.relu6)
+            h = bn(p, f"{pre}.{li + 2}", conv(p, f"{pre}.{li + 1}", h))
+            x = x + h if (stride == 1 and inp == oup) else h
+            inp = oup
+            fi += 1
+    x = _cna_act(p, f"features.{fi}", x, 1, 1, 1, F.relu6)
+    x = F.adaptive_avg_pool2d(x, 1).flatten(1)
+    return linear(p, "classifier.1", x)
+
+
+MBV3_SMALL = [(16, 3, 16, 16, True, 'relu', 2), (16, 3, 72, 24, False, 'relu', 2), (24, 3, 88, 24, False, 'relu', 1),
+              (24, 5, 96, 40, True, 'hardswish', 2), (40, 5, 240, 40, True, 'hardswish', 1),
+              (40, 5, 240, 40, True, 'hardswish', 1), (40, 5, 120, 48, True, 'hardswish', 1),
+              (48, 5, 144, 48, True, 'hardswish', 1), (48, 5, 288, 96, True, 'hardswish', 2),
+              (96, 5, 576, 96, True, 'hardswish', 1), (96, 5, 576, 96, True, 'hardswish', 1)]   # mobilenetv3.py:209-221
+MBV3_LARGE = [(16, 3, 16, 16, False, 'relu', 1), (16, 3, 64, 24, False, 'relu', 2), (24, 3, 72, 24, False, 'relu', 1),
+              (24, 5, 72, 40, True, 'relu', 2), (40, 5, 120, 40, True, 'relu', 1), (40, 5, 120, 40, True, 'relu', 1),
+              (40, 3, 240, 80, False, 'hardswish', 2), (80, 3, 200, 80, False, 'hardswish', 1),
+              (80, 3, 184, 80, False, 'hardswish', 1), (80, 3, 184, 80, False, 'hardswish', 1),
+              (80, 3, 480, 112, True, 'hardswish', 1), (112, 3, 672, 112, True, 'hardswish', 1),
+              (112, 5, 672, 160, True, 'hardswish', 2), (160, 5, 960, 160, True, 'hardswish', 1),
+              (160, 5, 960, 160, True, 'hardswish', 1)]                                        # :253-269
+
+
+def mobilenetv3(p, x, config, scale=1.0):
+    """MobileNetV3.forward, mobilenetv3.py:170-180; InvertedResidual.forward :111-121; SqueezeExcitation :47-56;
+    every BatchNorm has epsilon 1e-3 (:148)."""
+    EPS = 1e-3
+    adj = lambda c: make_divisible(c * scale, 8)
+    x = _cna_act(p, "conv", x, 3, 2, 1, F.hardswish, EPS)
+    for i, (cin, k, cexp, cout, use_se, actn, stride) in enumerate(config):
+        cin, cexp, cout = adj(cin), adj(cexp), adj(cout)
+        act = F.relu if actn == 'relu' else F.hardswish
+        pre = f"blocks.{i}"
+        identity = x
+        if cin != cexp:
+            x = _cna_act(p, pre + ".expand_conv", x, 1, 1, 1, act, EPS)
+        x = _cna_act(p, pre + ".bottleneck_conv", x, k, stride, cexp, act, EPS)
+        if use_se:
+            s = F.adaptive_avg_pool2d(x, 1)
+            s = F.relu(conv(p, pre + ".mid_se.fc1", s))
+            s = F.hardsigmoid(conv(p, pre + ".mid_se.fc2", s))
+            x = s * x
+        x = _cna_act(p, pre + ".linear_conv", x, 1, 1, 1, None, EPS)
+        if stride == 1 and cin == cout:
+            x = identity + x
+    x = _cna_act(p, "lastconv", x, 1, 1, 1, F.hardswish, EPS)
+    x = F.adaptive_avg_pool2d(x, 1).flatten(1)
+    x = F.hardswish(linear(p, "classifier.0", x))
+    return linear(p, "classifier.3", x)

@@ -183,6 +183,13 @@ def main():
     gen_restatement_only("swintransformer_tiny_patch4_window7_224", "swintransformer_tiny_patch4_window7_224",
                          lambda p, x: OF.swin(p, x, "swintransformer_tiny_patch4_window7_224"), 1, 13, 4,
                          "swin_t_b1.npz", "reference swin_transformer.py hard-imports paddle/paddle2tlx")
+    note = "reference mobilenetv2/v3.py hard-import paddle and use broken package-relative imports"
+    gen_restatement_only("mobilenet_v2", "mobilenet_v2", lambda p, x: OF.mobilenetv2(p, x), 2, 7, 5,
+                         "mobilenetv2_b2.npz", note, hw=128)
+    gen_restatement_only("mobilenet_v3_small", "mobilenet_v3_small",
+                         lambda p, x: OF.mobilenetv3(p, x, OF.MBV3_SMALL), 2, 8, 6, "mobilenetv3_small_b2.npz", note, hw=128)
+    gen_restatement_only("mobilenet_v3_large", "mobilenet_v3_large",
+                         lambda p, x: OF.mobilenetv3(p, x, OF.MBV3_LARGE), 1, 9, 7, "mobilenetv3_large_b1.npz", note, hw=128)
     gen_mobilenetv1(2, 4, 1, "mobilenetv1_b2.npz")
     gen_darknet(1, 64, 5, 2, "darknet53_b1.npz")
     gen_yolov3(1, 64, 6, 3, "yolov3_b1.npz")

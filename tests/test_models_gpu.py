@@ -23,14 +23,16 @@ def build(ctor, seed, dev, **kw):
 
 CLASSIFIERS = [("swin_b_b2.npz", "swintransformer_base_patch4_window7_224"),
                ("swin_t_b1.npz", "swintransformer_tiny_patch4_window7_224"),
-               ("mobilenetv1_b2.npz", "MobileNetV1")]
+               ("mobilenetv1_b2.npz", "MobileNetV1"), ("mobilenetv2_b2.npz", "mobilenet_v2"),
+               ("mobilenetv3_small_b2.npz", "mobilenet_v3_small"), ("mobilenetv3_large_b1.npz", "mobilenet_v3_large")]
+HW = {"mobilenetv2_b2.npz": 128, "mobilenetv3_small_b2.npz": 128, "mobilenetv3_large_b1.npz": 128}
 
 
 @pytest.mark.parametrize("fname,ctor", CLASSIFIERS)
 def test_classifier_fp32_matches_golden_1e4_and_argmax_exact(dev, fp32_mode, fname, ctor):
     g = np.load(os.path.join(GOLDEN, fname))
     m = build(ctor, int(g["weight_seed"]), dev)
-    x = torch.from_numpy(seeded.image_batch(int(g["batch"]), int(g["input_seed"]))).to(dev)
+    x = torch.from_numpy(seeded.image_batch(int(g["batch"]), int(g["input_seed"]), hw=HW.get(fname, 224))).to(dev)
     y = m(x)
     err = np.abs(y.cpu().numpy() - g["logits"]).max()
     assert err <= 1e-4, err
@@ -42,7 +44,7 @@ def test_classifier_fp32_matches_golden_1e4_and_argmax_exact(dev, fp32_mode, fna
 def test_classifier_fp16_tracks_golden(dev, fp16_mode, fname, ctor):
     g = np.load(os.path.join(GOLDEN, fname))
     m = build(ctor, int(g["weight_seed"]), dev)
-    x = torch.from_numpy(seeded.image_batch(int(g["batch"]), int(g["input_seed"]))).to(dev)
+    x = torch.from_numpy(seeded.image_batch(int(g["batch"]), int(g["input_seed"]), hw=HW.get(fname, 224))).to(dev)
     y = m(x).float().cpu().numpy()
     ref = g["logits"]
     err = np.abs(y - ref).max()

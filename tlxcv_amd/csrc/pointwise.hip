@@ -226,6 +226,26 @@ __global__ void dwconv_kernel(const T* __restrict__ x, const T* __restrict__ w, 
     }
 }
 
+// Squeeze-Excitation gating: y[n][p][c] = x[n][p][c] * s[n][c]
+template <typename T>
+__global__ void scale_channels_kernel(const T* __restrict__ x, const T* __restrict__ s, T* __restrict__ y, int N,
+                                      int HW, int C, int x_ld, int s_ld, int y_ld) {
+    constexpr int V = Chunk<T>::N;
+    const int nch = C / V;
+    const long total = (long)N * HW * nch;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % nch);
+        const long p = i / nch;
+        const long n = p / HW;
+        float xv[V], sv[V];
+        Chunk<T>::load(x + p * x_ld + cg * V, xv);
+        Chunk<T>::load(s + n * s_ld + cg * V, sv);
+#pragma unroll
+        for (int e = 0; e < V; ++e) xv[e] *= sv[e];
+        Chunk<T>::store(y + p * y_ld + cg * V, xv);
+    }
+}
+
 // nearest x2 upsample into a channel window of a wider buffer
 template <typename T>
 __global__ void upsample2x_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C, int x_ld,
@@ -420,6 +440,20 @@ extern "C" int tlxmi_dwconv2d(const tlxmi_dwconv2d_desc* d, const void* x, const
     else
         hipLaunchKernelGGL((dwconv_kernel<float>), g, b, 0, as_stream(stream), (const float*)x, (const float*)w, scale, shift, (float*)y, *d);
     return check_launch("dwconv2d");
+}
+
+extern "C" int tlxmi_scale_channels(const void* x, const void* sc, void* y, int dt, int N, int HW, int C, int x_ld,
+                                    int s_ld, int y_ld, void* stream) {
+    TLXMI_REQUIRE(x && sc && y && N > 0 && HW > 0, TLXMI_ERR_BAD_ARG, "scale_channels: bad argument");
+    REQUIRE_CHUNKED("scale_channels", dt, C, x_ld, s_ld, y_ld);
+    TLXMI_REQUIRE(aligned16(x) && aligned16(sc) && aligned16(y), TLXMI_ERR_ALIGNMENT, "scale_channels: buffers must be 16-byte aligned");
+    const long work = (long)N * HW * (C / VECN(dt));
+    dim3 g(grid_for(work)), b(256);
+    if (dt == TLXMI_F16)
+        hipLaunchKernelGGL((scale_channels_kernel<half_t>), g, b, 0, as_stream(stream), (const half_t*)x, (const half_t*)sc, (half_t*)y, N, HW, C, x_ld, s_ld, y_ld);
+    else
+        hipLaunchKernelGGL((scale_channels_kernel<float>), g, b, 0, as_stream(stream), (const float*)x, (const float*)sc, (float*)y, N, HW, C, x_ld, s_ld, y_ld);
+    return check_launch("scale_channels");
 }
 
 extern "C" int tlxmi_upsample2x_nearest(const void* x, void* y, int dt, int N, int H, int W, int C, int x_ld, int y_ld,

@@ -273,6 +273,16 @@ def affine_act(x, scale=None, shift=None, res=None, act=ACT_NONE, act_param=0.0,
     return y
 
 
+def scale_channels(x, s):
+    """x (N,H,W,C) * s (N,C) broadcast over pixels (Squeeze-Excitation gate)."""
+    need_gpu(x, "input")
+    N, Cc = x.shape[0], x.shape[-1]
+    HW = x.numel() // (N * Cc)
+    y = torch.empty_like(x)
+    _lib.call("tlxmi_scale_channels", _p(x), _p(s), _p(y), dt_code(x.dtype), N, HW, Cc, Cc, s.shape[-1], Cc, _stream())
+    return y
+
+
 def layernorm(x, gamma, beta, eps):
     need_gpu(x, "input")
     if not x.is_contiguous():

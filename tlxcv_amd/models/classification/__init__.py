@@ -7,3 +7,5 @@ from .swin_transformer import (SwinTransformer, swintransformer_tiny_patch4_wind
                                swintransformer_small_patch4_window7_224, swintransformer_base_patch4_window7_224,
                                swintransformer_large_patch4_window7_224)
 from .mobilenetv1 import MobileNetV1  # noqa: F401
+from .mobilenetv2 import (MobileNetV2, mobilenet_v2, MobileNetV3Small, MobileNetV3Large, mobilenet_v3_small,  # noqa: F401
+                          mobilenet_v3_large)

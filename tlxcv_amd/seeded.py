@@ -32,7 +32,8 @@ def image_batch(n, seed=0, hw=224, c=3):
 def _is_last_bn_of_block(name):
     # ResNet: bn3 of a bottleneck / bn2 of a basic block / the downsample BN feed the residual add;
     # DarkNet: the BatchNorm of BasicBlock.conv2 (darknet.py:142-153) does.
-    return name.endswith(("bn3", "downsample.1", "conv2.batch_norm")) or name.endswith(".bn2")
+    # MobileNetV2/V3: the BatchNorm of the linear projection (mobilenetv2.py:30-33, mobilenetv3.py:107-110).
+    return name.endswith(("bn3", "downsample.1", "conv2.batch_norm", "linear_conv.1")) or name.endswith(".bn2")
 
 
 def fill(shapes, seed):
