@@ -145,12 +145,19 @@ def main():
         # ResNet-50's layer-by-layer arithmetic intensity (~144 FLOP/B) is below the machine balance
         # (~312): HBM-bound.  ViT-B/16 (~436 FLOP/B) is MFMA-bound.  Both fractions are reported.
         hbm_bound = a.workload == "resnet50"
+        # HBM bytes per launch from PMC counters cannot be collected inside this process: they come from the
+        # separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command
+        # (tools/pmc_traffic.sh; FETCH_SIZE doubled per MI355X_MICROARCH.md), committed under profiles/.
+        traffic = None
+        tj = os.path.join(REPO, "profiles", "r01", f"traffic_{a.workload}.json")
+        if os.path.exists(tj) and a.batch == 256:
+            traffic = int(json.load(open(tj))["hbm_bytes_per_launch"])
         line["roofline"] = {
             "bound": "hbm" if hbm_bound else "mfma",
             "achieved": round(gbs if hbm_bound else tfs, 1),
             "peak": HBM_PEAK_GBS if hbm_bound else MFMA_F16_PEAK_TF,
             "unit": "GB/s" if hbm_bound else "TFLOP/s",
-            "frac": round(gbs / HBM_PEAK_GBS if hbm_bound else tfs / MFMA_F16_PEAK_TF, 4), "traffic": None,
+            "frac": round(gbs / HBM_PEAK_GBS if hbm_bound else tfs / MFMA_F16_PEAK_TF, 4), "traffic": traffic,
             "kernel": "conv_igemm_kernel (all instantiations; every conv / linear launch of one forward)",
             "launches_per_step": nl // nprobe, "avg_launch_us": round(per_launch_us, 2),
             "alg_bytes_per_launch": int(alg_bytes / nl), "alg_flops_per_launch": int(flops / nl),
