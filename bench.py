@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="images per GPU")
     ap.add_argument("--workload", default="resnet50", choices=["resnet50", "vit_b16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch kernel by kernel instead of replaying a hipGraph")
     a = ap.parse_args()
 
     import tlxcv_amd
@@ -91,8 +92,13 @@ def main():
     x = torch.from_numpy(seeded.image_batch(min(a.batch, 32), rank)).to(dev)
     x = x.repeat((a.batch + x.shape[0] - 1) // x.shape[0], 1, 1, 1)[: a.batch].contiguous()   # resident in HBM
 
+    fwd = model
+    if not a.no_graph:
+        from tlxcv_amd.graph import GraphedForward
+        fwd = GraphedForward(model, x)       # the whole forward as one hipGraph; x is its static input
+
     def step():
-        y = model(x)
+        y = fwd(x) if fwd is model else fwd()
         return D.all_gather_logits(y) if world > 1 else y
 
     def fence():
@@ -123,7 +129,8 @@ def main():
         "config": {"workload": {"resnet50": "ResNet-50 fp16 forward, 224x224, batch 256 per GPU (BASELINE configs[1])",
                                 "vit_b16": "ViT-B/16 fp16 forward, 224x224, batch 256 per GPU (BASELINE configs[2])"}[a.workload],
                    "global_batch": a.batch * world, "per_gpu_batch": a.batch, "weights": "seeded random (tlxcv_amd.seeded, seed 1)",
-                   "parallelism": f"batch-sharded x{world}, all-gather logits" if world > 1 else "single GPU"},
+                   "parallelism": f"batch-sharded x{world}, all-gather logits" if world > 1 else "single GPU",
+                   "launch": "per-kernel" if a.no_graph else "hipGraph replay of the forward"},
     }
 
     if rank == 0:

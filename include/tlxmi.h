@@ -77,6 +77,12 @@ int tlxmi_device_count(void);
  * ---------------------------------------------------------------------------------------- */
 int tlxmi_nchw_to_nhwc(const void* src, int src_dtype, void* dst, int dst_dtype, int N, int C, int H,
                        int W, int Cpad, void* stream);
+/* Same with a b x b space-to-depth fold: dst [N][H/b][W/b][Cpad], channel (ph*b + pw)*C + c holds
+ * src[n][c][h2*b+ph][w2*b+pw].  Lets the 3-channel stem / patch-embedding convs (resnet.py:199-207 7x7/2,
+ * vision_transformer.py:197-204 16x16/16, swin_transformer.py:490 4x4/4) run as dense-K implicit GEMMs
+ * (K 448 -> 256, 2048 -> 768, 128 -> 48 halves) with filters re-indexed once on the host side. */
+int tlxmi_nchw_to_nhwc_s2d(const void* src, int src_dtype, void* dst, int dst_dtype, int N, int C, int H,
+                           int W, int b, int Cpad, void* stream);
 /* dst: [N][C][H][W] contiguous; src: NHWC with pixel stride ld (>= C). */
 int tlxmi_nhwc_to_nchw(const void* src, int src_dtype, int ld, void* dst, int dst_dtype, int N, int C,
                        int H, int W, void* stream);
@@ -111,7 +117,8 @@ typedef struct tlxmi_conv2d_desc {
     int32_t Cout;            /* true output channels */
     int32_t R, S;            /* filter height, width */
     int32_t stride_h, stride_w, pad_h, pad_w, dil_h, dil_w;
-    int32_t Ho, Wo;          /* output extent (caller computed; checked) */
+    int32_t Ho, Wo;          /* output extent: at most the full-correlation extent of (H,W,pad,R,S,stride,dil);
+                              * smaller values crop (asymmetric padding of the space-to-depth stem) */
     int32_t x_ld, y_ld, res_ld; /* pixel strides in elements (x_ld >= C, y_ld >= Cout) */
     int32_t y_nstride;       /* elements between images of y; 0 = dense (Ho*Wo*y_ld).  Lets the   */
     int32_t res_nstride;     /* patch-embed conv write rows 1.. of a [B][1+P][D] token matrix     */

@@ -125,3 +125,28 @@ def test_descriptor_errors_raise(dev):
         E.conv2d(x, pk, 1, 0)                      # 3x3 valid on 2x2
     with pytest.raises(RuntimeError, match="dtype"):
         E.conv2d(x.float(), pk, 1, 1)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["fp32", "fp16"])
+@pytest.mark.parametrize("k,s,p,b,H", [(7, 2, 3, 2, 64), (16, 16, 0, 4, 64), (4, 4, 0, 4, 56), (3, 2, 1, 2, 30),
+                                       (16, 16, 0, 2, 32), (5, 2, 2, 2, 22)])
+def test_space_to_depth_stem_equals_plain_conv(dev, dtype, k, s, p, b, H):
+    """GroupConv2d.run_stem (b x b fold + re-indexed filter + cropped extent) == the plain conv."""
+    import tlxcv_amd
+    from tlxcv_amd.tlx import nn
+    tlxcv_amd.set_precision("fp32" if dtype == torch.float32 else "fp16")
+    try:
+        rng = np.random.default_rng(5)
+        conv = nn.GroupConv2d(in_channels=3, out_channels=40, kernel_size=k, stride=s, padding=p,
+                              data_format="channels_first")
+        w, bias = rnd(rng, (40, 3, k, k), 0.2), rnd(rng, (40,), 0.1)
+        x = rnd(rng, (2, 3, H, H))
+        if dtype == torch.float16:
+            w, x = q16(w), q16(x)
+        conv.load_dict({"filters": w, "biases": bias})
+        conv = conv.to(dev).set_eval()
+        want = torch.nn.functional.conv2d(x, w, bias, s, p)
+        got = conv.run_stem(x.to(dev), b)
+        torch.testing.assert_close(engine_to_nchw(got), want, **tol(dtype))
+    finally:
+        tlxcv_amd.set_precision("fp16")

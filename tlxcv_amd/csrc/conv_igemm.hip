@@ -117,7 +117,9 @@ static __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const char* p,
 }
 
 // WGM = waves along the pixel axis (2 or 4; always 2 along channels), STAGES = LDS-DMA ring depth.
-template <typename T, int BM, int BN, bool IS_1X1, int WGM, int STAGES>
+// RESP = the residual tile is prefetched into registers at kernel entry (dense, 16-byte-aligned residual):
+// its HBM latency then overlaps the first DMA stage instead of starting after the last MFMA.
+template <typename T, int BM, int BN, bool IS_1X1, int WGM, int STAGES, bool RESP>
 __global__ __launch_bounds__(WGM * 128) void conv_igemm_kernel(const ConvArgs a) {
     constexpr int ES = (int)sizeof(T);
     constexpr int NW = WGM * 2, NT = NW * 64;     // waves, threads
@@ -244,12 +246,30 @@ __global__ __launch_bounds__(WGM * 128) void conv_igemm_kernel(const ConvArgs a)
 #pragma unroll
         for (int pi = 0; pi < PI; ++pi) acc[ci][pi] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // epilogue geometry (phase 2): BN/8 lanes per pixel row, RPP rows per pass
+    constexpr int CPR = BN / 8;          // 8-channel chunks per row
+    constexpr int RPP = NT / CPR;        // rows per pass
+    constexpr int NIT = BM / RPP;
+    constexpr int RW = RESP ? NIT : 1;
+    u32x4 rres[RW][ES / 2];              // prefetched residual, raw
+
     // ---- K loop.  The DMA ring runs STAGES-1 steps ahead of the MFMAs; one barrier per step:
     //   wait (counted vmcnt) until this wave's pieces of step kt have landed, barrier (everyone's have,
     //   and everyone is done reading the buffer of step kt-1), re-fill that buffer with step kt+STAGES-1.
     stage(0);
     if constexpr (STAGES == 3) {
         if (a.ktiles > 1) { advance(); stage(1); }
+    }
+    if constexpr (RESP) {
+        const int ch0 = bn0 + 8 * (t % CPR);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int m = bm0 + t / CPR + it * RPP;
+            const bool ok = m < a.M && ch0 + 8 <= a.Cout;
+            const u32x4* rp = reinterpret_cast<const u32x4*>(a.res + ((size_t)(ok ? m : 0) * a.res_ld + (ok ? ch0 : 0)) * ES);
+#pragma unroll
+            for (int h = 0; h < ES / 2; ++h) rres[it][h] = rp[h];
+        }
     }
     int buf = 0;
     for (int kt = 0; kt < a.ktiles; ++kt) {
@@ -326,9 +346,6 @@ __global__ __launch_bounds__(WGM * 128) void conv_igemm_kernel(const ConvArgs a)
     // ---- epilogue, phase 2: whole rows leave the block: BN/8 consecutive lanes cover one pixel's BN
     // channels (full 128-byte lines); the residual is read the same way.
     {
-        constexpr int CPR = BN / 8;          // 8-channel chunks per row
-        constexpr int RPP = NT / CPR;        // rows per pass
-        constexpr int NIT = BM / RPP;
         const int chunk = t % CPR;
         const int ch0 = bn0 + 8 * chunk;
         const bool res_after = (a.flags & TLXMI_EPI_RES_AFTER_ACT) != 0;
@@ -338,7 +355,7 @@ __global__ __launch_bounds__(WGM * 128) void conv_igemm_kernel(const ConvArgs a)
             const char* rp = a.res ? a.res + ((size_t)(bm0 + row0) * a.res_ld + ch0) * ES : nullptr;
             char* yp = a.y + ((size_t)(bm0 + row0) * a.y_ld + ch0) * ES;
             const size_t ystep = (size_t)RPP * a.y_ld * ES, rstep = (size_t)RPP * a.res_ld * ES;
-#pragma unroll 4
+#pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int row = row0 + it * RPP;
                 const int m = bm0 + row;
@@ -355,7 +372,18 @@ __global__ __launch_bounds__(WGM * 128) void conv_igemm_kernel(const ConvArgs a)
                 for (int bb = 0; bb < 4; ++bb) { v[bb] = lo[bb]; v[4 + bb] = hi[bb]; }
                 float rv[8];
                 if (a.res) {
-                    if (full) {
+                    if constexpr (RESP) {
+                        if constexpr (ES == 2) {
+                            const half8v h = __builtin_bit_cast(half8v, rres[it][0]);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) rv[e] = (float)h[e];
+                        } else {
+                            const f32x4 r0 = __builtin_bit_cast(f32x4, rres[it][0]);
+                            const f32x4 r1 = __builtin_bit_cast(f32x4, rres[it][ES / 2 - 1]);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { rv[e] = r0[e]; rv[4 + e] = r1[e]; }
+                        }
+                    } else if (full) {
                         load8<T>(rp, rv);
                     } else {
 #pragma unroll
@@ -406,20 +434,23 @@ template <typename T, int BM, int BN, int WGM, int STAGES> static int launch(con
     if (lds < (size_t)BM * BN * 4) lds = (size_t)BM * BN * 4;
     const long grid = (long)b.mtiles * b.ntiles;
     const bool is1x1 = a.R == 1 && a.S == 1 && a.ph == 0 && a.pw == 0;
+    const bool resp = a.res && a.vec_io && !a.strided_n;
+    const void* fns[4] = {reinterpret_cast<const void*>(&conv_igemm_kernel<T, BM, BN, false, WGM, STAGES, false>),
+                          reinterpret_cast<const void*>(&conv_igemm_kernel<T, BM, BN, false, WGM, STAGES, true>),
+                          reinterpret_cast<const void*>(&conv_igemm_kernel<T, BM, BN, true, WGM, STAGES, false>),
+                          reinterpret_cast<const void*>(&conv_igemm_kernel<T, BM, BN, true, WGM, STAGES, true>)};
+    const int which = (is1x1 ? 2 : 0) + (resp ? 1 : 0);
     if (lds > 64 * 1024) {
-        static bool raised[2] = {false, false};
-        if (!raised[is1x1]) {
-            const void* fn = is1x1 ? reinterpret_cast<const void*>(&conv_igemm_kernel<T, BM, BN, true, WGM, STAGES>)
-                                   : reinterpret_cast<const void*>(&conv_igemm_kernel<T, BM, BN, false, WGM, STAGES>);
-            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        static bool raised[4] = {false, false, false, false};
+        if (!raised[which]) {
+            hipError_t e = hipFuncSetAttribute(fns[which], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return fail(TLXMI_ERR_LAUNCH, "conv2d: cannot raise LDS limit: %s", hipGetErrorString(e));
-            raised[is1x1] = true;
+            raised[which] = true;
         }
     }
-    if (is1x1)
-        hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, true, WGM, STAGES>), dim3((unsigned)grid), dim3(WGM * 128), lds, st, b);
-    else
-        hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, false, WGM, STAGES>), dim3((unsigned)grid), dim3(WGM * 128), lds, st, b);
+    void* args[] = {&b};
+    hipError_t e = hipLaunchKernel(fns[which], dim3((unsigned)grid), dim3(WGM * 128), args, lds, st);
+    if (e != hipSuccess) return fail(TLXMI_ERR_LAUNCH, "conv2d: HIP launch failed: %s", hipGetErrorString(e));
     return TLXMI_OK;
 }
 
@@ -504,11 +535,11 @@ extern "C" int tlxmi_conv2d(const tlxmi_conv2d_desc* d, const void* x, const voi
     TLXMI_REQUIRE(d->y_ld >= d->Cout, TLXMI_ERR_BAD_ARG, "conv2d: y_ld=%d < Cout=%d", d->y_ld, d->Cout);
     const int Ho = (d->H + 2 * d->pad_h - d->dil_h * (d->R - 1) - 1) / d->stride_h + 1;
     const int Wo = (d->W + 2 * d->pad_w - d->dil_w * (d->S - 1) - 1) / d->stride_w + 1;
-    TLXMI_REQUIRE(Ho == d->Ho && Wo == d->Wo && Ho > 0 && Wo > 0, TLXMI_ERR_BAD_ARG,
-                  "conv2d: output extent %dx%d does not match descriptor %dx%d", Ho, Wo, d->Ho, d->Wo);
+    TLXMI_REQUIRE(d->Ho > 0 && d->Wo > 0 && d->Ho <= Ho && d->Wo <= Wo, TLXMI_ERR_BAD_ARG,
+                  "conv2d: output extent %dx%d exceeds the correlation extent %dx%d", d->Ho, d->Wo, Ho, Wo);
     TLXMI_REQUIRE(d->act >= TLXMI_ACT_NONE && d->act <= TLXMI_ACT_SILU, TLXMI_ERR_BAD_ARG, "conv2d: bad act %d", d->act);
     TLXMI_REQUIRE(!res || d->res_ld >= d->Cout, TLXMI_ERR_BAD_ARG, "conv2d: res_ld=%d < Cout", d->res_ld);
-    const long long M = (long long)d->N * Ho * Wo;
+    const long long M = (long long)d->N * d->Ho * d->Wo;
     const long long x_bytes = (long long)d->N * d->H * d->W * d->x_ld * es;
     TLXMI_REQUIRE(M < (1ll << 31) && x_bytes < (1ll << 31) && M * (long long)d->y_ld * es < (1ll << 40), TLXMI_ERR_UNSUPPORTED,
                   "conv2d: input of %lld bytes exceeds the 2 GiB the 32-bit buffer offsets address", x_bytes);
@@ -518,9 +549,9 @@ extern "C" int tlxmi_conv2d(const tlxmi_conv2d_desc* d, const void* x, const voi
     a.scale = scale; a.shift = shift; a.res = (const char*)res;
     a.N = d->N; a.H = d->H; a.W = d->W; a.C = d->C; a.Cout = d->Cout; a.R = d->R; a.S = d->S;
     a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_h; a.pw = d->pad_w; a.dh = d->dil_h; a.dw = d->dil_w;
-    a.Ho = Ho; a.Wo = Wo; a.x_ld = d->x_ld; a.y_ld = d->y_ld; a.res_ld = res ? d->res_ld : 0;
+    a.Ho = d->Ho; a.Wo = d->Wo; a.x_ld = d->x_ld; a.y_ld = d->y_ld; a.res_ld = res ? d->res_ld : 0;
     a.act = d->act; a.act_param = d->act_param; a.flags = d->flags;
-    a.M = (int)M; a.HoWo = Ho * Wo;
+    a.M = (int)M; a.HoWo = d->Ho * d->Wo;
     a.cpt = d->C * es / 16;
     a.kchunks = d->R * d->S * a.cpt;
     a.ktiles = (a.kchunks + 7) / 8;

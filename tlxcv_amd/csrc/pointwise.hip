@@ -65,6 +65,37 @@ __global__ void nchw_to_nhwc_kernel(const TS* __restrict__ src, TD* __restrict__
     }
 }
 
+// NCHW -> NHWC with a b x b space-to-depth fold: channel (ph*b+pw)*C + c of output pixel (h2, w2)
+template <typename TS, typename TD>
+__global__ void nchw_to_nhwc_s2d_kernel(const TS* __restrict__ src, TD* __restrict__ dst, int N, int C, int H, int W,
+                                        int b, int Cpad) {
+    constexpr int V = Chunk<TD>::N;
+    const int H2 = H / b, W2 = W / b;
+    const long HW = (long)H * W, P = (long)N * H2 * W2;
+    const int nch = Cpad / V, Cs = b * b * C;
+    const long total = P * nch;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long p = i % P;
+        const int cg = (int)(i / P);
+        const int w2 = (int)(p % W2);
+        const long t = p / W2;
+        const int h2 = (int)(t % H2);
+        const long n = t / H2;
+        float v[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const int ch = cg * V + e;
+            float x = 0.f;
+            if (ch < Cs) {
+                const int c = ch % C, q = ch / C, pw = q % b, ph = q / b;
+                x = (float)src[(n * C + c) * HW + (long)(h2 * b + ph) * W + (w2 * b + pw)];
+            }
+            v[e] = x;
+        }
+        Chunk<TD>::store(dst + p * Cpad + cg * V, v);
+    }
+}
+
 template <typename TS, typename TD>
 __global__ void nhwc_to_nchw_kernel(const TS* __restrict__ src, int ld, TD* __restrict__ dst, int N, int C, int H,
                                     int W) {
@@ -332,6 +363,28 @@ extern "C" int tlxmi_nchw_to_nhwc(const void* src, int sdt, void* dst, int ddt, 
     else
         hipLaunchKernelGGL((nchw_to_nhwc_kernel<half_t, float>), g, b, 0, st, (const half_t*)src, (float*)dst, N, C, H, W, Cpad);
     return check_launch("nchw_to_nhwc");
+}
+
+extern "C" int tlxmi_nchw_to_nhwc_s2d(const void* src, int sdt, void* dst, int ddt, int N, int C, int H, int W, int b,
+                                      int Cpad, void* stream) {
+    TLXMI_REQUIRE(src && dst, TLXMI_ERR_BAD_ARG, "nchw_to_nhwc_s2d: null buffer");
+    TLXMI_REQUIRE(DT_OK(sdt) && DT_OK(ddt), TLXMI_ERR_BAD_ARG, "nchw_to_nhwc_s2d: bad dtype");
+    TLXMI_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && b >= 1 && H % b == 0 && W % b == 0 && Cpad >= b * b * C,
+                  TLXMI_ERR_BAD_ARG, "nchw_to_nhwc_s2d: H=%d W=%d must be multiples of b=%d, Cpad >= b*b*C", H, W, b);
+    TLXMI_REQUIRE(Cpad % VECN(ddt) == 0 && aligned16(dst), TLXMI_ERR_ALIGNMENT,
+                  "nchw_to_nhwc_s2d: Cpad=%d must be a whole number of 16-byte chunks", Cpad);
+    const long work = (long)N * (H / b) * (W / b) * (Cpad / VECN(ddt));
+    dim3 g(grid_for(work)), blk(256);
+    hipStream_t st = as_stream(stream);
+    if (sdt == TLXMI_F32 && ddt == TLXMI_F16)
+        hipLaunchKernelGGL((nchw_to_nhwc_s2d_kernel<float, half_t>), g, blk, 0, st, (const float*)src, (half_t*)dst, N, C, H, W, b, Cpad);
+    else if (sdt == TLXMI_F32 && ddt == TLXMI_F32)
+        hipLaunchKernelGGL((nchw_to_nhwc_s2d_kernel<float, float>), g, blk, 0, st, (const float*)src, (float*)dst, N, C, H, W, b, Cpad);
+    else if (sdt == TLXMI_F16 && ddt == TLXMI_F16)
+        hipLaunchKernelGGL((nchw_to_nhwc_s2d_kernel<half_t, half_t>), g, blk, 0, st, (const half_t*)src, (half_t*)dst, N, C, H, W, b, Cpad);
+    else
+        hipLaunchKernelGGL((nchw_to_nhwc_s2d_kernel<half_t, float>), g, blk, 0, st, (const half_t*)src, (float*)dst, N, C, H, W, b, Cpad);
+    return check_launch("nchw_to_nhwc_s2d");
 }
 
 extern "C" int tlxmi_nhwc_to_nchw(const void* src, int sdt, int ld, void* dst, int ddt, int N, int C, int H, int W,

@@ -99,6 +99,47 @@ def nchw_to_nhwc(x, dtype=None, cpad=None):
     return y
 
 
+def nchw_to_nhwc_s2d(x, b, dtype=None):
+    """(N,C,H,W) -> (N,H/b,W/b,pad(b*b*C)): b x b space-to-depth fold, channel (ph*b+pw)*C + c."""
+    need_gpu(x, "input")
+    dtype = dtype or _precision
+    N, Cc, H, W = x.shape
+    if H % b or W % b:
+        raise RuntimeError(f"space-to-depth needs H, W multiples of {b}, got {H}x{W}")
+    v = vec(dtype)
+    cpad = (b * b * Cc + v - 1) // v * v
+    if x.dtype not in (torch.float16, torch.float32):
+        x = x.float()
+    x = x.contiguous()
+    y = torch.empty((N, H // b, W // b, cpad), dtype=dtype, device=x.device)
+    _lib.call("tlxmi_nchw_to_nhwc_s2d", _p(x), dt_code(x.dtype), _p(y), dt_code(dtype), N, Cc, H, W, b, cpad, _stream())
+    return y
+
+
+def s2d_filter(w_oihw, b, pad):
+    """Re-index an OIHW filter for a b x b space-to-depth input (host side, once):
+    W2[o][(ph*b+pw)*C + c][r2][s2] = W[o][c][b*r2 + ph - off][b*s2 + pw - off], zero outside;
+    returns (W2, new padding).  The conv then runs with stride/b and output extent cropped by the caller."""
+    O, Cc, R, S = w_oihw.shape
+    ph_ = pad if isinstance(pad, int) else pad[0]
+    pad2 = (ph_ + b - 1) // b
+    off = pad2 * b - ph_
+    R2, S2 = (R + off + b - 1) // b, (S + off + b - 1) // b
+    w2 = torch.zeros((O, b * b * Cc, R2, S2), dtype=torch.float32, device=w_oihw.device)
+    w = w_oihw.detach().float()
+    for ph in range(b):
+        for pw in range(b):
+            for r2 in range(R2):
+                r = b * r2 + ph - off
+                if not 0 <= r < R:
+                    continue
+                for s2 in range(S2):
+                    sx = b * s2 + pw - off
+                    if 0 <= sx < S:
+                        w2[:, (ph * b + pw) * Cc:(ph * b + pw + 1) * Cc, r2, s2] = w[:, :, r, sx]
+    return w2, pad2
+
+
 def nhwc_to_nchw(x, C_true=None, dtype=None):
     """(N,H,W,ld) -> contiguous (N,C,H,W)."""
     need_gpu(x)
@@ -150,7 +191,7 @@ def _pair(v):
 
 def conv2d(x, pk, stride=1, padding=0, dilation=1, scale=None, shift=None, res=None, act=ACT_NONE,
            act_param=0.0, res_after_act=False, out=None, out_ld=None, y_nstride=0, res_nstride=0,
-           res_bcast=False, res_ld=None):
+           res_bcast=False, res_ld=None, out_hw=None):
     """x (N,H,W,C>=Cin_pad...) NHWC -> y (N,Ho,Wo,Cout).  `out` may be a wider/pre-offset buffer."""
     need_gpu(x, "input")
     N, H, W, ld = x.shape
@@ -165,6 +206,8 @@ def conv2d(x, pk, stride=1, padding=0, dilation=1, scale=None, shift=None, res=N
     Wo = (W + 2 * pw - dw * (pk.S - 1) - 1) // sw + 1
     if Ho <= 0 or Wo <= 0:
         raise RuntimeError(f"conv2d: empty output {Ho}x{Wo} for input {H}x{W}")
+    if out_hw is not None:      # crop (asymmetric padding of a space-to-depth stem)
+        Ho, Wo = min(Ho, out_hw[0]), min(Wo, out_hw[1])
     if out is None:
         out = torch.empty((N, Ho, Wo, pk.Cout), dtype=x.dtype, device=x.device)
         out_ld = pk.Cout

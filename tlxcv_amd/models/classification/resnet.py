@@ -138,8 +138,12 @@ class ResNet(nn.Module):
         return nn.Sequential(layers)
 
     def forward(self, x):
-        v = as_nhwc(x, self.data_format)                       # NCHW fp32 -> NHWC(pad) engine dtype
-        v = self.conv1.run_nhwc(v, self.bn1, E.ACT_RELU)       # resnet.py:287-289
+        if (self.data_format == 'channels_first' and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
+                and not x.permute(0, 2, 3, 1).is_contiguous()):
+            # NCHW image: 2x2 space-to-depth fold + 4x4/1 conv == the 7x7/2 pad-3 stem (resnet.py:199-207, 287-289)
+            v = self.conv1.run_stem(x, 2, self.bn1, E.ACT_RELU)
+        else:
+            v = self.conv1.run_nhwc(as_nhwc(x, self.data_format), self.bn1, E.ACT_RELU)
         v = self.maxpool.run_nhwc(v)                           # :290
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
             for blk in layer:

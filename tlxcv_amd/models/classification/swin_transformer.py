@@ -196,7 +196,10 @@ class PatchEmbed(nn.Module):
         self.norm = layer_norm(embed_dim) if layer_norm is not None else None
 
     def forward(self, x):
-        y = self.proj.run_nhwc(as_nhwc(x, 'channels_first'))                       # (B, H/4, W/4, D): :500-501
+        if self.patch_size[0] % 4 == 0 and not x.permute(0, 2, 3, 1).is_contiguous():
+            y = self.proj.run_stem(x, 4)                                           # 4x4/4 conv == 1x1 conv on 48 folded channels
+        else:
+            y = self.proj.run_nhwc(as_nhwc(x, 'channels_first'))                   # (B, H/4, W/4, D): :500-501
         y = y.view(y.shape[0], -1, y.shape[-1])
         return self.norm(y) if self.norm is not None else y
 

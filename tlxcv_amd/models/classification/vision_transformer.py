@@ -176,14 +176,18 @@ class VisionTransformer(nn.Module):
         pe = self.patch_embed
         pe.check(x)
         dt = E.precision()
-        v = as_nhwc(x, self.data_format)
-        B, P, D = v.shape[0], pe.num_patches, self.embed_dim
+        B, P, D = x.shape[0], pe.num_patches, self.embed_dim
         pos = self._cached("pos", lambda: self.pos_embed.detach()[0, 1:].to(dt).contiguous())            # (P, D)
         row0 = self._cached("row0", lambda: (self.cls_token.detach()[0, 0] + self.pos_embed.detach()[0, 0])
                             .to(dt).contiguous())                                                         # (D,)
-        tok = torch.empty((B, P + 1, D), dtype=dt, device=v.device)
+        tok = torch.empty((B, P + 1, D), dtype=dt, device=x.device)
         # rows 1..P: conv + bias + pos_embed[1:]   (vision_transformer.py:206-220, 321-323)
-        pe.proj.run_nhwc(v, res=pos, out=tok[:, 1:], out_ld=D, y_nstride=(P + 1) * D, res_bcast=True, res_ld=D)
+        kw = dict(res=pos, out=tok[:, 1:], out_ld=D, y_nstride=(P + 1) * D, res_bcast=True, res_ld=D)
+        fold = 4 if pe.patch_size[0] % 4 == 0 else (2 if pe.patch_size[0] % 2 == 0 else 0)
+        if self.data_format == "channels_first" and fold and not x.permute(0, 2, 3, 1).is_contiguous():
+            pe.proj.run_stem(x, fold, **kw)                    # K = 3*16*16 = 768 dense instead of 8*16*16
+        else:
+            pe.proj.run_nhwc(as_nhwc(x, self.data_format), **kw)
         # row 0: cls_token + pos_embed[0]
         E.broadcast_rows_into(row0, tok, B, (P + 1) * D)
         for blk in self.blocks:

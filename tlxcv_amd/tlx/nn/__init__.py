@@ -391,6 +391,34 @@ class GroupConv2d(Module):
             raise NotImplementedError("depthwise conv with fused residual")
         return E.dwconv2d(x, pk, self.stride, self.padding, self.dilation, scale, shift, act, act_param)
 
+    def run_stem(self, x_nchw, b, bn=None, act=E.ACT_NONE, act_param=0.0, **kw):
+        """Few-channel first conv (RGB stem / patch embedding) on a b x b space-to-depth input: the 3-channel
+        image would leave 5 of every 8 fp16 K-lanes zero; folding b x b pixels into channels makes K dense
+        (7x7/2 stem: 448 -> 256; 16x16/16 patch embed: 2048 -> 768).  Same arithmetic, re-indexed once."""
+        self._require_eval()
+        E.need_gpu(x_nchw, "input")
+        if self.data_format != "channels_first" or self.n_group != 1 or self.dilation != (1, 1):
+            raise NotImplementedError("run_stem: channels_first, dense, undilated convs only")
+        sh, sw = self.stride
+        if sh % b or sw % b or sh != sw or self.padding[0] != self.padding[1]:
+            raise NotImplementedError("run_stem: stride must be a multiple of the fold")
+        dt = E.precision()
+        N, Cc, H, W = x_nchw.shape
+        Ho = (H + 2 * self.padding[0] - self.kernel_size[0]) // sh + 1
+        Wo = (W + 2 * self.padding[1] - self.kernel_size[1]) // sw + 1
+
+        def build():
+            w2, pad2 = E.s2d_filter(self.filters, b, self.padding[0])
+            return E.PackedFilter(w2, dt), pad2
+        pk, pad2 = self._cached(("s2d", b), build)
+        if bn is not None:
+            scale, shift = self._cached(("bn", id(bn)), lambda: bn.folded(self.biases))
+        else:
+            scale, shift = None, (self._cached("bias", lambda: E._f32(self.biases)) if self.biases is not None else None)
+        v = E.nchw_to_nhwc_s2d(x_nchw, b, dt)
+        return E.conv2d(v, pk, (sh // b, sw // b), pad2, 1, scale, shift, act=act, act_param=act_param,
+                        out_hw=(Ho, Wo), **kw)
+
     def forward(self, x):
         y = self.run_nhwc(as_nhwc(x, self.data_format))
         y = from_nhwc(y, self.data_format)
