@@ -31,7 +31,7 @@ typedef __fp16 fp16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) fp16x4 lds_fp16x4;
 
 template <int HD, int NT>  // NT = number of 16-key tiles (even), keys padded to 16*NT
-__global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const AttnArgs a) {
     constexpr int SR = HD * 2 + 32;          // padded LDS row stride in bytes (160 / 96)
     constexpr int NP = 16 * NT;              // padded key count
     constexpr int KS = HD / 32;              // k-steps of the QK^T product
@@ -50,60 +50,131 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnArgs a) {
     const half_t* kbase = qbase + (size_t)heads * HD;
     const half_t* vbase = qbase + (size_t)2 * heads * HD;
 
-    // ---- stage K and V (zero rows for padded keys)
-    for (int i = t; i < NP * CPR; i += 256) {
-        const int key = i / CPR, c = i - key * CPR;
-        u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
-        if (key < N) {
-            kv = *reinterpret_cast<const u32x4*>(kbase + (size_t)key * tok_ld + c * 8);
-            vv = *reinterpret_cast<const u32x4*>(vbase + (size_t)key * tok_ld + c * 8);
+    // ---- Q fragments (B operand) of this wave's first query tile, fetched before the K/V staging so that
+    // their HBM latency hides behind it: lane's query row, d = 32*ks + 8g .. +7
+    const int nqt = (N + 15) >> 4;
+    u32x4 qcur[KS];
+    {
+        const int query = wv * 16 + li;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            qcur[ks] = u32x4{0u, 0u, 0u, 0u};
+            if (query < N) qcur[ks] = *reinterpret_cast<const u32x4*>(qbase + (size_t)query * tok_ld + ks * 32 + g * 8);
         }
-        *reinterpret_cast<u32x4*>(Ks + key * SR + c * 16) = kv;
-        *reinterpret_cast<u32x4*>(Vs + key * SR + c * 16) = vv;
+    }
+
+    // ---- stage K and V (zero rows for padded keys); loads are issued in batches ahead of the LDS writes
+    constexpr int ITEMS = NP * CPR, PER = (ITEMS + 255) / 256, BATCH = PER < 4 ? PER : 4;
+    for (int b0 = 0; b0 < PER; b0 += BATCH) {
+        u32x4 kv[BATCH], vv[BATCH];
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int i = t + (b0 + u) * 256;
+            const int key = i / CPR, c = i - key * CPR;
+            kv[u] = u32x4{0u, 0u, 0u, 0u};
+            vv[u] = u32x4{0u, 0u, 0u, 0u};
+            if (i < ITEMS && key < N) {
+                kv[u] = *reinterpret_cast<const u32x4*>(kbase + (size_t)key * tok_ld + c * 8);
+                vv[u] = *reinterpret_cast<const u32x4*>(vbase + (size_t)key * tok_ld + c * 8);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int i = t + (b0 + u) * 256;
+            const int key = i / CPR, c = i - key * CPR;
+            if (i < ITEMS) {
+                *reinterpret_cast<u32x4*>(Ks + key * SR + c * 16) = kv[u];
+                *reinterpret_cast<u32x4*>(Vs + key * SR + c * 16) = vv[u];
+            }
+        }
+    }
+    // Swin-sized windows: the (N, N) relative-position bias of this head and the shift mask of this window are
+    // summed once into an LDS table (coalesced reads) instead of two dependent global gathers per score
+    constexpr bool TABLE = NT <= 4;
+    float* Ts = reinterpret_cast<float*>(smem + 2 * NP * SR);
+    const float* bias = a.bias ? a.bias + (size_t)h * N * N : nullptr;
+    const float* mask = (a.mask && a.nW > 0) ? a.mask + (size_t)(b % a.nW) * N * N : nullptr;
+    if constexpr (TABLE) {
+        if (bias || mask) {
+            for (int i = t; i < N * N; i += 256) Ts[i] = (bias ? bias[i] : 0.f) + (mask ? mask[i] : 0.f);
+        }
     }
     __syncthreads();
 
-    const float* bias = a.bias ? a.bias + (size_t)h * N * N : nullptr;
-    const float* mask = (a.mask && a.nW > 0) ? a.mask + (size_t)(b % a.nW) * N * N : nullptr;
     half_t* obase = reinterpret_cast<half_t*>(a.out) + (size_t)b * N * heads * HD + (size_t)h * HD;
 
-    const int nqt = (N + 15) >> 4;
+    // transposing V reads: lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3
+    const int vlane = (4 * g + (li >> 2)) * SR + (li & 3) * 8;
+    auto load_v = [&](int pr, fp16x4 (&lo)[DT], fp16x4 (&hi)[DT]) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const char* a0 = Vs + pr * 32 * SR + vlane + dt * 32;
+            lo[dt] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16x4*)(a0));
+            hi[dt] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16x4*)(a0 + 16 * SR));
+        }
+    };
+    const int klane = li * SR + g * 16;
+
+#pragma unroll 1
     for (int qt = wv; qt < nqt; qt += 4) {
         const int query = qt * 16 + li;
         const bool qok = query < N;
-        // Q fragments (B operand): this lane's query row, d = 32*ks + 8g .. +7
-        u32x4 qf[KS];
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            u32x4 z = {0u, 0u, 0u, 0u};
-            qf[ks] = qok ? *reinterpret_cast<const u32x4*>(qbase + (size_t)query * tok_ld + ks * 32 + g * 8) : z;
-        }
-        // ---- scores: s[kt][r] = S[query][key = 16kt + 4g + r]
-        float s[NT][4];
-        float mx = -INFINITY;
-#pragma unroll
-        for (int kt = 0; kt < NT; ++kt) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        // next tile's Q rows travel while this tile computes
+        u32x4 qnext[KS];
+        {
+            const int nq = query + 64;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const u32x4 kf = *reinterpret_cast<const u32x4*>(Ks + (kt * 16 + li) * SR + (ks * 4 + g) * 16);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8v, kf),
-                                                             __builtin_bit_cast(half8v, qf[ks]), acc, 0, 0, 0);
+                qnext[ks] = u32x4{0u, 0u, 0u, 0u};
+                if (qt + 4 < nqt && nq < N)
+                    qnext[ks] = *reinterpret_cast<const u32x4*>(qbase + (size_t)nq * tok_ld + ks * 32 + g * 8);
             }
+        }
+        // ---- scores: s[kt][r] = S[query][key = 16kt + 4g + r]; K fragments of tile kt+1 are read from LDS
+        // while the MFMAs of tile kt run
+        float s[NT][4];
+        float mx = -INFINITY;
+        u32x4 kf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) kf[ks] = *reinterpret_cast<const u32x4*>(Ks + klane + ks * 64);
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            u32x4 kn[KS];
+            if (kt + 1 < NT) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+                    kn[ks] = *reinterpret_cast<const u32x4*>(Ks + (kt + 1) * 16 * SR + klane + ks * 64);
+            }
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8v, kf[ks]),
+                                                             __builtin_bit_cast(half8v, qcur[ks]), acc, 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = kt * 16 + 4 * g + r;
                 float v = acc[r] * a.scale;
                 if (key < N) {
-                    if (bias && qok) v += bias[(size_t)query * N + key];
-                    if (mask && qok) v += mask[(size_t)query * N + key];
+                    if constexpr (TABLE) {
+                        if ((bias || mask) && qok) v += Ts[query * N + key];
+                    } else {
+                        if (bias && qok) v += bias[(size_t)query * N + key];
+                        if (mask && qok) v += mask[(size_t)query * N + key];
+                    }
                 } else {
                     v = -INFINITY;
                 }
                 s[kt][r] = v;
                 mx = fmaxf(mx, v);
             }
+            if (kt + 1 < NT) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) kf[ks] = kn[ks];
+            }
         }
+        // V fragments of the first key pair: in flight during the softmax
+        fp16x4 vlo[DT], vhi[DT];
+        load_v(0, vlo, vhi);
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         float sum = 0.f;
@@ -119,33 +190,33 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnArgs a) {
         sum += __shfl_xor(sum, 32, 64);
         const float inv = 1.f / sum;
 
-        // ---- O^T = V^T . P^T
+        // ---- O^T = V^T . P^T, V fragments of pair pr+1 read while pair pr multiplies
         f32x4 o[DT];
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int pr = 0; pr < NT / 2; ++pr) {
+            fp16x4 nlo[DT], nhi[DT];
+            if (pr + 1 < NT / 2) load_v(pr + 1, nlo, nhi);
             half8v pf;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 pf[r] = (half_t)s[2 * pr][r];
                 pf[4 + r] = (half_t)s[2 * pr + 1][r];
             }
-            // transposing reads: lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3
-            const int q4 = li >> 2, p4 = li & 3;
-            const int row0 = pr * 32 + 4 * g + q4;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                const char* a0 = Vs + row0 * SR + (dt * 16 + 4 * p4) * 2;
-                fp16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16x4*)(a0));
-                fp16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16x4*)(a0 + 16 * SR));
                 half8v vf;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    vf[r] = (half_t)lo[r];
-                    vf[4 + r] = (half_t)hi[r];
+                    vf[r] = (half_t)vlo[dt][r];
+                    vf[4 + r] = (half_t)vhi[dt][r];
                 }
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, o[dt], 0, 0, 0);
+            }
+            if (pr + 1 < NT / 2) {
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) { vlo[dt] = nlo[dt]; vhi[dt] = nhi[dt]; }
             }
         }
         if (qok) {
@@ -157,12 +228,14 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnArgs a) {
                 *reinterpret_cast<half4v*>(obase + (size_t)query * heads * HD + dt * 16 + 4 * g) = ov;
             }
         }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qcur[ks] = qnext[ks];
     }
 }
 
 template <int HD, int NT> static int launch_one(const AttnArgs& a, hipStream_t st) {
     constexpr int SR = HD * 2 + 32;
-    const size_t lds = (size_t)2 * 16 * NT * SR;
+    const size_t lds = (size_t)2 * 16 * NT * SR + (NT <= 4 ? (size_t)a.N * a.N * sizeof(float) : 0);
     if (lds > 64 * 1024) {
         static thread_local bool raised = false;
         if (!raised) {

@@ -54,6 +54,8 @@ struct ConvArgs {
     int mtiles, ntiles;
     int vec_io;   // 1: y (and res) rows allow 16-byte vector access
     unsigned x_bytes, w_bytes;  // extents for the buffer descriptors
+    unsigned y_bytes;           // extent of y when it may be written through a descriptor (0: plain stores)
+    int store_policy;           // 0 plain, 16 sc1 (write-through, line dropped from L2), 2 nt
 };
 
 __device__ __attribute__((aligned(16))) unsigned g_zero_page[4];  // source of padding / tail chunks
@@ -112,6 +114,9 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 static __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds, int voff) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)lds, 16, voff, 0, 0, 0);
 }
+template <int AUX> static __device__ __forceinline__ void buf_store16(__amdgpu_buffer_rsrc_t rsrc, u32x4 v, int voff) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff, 0, AUX);
+}
 static __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const char* p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p), 0, bytes, 0x00020000);
 }
@@ -149,6 +154,7 @@ __global__ __launch_bounds__(WGM * 128) void conv_igemm_kernel(const ConvArgs a)
     // zeros of padding taps / tail rows / tail K chunks (offset OOB) with no select on the data path.
     const __amdgpu_buffer_rsrc_t xsrd = make_srd(a.x, a.x_bytes);
     const __amdgpu_buffer_rsrc_t wsrd = make_srd(a.w, a.w_bytes);
+    const __amdgpu_buffer_rsrc_t ysrd = make_srd(a.y, a.y_bytes);
 
     // ---- loader state.  Wave `wid` fills pieces wid, wid+4, ... ; inside a piece lane l owns tile row
     // 8*piece + (l>>3), LDS slot (l&7).  (row>>1)&7 = (4*(wid&1) + (l>>4)) & 7 for all of them, so the
@@ -400,7 +406,11 @@ __global__ __launch_bounds__(WGM * 128) void conv_igemm_kernel(const ConvArgs a)
                     for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
                 } else if (sizeof(T) == 2 && a.act == TLXMI_ACT_GELU) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
+                    for (int e = 0; e < 8; e += 2) {
+                        const f32x2v g2 = gelu_fast2(f32x2v{v[e], v[e + 1]});
+                        v[e] = g2[0];
+                        v[e + 1] = g2[1];
+                    }
                 } else if (a.act != TLXMI_ACT_NONE) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e], a.act, a.act_param);
@@ -409,7 +419,28 @@ __global__ __launch_bounds__(WGM * 128) void conv_igemm_kernel(const ConvArgs a)
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += rv[e];
                 }
-                if (full) {
+                if (full && a.store_policy != 0 && !a.strided_n) {
+                    // outputs are never re-read by this launch: keep them from evicting the operand panels from L2
+                    const int yoff = (int)(yp - a.y);
+                    u32x4 pk[ES / 2];
+                    if constexpr (ES == 2) {
+                        half8v h;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) h[e] = (half_t)v[e];
+                        pk[0] = __builtin_bit_cast(u32x4, h);
+                    } else {
+                        f32x4 f0, f1;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { f0[e] = v[e]; f1[e] = v[4 + e]; }
+                        pk[0] = __builtin_bit_cast(u32x4, f0);
+                        pk[ES / 2 - 1] = __builtin_bit_cast(u32x4, f1);
+                    }
+#pragma unroll
+                    for (int hh = 0; hh < ES / 2; ++hh) {
+                        if (a.store_policy == 16) buf_store16<16>(ysrd, pk[hh], yoff + 16 * hh);
+                        else buf_store16<2>(ysrd, pk[hh], yoff + 16 * hh);
+                    }
+                } else if (full) {
                     store8<T>(yp, v);
                 } else {
 #pragma unroll
@@ -558,6 +589,13 @@ extern "C" int tlxmi_conv2d(const tlxmi_conv2d_desc* d, const void* x, const voi
     a.Kp_bytes = a.ktiles * 128;
     a.mtiles = a.ntiles = 0;
     a.x_bytes = (unsigned)x_bytes;
+    {
+        // non-temporal stores by default (measured: -3..-28 % per layer); TLXMI_STORE=0/16/2 overrides for tuning
+        static const int pol = [] { const char* e = getenv("TLXMI_STORE"); return e ? atoi(e) : 2; }();
+        const long long yb = M * (long long)d->y_ld * es;
+        a.y_bytes = yb < (1ll << 31) ? (unsigned)yb : 0u;
+        a.store_policy = (a.y_bytes && !d->y_nstride) ? pol : 0;
+    }
     a.w_bytes = (unsigned)(((size_t)(d->Cout + 127) / 128 * 128) * (size_t)a.Kp_bytes);
     const int vecn = 16 / es;  // elements per 16 bytes
     const bool bcast = res && (d->flags & TLXMI_EPI_RES_BCAST_N);
