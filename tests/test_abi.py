@@ -72,3 +72,27 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         _lib.load()
+
+
+def test_host_dispatch_survives_without_a_device():
+    """The tile cost model / launch plumbing is host code: drive it with fake (aligned, never dereferenced on
+    the host) pointers over the shapes of the three headline models.  Without a GPU the launch itself fails
+    with TLXMI_ERR_LAUNCH (-4) — what must not happen is a host crash (division by zero in the model, ...)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("would launch on the device with fake pointers")
+    from tlxcv_amd import _lib
+    lib = _lib.load()
+    shapes = [(256, 224, 224, 8, 64, 7, 2, 3), (256, 56, 56, 64, 256, 1, 1, 0), (256, 14, 14, 256, 256, 3, 1, 1),
+              (50432, 1, 1, 768, 2304, 1, 1, 0), (50432, 1, 1, 3072, 768, 1, 1, 0), (256, 1, 1, 2048, 1000, 1, 1, 0),
+              (6272, 1, 1, 128, 384, 1, 1, 0), (1, 5, 5, 8, 3, 3, 1, 1)]
+    for dt in (0, 1):
+        for (N, H, W, Cc, Co, k, s, p) in shapes:
+            Ho = (H + 2 * p - k) // s + 1
+            d = _lib.ConvDesc(dtype=dt, N=N, H=H, W=W, C=Cc, Cout=Co, R=k, S=k, stride_h=s, stride_w=s, pad_h=p,
+                              pad_w=p, dil_h=1, dil_w=1, Ho=Ho, Wo=Ho if W > 1 else 1, x_ld=Cc, y_ld=Co, res_ld=Co,
+                              act=1)
+            for res in (None, ctypes.c_void_p(1 << 24)):
+                rc = lib.tlxmi_conv2d(ctypes.byref(d), ctypes.c_void_p(1 << 20), ctypes.c_void_p(1 << 22), None, None,
+                                      res, ctypes.c_void_p(1 << 26), None)
+                assert rc in (0, -4), (rc, lib.tlxmi_last_error())

@@ -27,6 +27,7 @@
 // chunk (l&7) ^ ((r>>1)&7) of its row.  Pieces are dealt to waves so that this chunk index is
 // the same for every piece a lane loads (one im2col position per lane per step).
 #include "common.h"
+#include "gemm256.h"
 #include <stdlib.h>
 
 namespace tlxmi {
@@ -52,6 +53,7 @@ struct ConvArgs {
     int cpt;      // chunks per filter tap = C*sizeof(T)/16
     int Kp_bytes; // packed filter row pitch in bytes (= ktiles*128)
     int mtiles, ntiles;
+    int gn;       // N-tiles per column panel of the tile walk
     int vec_io;   // 1: y (and res) rows allow 16-byte vector access
     unsigned x_bytes, w_bytes;  // extents for the buffer descriptors
     unsigned y_bytes;           // extent of y when it may be written through a descriptor (0: plain stores)
@@ -145,8 +147,15 @@ __global__ __launch_bounds__(WGM * 128) void conv_igemm_kernel(const ConvArgs a)
         const int nb = a.mtiles * a.ntiles, id = blockIdx.x;
         const int xcd = id & 7, qd = nb >> 3, rm = nb & 7;
         const int L = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (id >> 3);
-        tile_n = L % a.ntiles;
-        tile_m = L / a.ntiles;
+        // column panels of `gn` N-tiles (filter panel <= ~1.5 MB stays in the XCD's L2), M fastest inside
+        const int per_group = a.mtiles * a.gn;
+        int grp = L / per_group;
+        const int ngroups = (a.ntiles + a.gn - 1) / a.gn;
+        if (grp > ngroups - 1) grp = ngroups - 1;
+        const int rem = L - grp * per_group;
+        const int gn_here = (a.ntiles - grp * a.gn) < a.gn ? (a.ntiles - grp * a.gn) : a.gn;
+        tile_m = rem / gn_here;
+        tile_n = grp * a.gn + rem % gn_here;
     }
     const int bm0 = tile_m * BM, bn0 = tile_n * BN;
 
@@ -460,6 +469,11 @@ template <typename T, int BM, int BN, int WGM, int STAGES> static int launch(con
     ConvArgs b = a;
     b.mtiles = (a.M + BM - 1) / BM;
     b.ntiles = (a.Cout + BN - 1) / BN;
+    {
+        static const long budget = [] { const char* e = getenv("TLXMI_PANEL_KB"); return (e ? atol(e) : (1l << 20)) * 1024; }();   // default: no panels (N fastest); measured neutral
+        long gn = budget / ((long)BN * a.Kp_bytes);
+        b.gn = (int)(gn < 1 ? 1 : (gn > b.ntiles ? b.ntiles : gn));
+    }
     // LDS: the DMA ring (one buffer is enough when K fits a single step), re-used by the fp32 epilogue tile
     size_t lds = (size_t)(a.ktiles > 1 ? STAGES : 1) * (BM + BN) * 128;
     if (lds < (size_t)BM * BN * 4) lds = (size_t)BM * BN * 4;
@@ -509,21 +523,30 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st) {
     const double obytes = (double)a.M * a.Cout * sizeof(T) * (a.res ? 2.0 : 1.0);
     const double obi = obytes / flops;
     // candidate 4 = 256x128 pixels x channels, 8 waves, 3-deep DMA ring (one block per CU): MFMA-bound layers
-    Cand cands[5] = {{128, 128, 1.00f}, {64, 128, 0.85f}, {128, 64, 0.85f}, {64, 64, 0.70f}, {256, 128, 1.10f}};
+    // candidate 5 = gemm256.hip: 256x256, 8 waves, 4-deep ring of 64-byte K steps (pure GEMM rows only)
+    // candidate 6 = gemm256.hip's 256x128 variant: 4 waves, 3-deep ring, two workgroups per CU
+    Cand cands[7] = {{128, 128, 1.00f}, {64, 128, 0.85f}, {128, 64, 0.85f}, {64, 64, 0.70f}, {256, 128, 1.10f},
+                     {256, 256, 1.15f}, {256, 128, 1.15f}};
+    const bool gemm256_ok = a.R == 1 && a.S == 1 && a.ph == 0 && a.pw == 0 && a.sh == 1 && a.sw == 1 && !a.strided_n &&
+                            a.vec_io && a.Cout % 8 == 0 && a.y_bytes != 0 && a.Cout >= 256 && a.ktiles >= 2 &&
+                            (!a.res || (long long)a.M * a.res_ld * (long long)sizeof(T) < (1ll << 31));
+    if (!gemm256_ok) cands[5].eff = cands[6].eff = 0.f;
     if (obi >= 0.0015 || a.ktiles < 4) cands[4].eff = 0.f;
+    if (obi >= 0.0015) cands[5].eff = cands[6].eff = 0.f;
     if (obi >= 0.012) { cands[0].eff = 0.65f; cands[1].eff = 0.80f; cands[2].eff = 0.85f; cands[3].eff = 1.00f; }
     else if (obi >= 0.0015) { cands[0].eff = 0.85f; cands[1].eff = 0.90f; cands[2].eff = 1.00f; cands[3].eff = 0.90f; }
     const int cus = num_cus();
     int best = 0;
     float best_score = -1.f;
-    for (int i = 0; i < 5; ++i) {
+    for (int i = 0; i < 7; ++i) {
         const int bm = cands[i].bm, bn = cands[i].bn;
         if (cands[i].eff <= 0.f) continue;
         if (bn == 128 && a.Cout <= 64) continue;
-        size_t lds = (size_t)(a.ktiles > 1 ? (i == 4 ? 3 : 2) : 1) * (bm + bn) * 128;
-        if (lds < (size_t)bm * bn * 4) lds = (size_t)bm * bn * 4;
+        size_t lds = i == 5 ? (size_t)128 * 1024 : i == 6 ? (size_t)72 * 1024 : (size_t)(a.ktiles > 1 ? (i == 4 ? 3 : 2) : 1) * (bm + bn) * 128;
+        if (i < 5 && lds < (size_t)bm * bn * 4) lds = (size_t)bm * bn * 4;   // fp32 epilogue tile (gemm256 stores from registers)
         int per_cu = (int)((160 * 1024) / lds);
-        const int reg_cap = i == 4 ? 1 : (bm == 128 && bn == 128) ? 3 : ((bm == 64 && bn == 64) ? 8 : 5);
+        if (per_cu < 1) continue;
+        const int reg_cap = i == 6 ? 2 : i >= 4 ? 1 : (bm == 128 && bn == 128) ? 3 : ((bm == 64 && bn == 64) ? 8 : 5);
         if (per_cu > reg_cap) per_cu = reg_cap;
         const long blocks = (long)((a.M + bm - 1) / bm) * ((a.Cout + bn - 1) / bn);
         const long slots = (long)cus * per_cu;
@@ -535,7 +558,17 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st) {
         if (score > best_score) { best_score = score; best = i; }
     }
     static const int forced = [] { const char* e = getenv("TLXMI_TILE"); return e ? atoi(e) : -1; }();  // tuning aid
-    if (forced >= 0 && forced < 5 && !(cands[forced].bn == 128 && a.Cout <= 64)) best = forced;
+    if (forced >= 0 && forced < 7 && !(cands[forced].bn == 128 && a.Cout <= 64) && (forced < 5 || gemm256_ok)) best = forced;
+    if (best >= 5) {
+        Gemm256Args g;
+        g.x = a.x; g.w = a.w; g.y = a.y; g.scale = a.scale; g.shift = a.shift; g.res = a.res;
+        g.M = a.M; g.Cout = a.Cout; g.x_ld = a.x_ld; g.y_ld = a.y_ld; g.res_ld = a.res_ld;
+        g.kchunks = a.kchunks; g.ksteps = a.Kp_bytes / 64; g.Kp_bytes = a.Kp_bytes;
+        g.act = a.act; g.act_param = a.act_param; g.flags = a.flags; g.mtiles = g.ntiles = 0;
+        g.x_bytes = a.x_bytes; g.w_bytes = a.w_bytes; g.y_bytes = a.y_bytes;
+        g.res_bytes = a.res ? (unsigned)((long long)a.M * a.res_ld * (long long)sizeof(T)) : 0u;
+        return launch_gemm256(sizeof(T) == 2 ? TLXMI_F16 : TLXMI_F32, best - 5, g, st);
+    }
     switch (best) {
         case 0: return launch<T, 128, 128, 2, 2>(a, st);
         case 1: return launch<T, 64, 128, 2, 2>(a, st);
@@ -588,6 +621,7 @@ extern "C" int tlxmi_conv2d(const tlxmi_conv2d_desc* d, const void* x, const voi
     a.ktiles = (a.kchunks + 7) / 8;
     a.Kp_bytes = a.ktiles * 128;
     a.mtiles = a.ntiles = 0;
+    a.gn = 1;
     a.x_bytes = (unsigned)x_bytes;
     {
         // non-temporal stores by default (measured: -3..-28 % per layer); TLXMI_STORE=0/16/2 overrides for tuning

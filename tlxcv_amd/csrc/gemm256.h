@@ -1,0 +1,28 @@
+// Arguments of the 256 x 256 tile GEMM (gemm256.hip), filled by conv_igemm.hip's dispatcher.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace tlxmi {
+
+struct Gemm256Args {
+    const char* x;
+    const char* w;
+    char* y;
+    const float* scale;
+    const float* shift;
+    const char* res;
+    int M, Cout, x_ld, y_ld, res_ld;
+    int kchunks;   // true 16-byte chunks per row
+    int ksteps;    // 64-byte steps (packed pitch / 64)
+    int Kp_bytes;  // packed filter row pitch
+    int act;
+    float act_param;
+    unsigned flags;
+    int mtiles, ntiles;
+    int gn;        // N-tiles per column panel of the tile walk
+    unsigned x_bytes, w_bytes, y_bytes, res_bytes;
+};
+
+int launch_gemm256(int dtype, int variant, const Gemm256Args& a, hipStream_t st);
+
+}  // namespace tlxmi
