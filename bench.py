@@ -32,7 +32,8 @@ MFMA_F16_PEAK_TF = 2500.0  # dense fp16 MFMA
 
 def build_model(workload, dev):
     from tlxcv_amd import models, seeded
-    ctor = {"resnet50": "resnet50", "vit_b16": "vit_base_patch16_224"}[workload]
+    ctor = {"resnet50": "resnet50", "vit_b16": "vit_base_patch16_224",
+            "swin_b": "swintransformer_base_patch4_window7_224"}[workload]
     m = getattr(models, ctor)()
     params = seeded.fill(seeded.shapes_of(m), 1)
     m.load_dict(params)
@@ -51,7 +52,8 @@ def cpu_baseline(workload, params, batch=16, warm=1, iters=3):
     torch.set_num_threads(cores)
     p = {k: torch.from_numpy(v) for k, v in params.items()}
     x = torch.from_numpy(seeded.image_batch(batch, 0))
-    fn = {"resnet50": lambda: OF.resnet(p, x, 50), "vit_b16": lambda: OF.vit(p, x, "vit_base_patch16_224")}[workload]
+    fn = {"resnet50": lambda: OF.resnet(p, x, 50), "vit_b16": lambda: OF.vit(p, x, "vit_base_patch16_224"),
+          "swin_b": lambda: OF.swin(p, x, "swintransformer_base_patch4_window7_224")}[workload]
     with torch.no_grad():
         for _ in range(warm):
             fn()
@@ -69,11 +71,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=256, help="images per GPU")
-    ap.add_argument("--workload", default="resnet50", choices=["resnet50", "vit_b16"])
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU (default 256; 128 for swin_b)")
+    ap.add_argument("--workload", default="resnet50", choices=["resnet50", "vit_b16", "swin_b"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch kernel by kernel instead of replaying a hipGraph")
     a = ap.parse_args()
+    if a.batch is None:
+        a.batch = 128 if a.workload == "swin_b" else 256
 
     import tlxcv_amd
     from tlxcv_amd import dist as D, engine as E, seeded
@@ -127,7 +131,8 @@ def main():
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
         "config": {"workload": {"resnet50": "ResNet-50 fp16 forward, 224x224, batch 256 per GPU (BASELINE configs[1])",
-                                "vit_b16": "ViT-B/16 fp16 forward, 224x224, batch 256 per GPU (BASELINE configs[2])"}[a.workload],
+                                "vit_b16": "ViT-B/16 fp16 forward, 224x224, batch 256 per GPU (BASELINE configs[2])",
+                                "swin_b": "Swin-B (window 7) fp16 forward, 224x224, batch 128 per GPU (BASELINE configs[3])"}[a.workload],
                    "global_batch": a.batch * world, "per_gpu_batch": a.batch, "weights": "seeded random (tlxcv_amd.seeded, seed 1)",
                    "parallelism": f"batch-sharded x{world}, all-gather logits" if world > 1 else "single GPU",
                    "launch": "per-kernel" if a.no_graph else "hipGraph replay of the forward"},
@@ -157,7 +162,7 @@ def main():
         # (tools/pmc_traffic.sh; FETCH_SIZE doubled per MI355X_MICROARCH.md), committed under profiles/.
         traffic = None
         tj = os.path.join(REPO, "profiles", "r01", f"traffic_{a.workload}.json")
-        if os.path.exists(tj) and a.batch == 256:
+        if os.path.exists(tj) and a.batch == (128 if a.workload == "swin_b" else 256):
             traffic = int(json.load(open(tj))["hbm_bytes_per_launch"])
         line["roofline"] = {
             "bound": "hbm" if hbm_bound else "mfma",

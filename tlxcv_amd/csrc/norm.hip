@@ -7,13 +7,22 @@
 
 namespace tlxmi {
 
-template <typename T, int NCH, int RW>  // NCH = 16-byte chunks per lane and row, RW = rows per wave
+// NCH = 16-byte chunks per lane and row, RW = rows per lane group, LPR = lanes per row (16/32/64: narrow
+// rows such as Swin's C=128 use a quarter wave each, so all 64 lanes stay busy)
+template <int LPR> __device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <typename T, int NCH, int RW, int LPR>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, T* __restrict__ y, long rows,
                                                         int C, int x_ld, int y_ld, float eps) {
     constexpr int V = 16 / (int)sizeof(T);
-    const int lane = threadIdx.x & 63;
-    const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RW;
+    constexpr int GPW = 64 / LPR;                    // row groups per wave
+    const int lane = threadIdx.x & (LPR - 1);
+    const long row0 = (((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * GPW + ((threadIdx.x & 63) / LPR)) * RW;
     if (row0 >= rows) return;
     const int nch = C / V;
     // all RW x NCH 16-byte loads of this wave are issued before the first reduction: the kernel is a
@@ -23,7 +32,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
     for (int r = 0; r < RW; ++r)
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            const int ch = lane + 64 * i;
+            const int ch = lane + LPR * i;
             raw[r][i] = u32x4{0u, 0u, 0u, 0u};
             if (ch < nch && row0 + r < rows)
                 raw[r][i] = *reinterpret_cast<const u32x4*>(x + (row0 + r) * x_ld + ch * V);
@@ -32,7 +41,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
     float gm[NCH][V], bt[NCH][V];
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-        const int ch = lane + 64 * i;
+        const int ch = lane + LPR * i;
 #pragma unroll
         for (int e = 0; e < V; ++e) {
             const int c = ch < nch ? ch * V + e : 0;
@@ -59,11 +68,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
 #pragma unroll
             for (int e = 0; e < V; ++e) sum += v[i][e];   // lanes past the row hold zeros
         }
-        const float mean = wave_sum(sum) / (float)C;
+        const float mean = group_sum<LPR>(sum) / (float)C;
         float sq = 0.f;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            if (lane + 64 * i < nch) {
+            if (lane + LPR * i < nch) {
 #pragma unroll
                 for (int e = 0; e < V; ++e) {
                     const float d = v[i][e] - mean;
@@ -71,10 +80,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
                 }
             }
         }
-        const float rstd = 1.f / sqrtf(wave_sum(sq) / (float)C + eps);
+        const float rstd = 1.f / sqrtf(group_sum<LPR>(sq) / (float)C + eps);
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            const int ch = lane + 64 * i;
+            const int ch = lane + LPR * i;
             if (ch < nch) {
                 float o[V];
 #pragma unroll
@@ -99,15 +108,18 @@ template <typename T>
 static int launch_ln(const void* x, const float* gamma, const float* beta, void* y, long rows, int C, int x_ld,
                      int y_ld, float eps, hipStream_t st) {
     constexpr int V = 16 / (int)sizeof(T);
-    const int per_lane = (C / V + 63) / 64;
-#define LN_CASE(n, rw)                                                                                            \
-    hipLaunchKernelGGL((layernorm_kernel<T, n, rw>), dim3((unsigned)((rows + 4 * rw - 1) / (4 * rw))), dim3(256), 0, \
-                       st, (const T*)x, gamma, beta, (T*)y, rows, C, x_ld, y_ld, eps)
-    if (per_lane <= 1) LN_CASE(1, 4);
-    else if (per_lane <= 2) LN_CASE(2, 4);
-    else if (per_lane <= 4) LN_CASE(4, 2);
-    else if (per_lane <= 8) LN_CASE(8, 1);
-    else if (per_lane <= 16) LN_CASE(16, 1);
+    const int nch = C / V;
+#define LN_CASE(n, rw, lpr)                                                                                       \
+    hipLaunchKernelGGL((layernorm_kernel<T, n, rw, lpr>),                                                         \
+                       dim3((unsigned)((rows + 4 * rw * (64 / lpr) - 1) / (4 * rw * (64 / lpr)))), dim3(256), 0, st, \
+                       (const T*)x, gamma, beta, (T*)y, rows, C, x_ld, y_ld, eps)
+    if (nch <= 16) LN_CASE(1, 4, 16);
+    else if (nch <= 32) LN_CASE(1, 4, 32);
+    else if (nch <= 64) LN_CASE(1, 4, 64);
+    else if (nch <= 128) LN_CASE(2, 4, 64);
+    else if (nch <= 256) LN_CASE(4, 2, 64);
+    else if (nch <= 512) LN_CASE(8, 1, 64);
+    else if (nch <= 1024) LN_CASE(16, 1, 64);
     else return fail(TLXMI_ERR_UNSUPPORTED, "layernorm: C=%d too wide for the in-register row kernel", C);
 #undef LN_CASE
     return check_launch("layernorm");

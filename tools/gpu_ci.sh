@@ -21,6 +21,7 @@ for s in "$@"; do
         testsall) step pytest 900 python -m pytest tests -m gpu -q --timeout=600 ;;
         bench) step bench 600 python bench.py --steps 20 --warmup 5 ;;
         benchvit) step benchvit 600 python bench.py --workload vit_b16 --steps 10 --warmup 3 --no-cpu-baseline ;;
+        benchswin) step benchswin 600 python bench.py --workload swin_b --steps 10 --warmup 3 --no-cpu-baseline ;;
         prof) cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
               step prof 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline ;;
         *) echo "unknown step $s" ;;
