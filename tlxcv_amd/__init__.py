@@ -24,6 +24,9 @@ def install():
     sys.modules.setdefault("tensorlayerx.nn", tlx.nn)
     sys.modules.setdefault("tensorlayerx.nn.initializers", tlx.nn.initializers)
     sys.modules.setdefault("tensorlayerx.ops", tlx.ops)
+    sys.modules.setdefault("tensorlayerx.vision", tlx.vision)
+    sys.modules.setdefault("tensorlayerx.vision.transforms", tlx.vision.transforms)
+    sys.modules.setdefault("tensorlayerx.vision.transforms.utils", tlx.vision.transforms.utils)
     for sub in ("models", "tasks"):
         m = importlib.import_module(f"{__name__}.{sub}")
         sys.modules.setdefault(f"tlxcv.{sub}", m)

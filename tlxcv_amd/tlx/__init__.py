@@ -8,7 +8,7 @@ import numpy as np
 import torch
 
 from .. import engine as _E
-from . import nn, ops  # noqa: F401
+from . import nn, ops, vision  # noqa: F401
 from .nn import initializers  # noqa: F401
 from .ops import (GeLU, softmax, sigmoid, relu, arange, stack)  # noqa: F401
 

@@ -1,0 +1,93 @@
+"""`tensorlayerx.vision.transforms` subset: Compose, Resize, Normalize, ToTensor (+ CentralCrop, HWC2CHW).
+
+Host-side image preprocessing, exactly where the reference does it (PIL/numpy on the CPU, one image at a
+time, demo/image_classification/predict.py:21-29) — it is not on the accelerated path.  ToTensor hands the
+result to the device the engine runs on.  Semantics restated from the TensorLayerX documentation
+[TLX-recalled]: images are HWC arrays; Resize is bilinear by default; Normalize is (x - mean) / std per
+channel; ToTensor rescales by 1/255 only for uint8 input and reorders to CHW when asked.
+"""
+import numpy as np
+import torch
+
+from . import utils  # noqa: F401
+
+__all__ = ["Compose", "Resize", "Normalize", "ToTensor", "CentralCrop", "HWC2CHW"]
+
+
+class Compose:
+    def __init__(self, transforms):
+        self.transforms = list(transforms)
+
+    def __call__(self, data):
+        for t in self.transforms:
+            data = t(data)
+        return data
+
+
+def _as_hwc(img):
+    a = np.asarray(img)
+    if a.ndim == 2:
+        a = a[:, :, None]
+    return a
+
+
+class Resize:
+    def __init__(self, size, interpolation="bilinear"):
+        self.size = (size, size) if isinstance(size, int) else tuple(size)    # (h, w)
+        self.interpolation = interpolation
+
+    def __call__(self, img):
+        from PIL import Image
+        a = _as_hwc(img)
+        mode = {"bilinear": Image.BILINEAR, "nearest": Image.NEAREST, "bicubic": Image.BICUBIC}[self.interpolation]
+        h, w = self.size
+        if a.dtype == np.uint8:
+            pil = Image.fromarray(a.squeeze(-1) if a.shape[-1] == 1 else a)
+            out = np.asarray(pil.resize((w, h), mode))
+            return out[:, :, None] if out.ndim == 2 else out
+        chans = [np.asarray(Image.fromarray(a[:, :, c].astype(np.float32), mode="F").resize((w, h), mode))
+                 for c in range(a.shape[-1])]
+        return np.stack(chans, -1)
+
+
+class CentralCrop:
+    def __init__(self, size):
+        self.size = (size, size) if isinstance(size, int) else tuple(size)
+
+    def __call__(self, img):
+        a = _as_hwc(img)
+        h, w = self.size
+        top, left = (a.shape[0] - h) // 2, (a.shape[1] - w) // 2
+        return a[top:top + h, left:left + w]
+
+
+class Normalize:
+    def __init__(self, mean, std):
+        self.mean = np.asarray(mean, dtype=np.float32)
+        self.std = np.asarray(std, dtype=np.float32)
+
+    def __call__(self, img):
+        a = _as_hwc(img).astype(np.float32)
+        return (a - self.mean) / self.std
+
+
+class HWC2CHW:
+    def __call__(self, img):
+        return np.transpose(_as_hwc(img), (2, 0, 1))
+
+
+class ToTensor:
+    def __init__(self, data_format="HWC"):
+        if data_format not in ("HWC", "CHW"):
+            raise ValueError("data_format should be CHW or HWC. Got {}".format(data_format))
+        self.data_format = data_format
+
+    def __call__(self, img):
+        a = _as_hwc(img)
+        if a.dtype == np.uint8:
+            a = a.astype(np.float32) / 255.0
+        a = a.astype(np.float32)
+        if self.data_format == "CHW":
+            a = np.transpose(a, (2, 0, 1))
+        t = torch.from_numpy(np.ascontiguousarray(a))
+        return t.cuda() if torch.cuda.is_available() else t
