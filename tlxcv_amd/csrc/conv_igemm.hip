@@ -58,6 +58,7 @@ struct ConvArgs {
     unsigned x_bytes, w_bytes;  // extents for the buffer descriptors
     unsigned y_bytes;           // extent of y when it may be written through a descriptor (0: plain stores)
     int store_policy;           // 0 plain, 16 sc1 (write-through, line dropped from L2), 2 nt
+    int sb_off;                 // LDS byte offset of the block's scale/shift table (2 x BN floats)
 };
 
 __device__ __attribute__((aligned(16))) unsigned g_zero_page[4];  // source of padding / tail chunks
@@ -275,6 +276,15 @@ __global__ __launch_bounds__(WGM * 128) void conv_igemm_kernel(const ConvArgs a)
     if constexpr (STAGES == 3) {
         if (a.ktiles > 1) { advance(); stage(1); }
     }
+    // folded-BatchNorm / bias table of this block's BN channels -> LDS now, so the epilogue does not start
+    // with a dependent global load (visible to every wave after the K loop's barriers)
+    float* sbuf = reinterpret_cast<float*>(smem + a.sb_off);
+    if (t < BN) {
+        const int ch = bn0 + t < a.Cout ? bn0 + t : a.Cout - 1;
+        sbuf[t] = a.scale ? a.scale[ch] : 1.f;
+        sbuf[BN + t] = a.shift ? a.shift[ch] : 0.f;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the LDS writes are done before this wave's next barrier
+    }
     if constexpr (RESP) {
         const int ch0 = bn0 + 8 * (t % CPR);
 #pragma unroll
@@ -333,13 +343,12 @@ __global__ __launch_bounds__(WGM * 128) void conv_igemm_kernel(const ConvArgs a)
 #pragma unroll
         for (int cp = 0; cp < CP; ++cp) {
             const int col = wave_n0 + 32 * cp + 8 * g;  // tile-local first channel of this lane's 8
-            const int ch0 = bn0 + col;
             float sc[8], sf[8];
+            {
+                const f32x4 s0 = *reinterpret_cast<const f32x4*>(sbuf + col), s1 = *reinterpret_cast<const f32x4*>(sbuf + col + 4);
+                const f32x4 h0 = *reinterpret_cast<const f32x4*>(sbuf + BN + col), h1 = *reinterpret_cast<const f32x4*>(sbuf + BN + col + 4);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int ch = ch0 + e < a.Cout ? ch0 + e : a.Cout - 1;
-                sc[e] = a.scale ? a.scale[ch] : 1.f;
-                sf[e] = a.shift ? a.shift[ch] : 0.f;
+                for (int e = 0; e < 4; ++e) { sc[e] = s0[e]; sc[4 + e] = s1[e]; sf[e] = h0[e]; sf[4 + e] = h1[e]; }
             }
 #pragma unroll
             for (int pi = 0; pi < PI; ++pi) {
@@ -477,6 +486,8 @@ template <typename T, int BM, int BN, int WGM, int STAGES> static int launch(con
     // LDS: the DMA ring (one buffer is enough when K fits a single step), re-used by the fp32 epilogue tile
     size_t lds = (size_t)(a.ktiles > 1 ? STAGES : 1) * (BM + BN) * 128;
     if (lds < (size_t)BM * BN * 4) lds = (size_t)BM * BN * 4;
+    b.sb_off = (int)lds;
+    lds += 2 * BN * sizeof(float);
     const long grid = (long)b.mtiles * b.ntiles;
     const bool is1x1 = a.R == 1 && a.S == 1 && a.ph == 0 && a.pw == 0;
     const bool resp = a.res && a.vec_io && !a.strided_n;
@@ -544,6 +555,7 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st) {
         if (bn == 128 && a.Cout <= 64) continue;
         size_t lds = i == 5 ? (size_t)128 * 1024 : i == 6 ? (size_t)72 * 1024 : (size_t)(a.ktiles > 1 ? (i == 4 ? 3 : 2) : 1) * (bm + bn) * 128;
         if (i < 5 && lds < (size_t)bm * bn * 4) lds = (size_t)bm * bn * 4;   // fp32 epilogue tile (gemm256 stores from registers)
+        lds += 2 * bn * sizeof(float);                                        // scale / shift table
         int per_cu = (int)((160 * 1024) / lds);
         if (per_cu < 1) continue;
         const int reg_cap = i == 6 ? 2 : i >= 4 ? 1 : (bm == 128 && bn == 128) ? 3 : ((bm == 64 && bn == 64) ? 8 : 5);
@@ -622,6 +634,7 @@ extern "C" int tlxmi_conv2d(const tlxmi_conv2d_desc* d, const void* x, const voi
     a.Kp_bytes = a.ktiles * 128;
     a.mtiles = a.ntiles = 0;
     a.gn = 1;
+    a.sb_off = 0;
     a.x_bytes = (unsigned)x_bytes;
     {
         // non-temporal stores by default (measured: -3..-28 % per layer); TLXMI_STORE=0/16/2 overrides for tuning

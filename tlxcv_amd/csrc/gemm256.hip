@@ -128,6 +128,14 @@ __global__ __launch_bounds__(WGN * 128, 2) void gemm256_kernel(const Gemm256Args
     stage(0);
     if (ks > 1) stage(1);
     if (NSLOT == 4 && ks > 2) stage(2);
+    // scale / shift of this block's BN channels -> LDS behind the ring (read back in the epilogue)
+    float* sbuf = reinterpret_cast<float*>(smem + NSLOT * STEP);
+    if (t < BN) {
+        const int ch = bn0 + t < a.Cout ? bn0 + t : a.Cout - 1;
+        sbuf[t] = a.scale ? a.scale[ch] : 1.f;
+        sbuf[BN + t] = a.shift ? a.shift[ch] : 0.f;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the LDS writes are done before this wave's next barrier
+    }
     int slot = 0;
     for (int kt = 0; kt < ks; ++kt) {
         // DPS DMA instructions per wave and step: leave the younger steps in flight
@@ -158,10 +166,12 @@ __global__ __launch_bounds__(WGN * 128, 2) void gemm256_kernel(const Gemm256Args
         const int ch0 = bn0 + wave_n0 + 32 * cp + 8 * g;
         if (ch0 >= a.Cout) continue;      // Cout is a multiple of 8 on this path
         float sc[8], sf[8];
+        {
+            const int col = wave_n0 + 32 * cp + 8 * g;
+            const f32x4 s0 = *reinterpret_cast<const f32x4*>(sbuf + col), s1 = *reinterpret_cast<const f32x4*>(sbuf + col + 4);
+            const f32x4 h0 = *reinterpret_cast<const f32x4*>(sbuf + BN + col), h1 = *reinterpret_cast<const f32x4*>(sbuf + BN + col + 4);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            sc[e] = a.scale ? a.scale[ch0 + e] : 1.f;
-            sf[e] = a.shift ? a.shift[ch0 + e] : 0.f;
+            for (int e = 0; e < 4; ++e) { sc[e] = s0[e]; sc[4 + e] = s1[e]; sf[e] = h0[e]; sf[4 + e] = h1[e]; }
         }
         u32x4 rr[PI][ES / 2];
         if (a.res) {
@@ -244,7 +254,7 @@ template <typename T, int BN, int WGN, int NSLOT> static int launch_v(const Gemm
         long gn = budget / ((long)BN * a.Kp_bytes);
         a.gn = (int)(gn < 1 ? 1 : (gn > a.ntiles ? a.ntiles : gn));
     }
-    const size_t lds = (size_t)NSLOT * (256 + BN) * 64;
+    const size_t lds = (size_t)NSLOT * (256 + BN) * 64 + 2 * BN * sizeof(float);
     const void* fn = reinterpret_cast<const void*>(&gemm256_kernel<T, BN, WGN, NSLOT>);
     if (!raised) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
