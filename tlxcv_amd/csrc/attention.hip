@@ -12,6 +12,7 @@
 //                       This is the fp32 parity path and the generic fallback.
 //   attn_mfma_kernel  — fp16 throughput path (see below), hd in {32, 64}.
 #include "common.h"
+#include <stdlib.h>
 
 namespace tlxmi {
 

@@ -30,7 +30,10 @@ struct AttnArgs {
 typedef __fp16 fp16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) fp16x4 lds_fp16x4;
 
-template <int HD, int NT>  // NT = number of 16-key tiles (even), keys padded to 16*NT
+// NT = number of 16-key tiles (even), keys padded to 16*NT.  ADD = how bias + mask reach the scores:
+// 0 none (ViT: no code at all in the score loop), 1 summed once into an LDS table (Swin-sized windows),
+// 2 read from global memory per score (generic fallback).
+template <int HD, int NT, int ADD>
 __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const AttnArgs a) {
     constexpr int SR = HD * 2 + 32;          // padded LDS row stride in bytes (160 / 96)
     constexpr int NP = 16 * NT;              // padded key count
@@ -90,14 +93,11 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const AttnArgs a) {
     }
     // Swin-sized windows: the (N, N) relative-position bias of this head and the shift mask of this window are
     // summed once into an LDS table (coalesced reads) instead of two dependent global gathers per score
-    constexpr bool TABLE = NT <= 4;
     float* Ts = reinterpret_cast<float*>(smem + 2 * NP * SR);
     const float* bias = a.bias ? a.bias + (size_t)h * N * N : nullptr;
     const float* mask = (a.mask && a.nW > 0) ? a.mask + (size_t)(b % a.nW) * N * N : nullptr;
-    if constexpr (TABLE) {
-        if (bias || mask) {
-            for (int i = t; i < N * N; i += 256) Ts[i] = (bias ? bias[i] : 0.f) + (mask ? mask[i] : 0.f);
-        }
+    if constexpr (ADD == 1) {
+        for (int i = t; i < N * N; i += 256) Ts[i] = (bias ? bias[i] : 0.f) + (mask ? mask[i] : 0.f);
     }
     __syncthreads();
 
@@ -150,20 +150,22 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const AttnArgs a) {
             for (int ks = 0; ks < KS; ++ks)
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8v, kf[ks]),
                                                              __builtin_bit_cast(half8v, qcur[ks]), acc, 0, 0, 0);
+            // ADD == 0 keeps the raw dot products (the scale is folded into the exponent below); key tiles that lie
+            // wholly inside the sequence need no padding mask (wave-uniform test)
+            const bool full_tile = kt * 16 + 16 <= N;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = kt * 16 + 4 * g + r;
-                float v = acc[r] * a.scale;
-                if (key < N) {
-                    if constexpr (TABLE) {
-                        if ((bias || mask) && qok) v += Ts[query * N + key];
-                    } else {
-                        if (bias && qok) v += bias[(size_t)query * N + key];
-                        if (mask && qok) v += mask[(size_t)query * N + key];
+                float v = ADD == 0 ? acc[r] : acc[r] * a.scale;
+                if constexpr (ADD == 1) {
+                    if (qok && (full_tile || key < N)) v += Ts[query * N + key];
+                } else if constexpr (ADD == 2) {
+                    if (qok && (full_tile || key < N)) {
+                        if (bias) v += bias[(size_t)query * N + key];
+                        if (mask) v += mask[(size_t)query * N + key];
                     }
-                } else {
-                    v = -INFINITY;
                 }
+                if (!full_tile && key >= N) v = -INFINITY;
                 s[kt][r] = v;
                 mx = fmaxf(mx, v);
             }
@@ -177,12 +179,14 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const AttnArgs a) {
         load_v(0, vlo, vhi);
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float ec = a.scale * 1.44269504088896340736f;
         float sum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = __expf(s[kt][r] - mx);
+                // ADD == 0: softmax(scale * x) = exp2((x - max x) * scale * log2 e), one FMA + v_exp_f32
+                const float p = ADD == 0 ? __builtin_amdgcn_exp2f(fmaf(s[kt][r], ec, -mx * ec)) : __expf(s[kt][r] - mx);
                 s[kt][r] = p;
                 sum += p;
             }
@@ -233,20 +237,26 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const AttnArgs a) {
     }
 }
 
-template <int HD, int NT> static int launch_one(const AttnArgs& a, hipStream_t st) {
+template <int HD, int NT, int ADD> static int launch_add(const AttnArgs& a, hipStream_t st) {
     constexpr int SR = HD * 2 + 32;
-    const size_t lds = (size_t)2 * 16 * NT * SR + (NT <= 4 ? (size_t)a.N * a.N * sizeof(float) : 0);
+    const size_t lds = (size_t)2 * 16 * NT * SR + (ADD == 1 ? (size_t)a.N * a.N * sizeof(float) : 0);
     if (lds > 64 * 1024) {
         static thread_local bool raised = false;
         if (!raised) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<HD, NT>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<HD, NT, ADD>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return fail(TLXMI_ERR_LAUNCH, "attention: cannot raise LDS limit: %s", hipGetErrorString(e));
             raised = true;
         }
     }
-    hipLaunchKernelGGL((attn_mfma_kernel<HD, NT>), dim3(a.B * a.heads), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((attn_mfma_kernel<HD, NT, ADD>), dim3(a.B * a.heads), dim3(256), lds, st, a);
     return check_launch("attention(mfma)");
+}
+
+template <int HD, int NT> static int launch_one(const AttnArgs& a, hipStream_t st) {
+    if (!a.bias && !(a.mask && a.nW > 0) && a.scale > 0.f) return launch_add<HD, NT, 0>(a, st);   // scale folded into exp2: needs scale > 0
+    if (NT <= 4) return launch_add<HD, NT, 1>(a, st);
+    return launch_add<HD, NT, 2>(a, st);
 }
 
 template <int HD> static int launch_hd(const AttnArgs& a, hipStream_t st) {
