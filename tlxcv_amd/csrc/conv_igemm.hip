@@ -239,10 +239,21 @@ __global__ __launch_bounds__(WGM * 128) void conv_igemm_kernel(const ConvArgs a)
     auto advance = [&]() {
         q += 8;
         if constexpr (!IS_1X1) {
-            cc += 8;
-            while (cc >= a.cpt) {
-                cc -= a.cpt;
-                if (++s == a.S) { s = 0; ++r; }
+            if (a.cpt >= 8) {
+                // at most one tap boundary per 8-chunk step: branch-free (lanes wrap at different steps)
+                cc += 8;
+                const bool w1 = cc >= a.cpt;
+                cc -= w1 ? a.cpt : 0;
+                s += w1 ? 1 : 0;
+                const bool w2 = s == a.S;
+                s = w2 ? 0 : s;
+                r += w2 ? 1 : 0;
+            } else {
+                // few-channel inputs (space-to-depth stems): several taps per step, re-derive from q
+                const int tap = q / a.cpt;
+                cc = q - tap * a.cpt;
+                r = tap / a.S;
+                s = tap - r * a.S;
             }
         }
     };
