@@ -548,7 +548,7 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st) {
     // candidate 5 = gemm256.hip: 256x256, 8 waves, 4-deep ring of 64-byte K steps (pure GEMM rows only)
     // candidate 6 = gemm256.hip's 256x128 variant: 4 waves, 3-deep ring, two workgroups per CU
     Cand cands[7] = {{128, 128, 1.00f}, {64, 128, 0.85f}, {128, 64, 0.85f}, {64, 64, 0.70f}, {256, 128, 0.90f},
-                     {256, 256, 1.15f}, {256, 128, 1.15f}};
+                     {256, 256, 1.12f}, {256, 128, 1.20f}};
     const bool gemm256_ok = a.R == 1 && a.S == 1 && a.ph == 0 && a.pw == 0 && a.sh == 1 && a.sw == 1 && !a.strided_n &&
                             a.vec_io && a.Cout % 8 == 0 && a.y_bytes != 0 && a.Cout >= 256 && a.ktiles >= 2 &&
                             (!a.res || (long long)a.M * a.res_ld * (long long)sizeof(T) < (1ll << 31));

@@ -49,45 +49,64 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
             bt[i][e] = beta ? beta[c] : 0.f;
         }
     }
+    // three phases over all RW rows at once (the RW reduction chains are independent, so their cross-lane
+    // latencies overlap): sums -> means, centred squares -> rstd, normalise + store
+    auto unpack = [&](int r, int i, float* f) {
+        if constexpr (sizeof(T) == 2) {
+            const half8v h = __builtin_bit_cast(half8v, raw[r][i]);
+#pragma unroll
+            for (int e = 0; e < V; ++e) f[e] = (float)h[e];
+        } else {
+            const f32x4 h = __builtin_bit_cast(f32x4, raw[r][i]);
+#pragma unroll
+            for (int e = 0; e < V; ++e) f[e] = h[e];
+        }
+    };
+    float mean[RW], rstd[RW];
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
-        if (row0 + r >= rows) break;
-        float v[NCH][V];
         float sum = 0.f;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            if constexpr (sizeof(T) == 2) {
-                const half8v h = __builtin_bit_cast(half8v, raw[r][i]);
+            float f[V];
+            unpack(r, i, f);
 #pragma unroll
-                for (int e = 0; e < V; ++e) v[i][e] = (float)h[e];
-            } else {
-                const f32x4 h = __builtin_bit_cast(f32x4, raw[r][i]);
-#pragma unroll
-                for (int e = 0; e < V; ++e) v[i][e] = h[e];
-            }
-#pragma unroll
-            for (int e = 0; e < V; ++e) sum += v[i][e];   // lanes past the row hold zeros
+            for (int e = 0; e < V; ++e) sum += f[e];   // lanes past the row hold zeros
         }
-        const float mean = group_sum<LPR>(sum) / (float)C;
+        mean[r] = sum;
+    }
+#pragma unroll
+    for (int r = 0; r < RW; ++r) mean[r] = group_sum<LPR>(mean[r]) / (float)C;
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
         float sq = 0.f;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             if (lane + LPR * i < nch) {
+                float f[V];
+                unpack(r, i, f);
 #pragma unroll
                 for (int e = 0; e < V; ++e) {
-                    const float d = v[i][e] - mean;
+                    const float d = f[e] - mean[r];
                     sq += d * d;
                 }
             }
         }
-        const float rstd = 1.f / sqrtf(group_sum<LPR>(sq) / (float)C + eps);
+        rstd[r] = sq;
+    }
+#pragma unroll
+    for (int r = 0; r < RW; ++r) rstd[r] = 1.f / sqrtf(group_sum<LPR>(rstd[r]) / (float)C + eps);
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        if (row0 + r >= rows) break;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int ch = lane + LPR * i;
             if (ch < nch) {
-                float o[V];
+                float f[V], o[V];
+                unpack(r, i, f);
 #pragma unroll
-                for (int e = 0; e < V; ++e) o[e] = (v[i][e] - mean) * rstd * gm[i][e] + bt[i][e];
+                for (int e = 0; e < V; ++e) o[e] = (f[e] - mean[r]) * rstd[r] * gm[i][e] + bt[i][e];
                 if constexpr (sizeof(T) == 2) {
                     half8v h;
 #pragma unroll
@@ -115,8 +134,8 @@ static int launch_ln(const void* x, const float* gamma, const float* beta, void*
                        (const T*)x, gamma, beta, (T*)y, rows, C, x_ld, y_ld, eps)
     if (nch <= 16) LN_CASE(1, 4, 16);
     else if (nch <= 32) LN_CASE(1, 4, 32);
-    else if (nch <= 64) LN_CASE(1, 4, 64);
-    else if (nch <= 128) LN_CASE(2, 4, 64);
+    else if (nch <= 64) LN_CASE(1, 8, 64);
+    else if (nch <= 128) LN_CASE(2, 8, 64);
     else if (nch <= 256) LN_CASE(4, 2, 64);
     else if (nch <= 512) LN_CASE(8, 1, 64);
     else if (nch <= 1024) LN_CASE(16, 1, 64);

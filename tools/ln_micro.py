@@ -1,0 +1,16 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from tlxcv_amd import engine as E
+dev = torch.device("cuda:0")
+for rows, C in ((50432, 768), (401408, 128), (100352, 256)):
+    x = torch.randn((rows, C), device=dev).half()
+    g = torch.ones(C, device=dev); b = torch.zeros(C, device=dev)
+    for _ in range(5): E.layernorm(x, g, b, 1e-6)
+    torch.cuda.synchronize()
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for _ in range(20): E.layernorm(x, g, b, 1e-6)
+    t1.record(); torch.cuda.synchronize()
+    us = 1e3 * t0.elapsed_time(t1) / 20
+    print(f"LN {rows}x{C}: {us:.1f} us  {2 * rows * C * 2 / us / 1e3:.0f} GB/s")
