@@ -88,6 +88,7 @@ def main():
         if world == 1 and a.gpus > 1:
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path"
+    local = local % torch.cuda.device_count()   # (a 2-rank rehearsal on a 1-GPU box shares the device)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     tlxcv_amd.set_precision("fp16")
