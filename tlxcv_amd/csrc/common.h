@@ -48,6 +48,34 @@ __device__ __forceinline__ float apply_act(float x, int act, float p) {
     }
 }
 
+// Compile-time activation (the epilogues dispatch on `act` ONCE and run a specialised row loop: a runtime
+// switch per element bloats the unrolled epilogue to ~18k instructions and starves the instruction fetch).
+template <int ACT> __device__ __forceinline__ float apply_act_t(float x, float p) {
+    if constexpr (ACT == TLXMI_ACT_RELU) return fmaxf(x, 0.f);
+    else if constexpr (ACT == TLXMI_ACT_RELU6) return fminf(fmaxf(x, 0.f), 6.f);
+    else if constexpr (ACT == TLXMI_ACT_LEAKY) return x >= 0.f ? x : x * p;
+    else if constexpr (ACT == TLXMI_ACT_HARDSWISH) return x * fminf(fmaxf(x + 3.f, 0.f), 6.f) * (1.f / 6.f);
+    else if constexpr (ACT == TLXMI_ACT_HARDSIGMOID) return fminf(fmaxf(x + 3.f, 0.f), 6.f) * (1.f / 6.f);
+    else if constexpr (ACT == TLXMI_ACT_GELU) return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));
+    else if constexpr (ACT == TLXMI_ACT_SIGMOID) return 1.f / (1.f + __expf(-x));
+    else if constexpr (ACT == TLXMI_ACT_SILU) return x / (1.f + __expf(-x));
+    else return x;
+}
+template <int V> struct IntTag { static constexpr int value = V; };
+// calls f(IntTag<act>{}) for the runtime activation code
+#define TLXMI_DISPATCH_ACT(act, f)                          \
+    switch (act) {                                          \
+        case TLXMI_ACT_RELU: f(::tlxmi::IntTag<TLXMI_ACT_RELU>{}); break;               \
+        case TLXMI_ACT_RELU6: f(::tlxmi::IntTag<TLXMI_ACT_RELU6>{}); break;             \
+        case TLXMI_ACT_LEAKY: f(::tlxmi::IntTag<TLXMI_ACT_LEAKY>{}); break;             \
+        case TLXMI_ACT_HARDSWISH: f(::tlxmi::IntTag<TLXMI_ACT_HARDSWISH>{}); break;     \
+        case TLXMI_ACT_HARDSIGMOID: f(::tlxmi::IntTag<TLXMI_ACT_HARDSIGMOID>{}); break; \
+        case TLXMI_ACT_GELU: f(::tlxmi::IntTag<TLXMI_ACT_GELU>{}); break;               \
+        case TLXMI_ACT_SIGMOID: f(::tlxmi::IntTag<TLXMI_ACT_SIGMOID>{}); break;         \
+        case TLXMI_ACT_SILU: f(::tlxmi::IntTag<TLXMI_ACT_SILU>{}); break;               \
+        default: f(::tlxmi::IntTag<TLXMI_ACT_NONE>{}); break;                           \
+    }
+
 // GELU for the fp16 throughput path, two elements at a time so that hipcc emits packed fp32 math
 // (v_pk_mul_f32 / v_pk_fma_f32): erf(z) ~ z * P(z^2) on |z| <= 3.5 (odd degree-17 minimax fit, max
 // |error| 1.1e-4), clamped to +-1 beyond (1 - erf(3.5) = 7e-7).  The resulting GELU error,

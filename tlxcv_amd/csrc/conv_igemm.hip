@@ -59,6 +59,8 @@ struct ConvArgs {
     unsigned y_bytes;           // extent of y when it may be written through a descriptor (0: plain stores)
     int store_policy;           // 0 plain, 16 sc1 (write-through, line dropped from L2), 2 nt
     int sb_off;                 // LDS byte offset of the block's scale/shift table (2 x BN floats)
+    int first_wave;             // blocks resident at launch (CUs x blocks/CU); they start out of phase, see below
+    unsigned stagger;           // 100 MHz ticks per phase step (0: no stagger)
 };
 
 __device__ __attribute__((aligned(16))) unsigned g_zero_page[4];  // source of padding / tail chunks
@@ -159,6 +161,16 @@ __global__ __launch_bounds__(WGM * 128) void conv_igemm_kernel(const ConvArgs a)
         tile_n = grp * a.gn + rem % gn_here;
     }
     const int bm0 = tile_m * BM, bn0 = tile_n * BN;
+
+    // Blocks of the first round all start together and, tiles being equal work, would all reach their
+    // store phase together: the whole chip then alternates between an MFMA phase with idle HBM and a write
+    // burst with idle MFMAs.  Delaying each first-round block by a pseudo-random eighth of a tile time
+    // spreads the store phases of later rounds uniformly (co-resident blocks compute while others store).
+    if (a.stagger && (int)blockIdx.x < a.first_wave) {
+        const unsigned ph = (blockIdx.x * 2654435761u) >> 29;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(), wait = (unsigned long long)ph * a.stagger;
+        while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+    }
 
     // Buffer descriptors: 32-bit per-lane byte offsets, and the hardware range check supplies the
     // zeros of padding taps / tail rows / tail K chunks (offset OOB) with no select on the data path.
@@ -387,100 +399,114 @@ __global__ __launch_bounds__(WGM * 128) void conv_igemm_kernel(const ConvArgs a)
         const bool full = a.vec_io && (ch0 + 8 <= a.Cout);
         if (ch0 < a.Cout) {
             const int row0 = t / CPR;
-            const char* rp = a.res ? a.res + ((size_t)(bm0 + row0) * a.res_ld + ch0) * ES : nullptr;
-            char* yp = a.y + ((size_t)(bm0 + row0) * a.y_ld + ch0) * ES;
             const size_t ystep = (size_t)RPP * a.y_ld * ES, rstep = (size_t)RPP * a.res_ld * ES;
+            // one specialised, fully unrolled row loop per activation (dispatch happens once, not per element)
+            auto rows = [&](auto act_tag) {
+                constexpr int ACT = decltype(act_tag)::value;
+                const char* rp = a.res ? a.res + ((size_t)(bm0 + row0) * a.res_ld + ch0) * ES : nullptr;
+                char* yp = a.y + ((size_t)(bm0 + row0) * a.y_ld + ch0) * ES;
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int row = row0 + it * RPP;
-                const int m = bm0 + row;
-                if (m >= a.M) break;
-                if (a.strided_n) {
-                    const int n = m / a.HoWo, p = m - n * a.HoWo;
-                    yp = a.y + ((size_t)n * a.y_nstride + (size_t)p * a.y_ld + ch0) * ES;
-                    if (a.res) rp = a.res + ((size_t)n * a.res_nstride + (size_t)p * a.res_ld + ch0) * ES;
-                }
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(Ct + row * BN + (((2 * chunk) ^ (row & 7)) << 2));
-                const f32x4 hi = *reinterpret_cast<const f32x4*>(Ct + row * BN + (((2 * chunk + 1) ^ (row & 7)) << 2));
-                float v[8];
-#pragma unroll
-                for (int bb = 0; bb < 4; ++bb) { v[bb] = lo[bb]; v[4 + bb] = hi[bb]; }
-                float rv[8];
-                if (a.res) {
-                    if constexpr (RESP) {
-                        if constexpr (ES == 2) {
-                            const half8v h = __builtin_bit_cast(half8v, rres[it][0]);
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) rv[e] = (float)h[e];
-                        } else {
-                            const f32x4 r0 = __builtin_bit_cast(f32x4, rres[it][0]);
-                            const f32x4 r1 = __builtin_bit_cast(f32x4, rres[it][ES / 2 - 1]);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) { rv[e] = r0[e]; rv[4 + e] = r1[e]; }
-                        }
-                    } else if (full) {
-                        load8<T>(rp, rv);
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e)
-                            rv[e] = (ch0 + e < a.Cout) ? (float)reinterpret_cast<const T*>(rp)[e] : 0.f;
+                for (int it = 0; it < NIT; ++it) {
+                    const int row = row0 + it * RPP;
+                    const int m = bm0 + row;
+                    if (m >= a.M) break;
+                    if (a.strided_n) {
+                        const int n = m / a.HoWo, p = m - n * a.HoWo;
+                        yp = a.y + ((size_t)n * a.y_nstride + (size_t)p * a.y_ld + ch0) * ES;
+                        if (a.res) rp = a.res + ((size_t)n * a.res_nstride + (size_t)p * a.res_ld + ch0) * ES;
                     }
-                    if (!res_after) {
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(Ct + row * BN + (((2 * chunk) ^ (row & 7)) << 2));
+                    const f32x4 hi = *reinterpret_cast<const f32x4*>(Ct + row * BN + (((2 * chunk + 1) ^ (row & 7)) << 2));
+                    float v[8];
+#pragma unroll
+                    for (int bb = 0; bb < 4; ++bb) { v[bb] = lo[bb]; v[4 + bb] = hi[bb]; }
+                    float rv[8];
+                    if (a.res) {
+                        if constexpr (RESP) {
+                            if constexpr (ES == 2) {
+                                const half8v h = __builtin_bit_cast(half8v, rres[it][0]);
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) rv[e] = (float)h[e];
+                            } else {
+                                const f32x4 r0 = __builtin_bit_cast(f32x4, rres[it][0]);
+                                const f32x4 r1 = __builtin_bit_cast(f32x4, rres[it][ES / 2 - 1]);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) { rv[e] = r0[e]; rv[4 + e] = r1[e]; }
+                            }
+                        } else if (full) {
+                            load8<T>(rp, rv);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e)
+                                rv[e] = (ch0 + e < a.Cout) ? (float)reinterpret_cast<const T*>(rp)[e] : 0.f;
+                        }
+                        if (!res_after) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] += rv[e];
+                        }
+                    }
+                    if constexpr (ACT == TLXMI_ACT_GELU && ES == 2) {
+#pragma unroll
+                        for (int e = 0; e < 8; e += 2) {
+                            const f32x2v g2 = gelu_fast2(f32x2v{v[e], v[e + 1]});
+                            v[e] = g2[0];
+                            v[e + 1] = g2[1];
+                        }
+                    } else if constexpr (ACT != TLXMI_ACT_NONE) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = apply_act_t<ACT>(v[e], a.act_param);
+                    }
+                    if (a.res && res_after) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] += rv[e];
                     }
-                }
-                if (a.act == TLXMI_ACT_RELU) {
+                    if (full && a.store_policy != 0 && !a.strided_n) {
+                        // outputs are never re-read by this launch: keep them from evicting the operand panels from L2
+                        const int yoff = (int)(yp - a.y);
+                        u32x4 pk[ES / 2];
+                        if constexpr (ES == 2) {
+                            half8v h;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-                } else if (sizeof(T) == 2 && a.act == TLXMI_ACT_GELU) {
+                            for (int e = 0; e < 8; ++e) h[e] = (half_t)v[e];
+                            pk[0] = __builtin_bit_cast(u32x4, h);
+                        } else {
+                            f32x4 f0, f1;
 #pragma unroll
-                    for (int e = 0; e < 8; e += 2) {
-                        const f32x2v g2 = gelu_fast2(f32x2v{v[e], v[e + 1]});
-                        v[e] = g2[0];
-                        v[e + 1] = g2[1];
-                    }
-                } else if (a.act != TLXMI_ACT_NONE) {
+                            for (int e = 0; e < 4; ++e) { f0[e] = v[e]; f1[e] = v[4 + e]; }
+                            pk[0] = __builtin_bit_cast(u32x4, f0);
+                            pk[ES / 2 - 1] = __builtin_bit_cast(u32x4, f1);
+                        }
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e], a.act, a.act_param);
-                }
-                if (a.res && res_after) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += rv[e];
-                }
-                if (full && a.store_policy != 0 && !a.strided_n) {
-                    // outputs are never re-read by this launch: keep them from evicting the operand panels from L2
-                    const int yoff = (int)(yp - a.y);
-                    u32x4 pk[ES / 2];
-                    if constexpr (ES == 2) {
-                        half8v h;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) h[e] = (half_t)v[e];
-                        pk[0] = __builtin_bit_cast(u32x4, h);
+                        for (int hh = 0; hh < ES / 2; ++hh) {
+                            if (a.store_policy == 16) buf_store16<16>(ysrd, pk[hh], yoff + 16 * hh);
+                            else buf_store16<2>(ysrd, pk[hh], yoff + 16 * hh);
+                        }
+                    } else if (full) {
+                        store8<T>(yp, v);
                     } else {
-                        f32x4 f0, f1;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { f0[e] = v[e]; f1[e] = v[4 + e]; }
-                        pk[0] = __builtin_bit_cast(u32x4, f0);
-                        pk[ES / 2 - 1] = __builtin_bit_cast(u32x4, f1);
+                        for (int e = 0; e < 8; ++e)
+                            if (ch0 + e < a.Cout) reinterpret_cast<T*>(yp)[e] = (T)v[e];
                     }
-#pragma unroll
-                    for (int hh = 0; hh < ES / 2; ++hh) {
-                        if (a.store_policy == 16) buf_store16<16>(ysrd, pk[hh], yoff + 16 * hh);
-                        else buf_store16<2>(ysrd, pk[hh], yoff + 16 * hh);
-                    }
-                } else if (full) {
-                    store8<T>(yp, v);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        if (ch0 + e < a.Cout) reinterpret_cast<T*>(yp)[e] = (T)v[e];
+                    yp += ystep;
+                    rp += rstep;
                 }
-                yp += ystep;
-                rp += rstep;
-            }
+            };
+            TLXMI_DISPATCH_ACT(a.act, rows)
         }
     }
+}
+
+static int g_num_cus = 0;
+static int num_cus() {
+    if (g_num_cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess)
+            g_num_cus = p.multiProcessorCount;
+        if (g_num_cus <= 0) g_num_cus = 256;
+    }
+    return g_num_cus;
 }
 
 // resident blocks per CU for a tile shape: LDS bound (160 KiB) and the register allocation hipcc
@@ -500,6 +526,16 @@ template <typename T, int BM, int BN, int WGM, int STAGES> static int launch(con
     b.sb_off = (int)lds;
     lds += 2 * BN * sizeof(float);
     const long grid = (long)b.mtiles * b.ntiles;
+    {
+        static const int pct = [] { const char* e = getenv("TLXMI_STAGGER"); return e ? atoi(e) : 0; }();
+        int per_cu = (int)((160 * 1024) / lds);
+        const int reg_cap = WGM == 4 ? 1 : (BM == 128 && BN == 128) ? 3 : ((BM == 64 && BN == 64) ? 8 : 5);
+        if (per_cu > reg_cap) per_cu = reg_cap;
+        b.first_wave = num_cus() * per_cu;
+        // tile time estimate: MFMA work of one tile at ~60% of a CU's share (5.1 TFLOP/s per CU at 2.1 GHz)
+        const double tile_ns = 2.0 * BM * BN * (double)a.kchunks * (16 / (int)sizeof(T)) / (5100.0 / per_cu);
+        b.stagger = (pct > 0 && grid > 2 * b.first_wave) ? (unsigned)(tile_ns / 10.0 / 8.0 * pct / 100.0) : 0u;
+    }
     const bool is1x1 = a.R == 1 && a.S == 1 && a.ph == 0 && a.pw == 0;
     const bool resp = a.res && a.vec_io && !a.strided_n;
     const void* fns[4] = {reinterpret_cast<const void*>(&conv_igemm_kernel<T, BM, BN, false, WGM, STAGES, false>),
@@ -521,19 +557,7 @@ template <typename T, int BM, int BN, int WGM, int STAGES> static int launch(con
     return TLXMI_OK;
 }
 
-static int g_num_cus = 0;
-static int num_cus() {
-    if (g_num_cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t p;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess)
-            g_num_cus = p.multiProcessorCount;
-        if (g_num_cus <= 0) g_num_cus = 256;
-    }
-    return g_num_cus;
-}
-
-template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st) {
+template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, bool allow_stream = true) {
     // Tile choice = max over the four shapes of (grid quantisation efficiency) x (shape efficiency):
     // a launch of B blocks on S = CUs x resident-blocks-per-CU slots runs ceil(B/S) rounds, so B/(rounds*S)
     // of the machine does useful work; bigger tiles re-use operands better (fewer LDS bytes per MFMA).
@@ -547,24 +571,38 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st) {
     // candidate 4 = 256x128 pixels x channels, 8 waves, 3-deep DMA ring (one block per CU): MFMA-bound layers
     // candidate 5 = gemm256.hip: 256x256, 8 waves, 4-deep ring of 64-byte K steps (pure GEMM rows only)
     // candidate 6 = gemm256.hip's 256x128 variant: 4 waves, 3-deep ring, two workgroups per CU
-    Cand cands[7] = {{128, 128, 1.00f}, {64, 128, 0.85f}, {128, 64, 0.85f}, {64, 64, 0.70f}, {256, 128, 0.90f},
-                     {256, 256, 1.12f}, {256, 128, 1.20f}};
+    // candidate 7 = gemm_pp.hip: 256x256, 8 waves in two antiphase groups, 128-byte K tiles
+    // candidate 8 = gemm_stream.hip: candidate 7 as a persistent kernel (one K-tile stream per CU)
+    constexpr int NC = 9;
+    Cand cands[NC] = {{128, 128, 1.00f}, {64, 128, 0.85f}, {128, 64, 0.85f}, {64, 64, 0.70f}, {256, 128, 0.90f},
+                      {256, 256, 1.12f}, {256, 128, 1.20f}, {256, 256, 1.40f}, {256, 256, 1.50f}};
     const bool gemm256_ok = a.R == 1 && a.S == 1 && a.ph == 0 && a.pw == 0 && a.sh == 1 && a.sw == 1 && !a.strided_n &&
                             a.vec_io && a.Cout % 8 == 0 && a.y_bytes != 0 && a.Cout >= 256 && a.ktiles >= 2 &&
                             (!a.res || (long long)a.M * a.res_ld * (long long)sizeof(T) < (1ll << 31));
-    if (!gemm256_ok) cands[5].eff = cands[6].eff = 0.f;
+    if (!gemm256_ok) cands[5].eff = cands[6].eff = cands[7].eff = cands[8].eff = 0.f;
     if (obi >= 0.0015 || a.ktiles < 4) cands[4].eff = 0.f;
-    if (obi >= 0.0015) cands[5].eff = cands[6].eff = 0.f;
+    if (obi >= 0.0015) cands[5].eff = cands[6].eff = cands[7].eff = cands[8].eff = 0.f;
+    if (!allow_stream) cands[7].eff = cands[8].eff = 0.f;
+    // the persistent kernel hides the plain epilogue but not the GELU arithmetic (measured: fc1 of ViT-B)
+    if (a.act == TLXMI_ACT_GELU) cands[8].eff = 0.f;
+    // One workgroup per CU: the last round of a 256x256 launch runs a whole tile time however few tiles it
+    // has.  When its rows fit ONE round of 128x128 tiles (a quarter of the work each, about half a tile time
+    // alone on a CU), the rows of the full rounds go to the 256x256 kernel and the remaining rows to a second
+    // launch with small tiles (tail split, below).  Measured on ViT-B (tools/ab_tiles.py): fc1 (60 tiles left
+    // of 2364) 293 -> 282 us; with 79 tiles left (proj, fc2) the second launch costs what it saves.
+    const long t256 = (long)((a.M + 255) / 256) * ((a.Cout + 255) / 256);
+    const int cus = num_cus();
+    const long full_rounds = t256 / cus;
+    const bool tail_split = gemm256_ok && full_rounds >= 1 && (t256 % cus) != 0 && 4 * (t256 % cus) <= cus;
     if (obi >= 0.012) { cands[0].eff = 0.65f; cands[1].eff = 0.80f; cands[2].eff = 0.85f; cands[3].eff = 1.00f; }
     else if (obi >= 0.0015) { cands[0].eff = 0.85f; cands[1].eff = 0.90f; cands[2].eff = 1.00f; cands[3].eff = 0.90f; }
-    const int cus = num_cus();
     int best = 0;
     float best_score = -1.f;
-    for (int i = 0; i < 7; ++i) {
+    for (int i = 0; i < NC; ++i) {
         const int bm = cands[i].bm, bn = cands[i].bn;
         if (cands[i].eff <= 0.f) continue;
         if (bn == 128 && a.Cout <= 64) continue;
-        size_t lds = i == 5 ? (size_t)128 * 1024 : i == 6 ? (size_t)72 * 1024 : (size_t)(a.ktiles > 1 ? (i == 4 ? 3 : 2) : 1) * (bm + bn) * 128;
+        size_t lds = (i == 5 || i >= 7) ? (size_t)128 * 1024 : i == 6 ? (size_t)72 * 1024 : (size_t)(a.ktiles > 1 ? (i == 4 ? 3 : 2) : 1) * (bm + bn) * 128;
         if (i < 5 && lds < (size_t)bm * bn * 4) lds = (size_t)bm * bn * 4;   // fp32 epilogue tile (gemm256 stores from registers)
         lds += 2 * bn * sizeof(float);                                        // scale / shift table
         int per_cu = (int)((160 * 1024) / lds);
@@ -574,22 +612,59 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st) {
         const long blocks = (long)((a.M + bm - 1) / bm) * ((a.Cout + bn - 1) / bn);
         const long slots = (long)cus * per_cu;
         const long rounds = (blocks + slots - 1) / slots;
-        const float quant = (float)blocks / (float)(rounds * slots);
+        float quant = (float)blocks / (float)(rounds * slots);
+        if (i >= 7 && tail_split) quant = (float)blocks / ((float)full_rounds * slots + 2.f * (blocks % slots));   // tail at ~half efficiency
         // wasted work inside partial tiles
         const float fill = ((float)a.M * a.Cout) / ((float)blocks * bm * bn);
         const float score = quant * fill * cands[i].eff;
         if (score > best_score) { best_score = score; best = i; }
     }
-    static const int forced = [] { const char* e = getenv("TLXMI_TILE"); return e ? atoi(e) : -1; }();  // tuning aid
-    if (forced >= 0 && forced < 7 && !(cands[forced].bn == 128 && a.Cout <= 64) && (forced < 5 || gemm256_ok)) best = forced;
+    // tuning aid: TLXMI_TILE=<candidate>; with TLXMI_TILE_DYNAMIC set the variable is re-read on every call
+    static const bool dyn = getenv("TLXMI_TILE_DYNAMIC") != nullptr;
+    static const int forced0 = [] { const char* e = getenv("TLXMI_TILE"); return e ? atoi(e) : -1; }();
+    int forced = forced0;
+    if (dyn) { const char* e = getenv("TLXMI_TILE"); forced = e ? atoi(e) : -1; }
+    if (forced >= 0 && forced < NC && !(cands[forced].bn == 128 && a.Cout <= 64) && (forced < 5 || gemm256_ok)) best = forced;
+    if (best >= 7 && tail_split) {
+        // rows of the full rounds (whole M tiles) -> this candidate; the rest -> best small-tile candidate
+        const int nt = (a.Cout + 255) / 256;
+        const int m_split = (int)((full_rounds * cus) / nt) * 256;
+        if (m_split > 0 && m_split < a.M) {
+            ConvArgs lo = a, hi = a;
+            lo.N = 1; lo.H = lo.Ho = 1; lo.W = lo.Wo = m_split; lo.HoWo = lo.M = m_split;
+            hi.N = 1; hi.H = hi.Ho = 1; hi.W = hi.Wo = a.M - m_split; hi.HoWo = hi.M = a.M - m_split;
+            hi.x = a.x + (size_t)m_split * a.x_ld * sizeof(T);
+            hi.y = a.y + (size_t)m_split * a.y_ld * sizeof(T);
+            if (a.res) hi.res = a.res + (size_t)m_split * a.res_ld * sizeof(T);
+            lo.x_bytes = (unsigned)((size_t)m_split * a.x_ld * sizeof(T));
+            hi.x_bytes = a.x_bytes - lo.x_bytes;
+            lo.y_bytes = (unsigned)((size_t)m_split * a.y_ld * sizeof(T));
+            hi.y_bytes = a.y_bytes - lo.y_bytes;
+            lo.y_nstride = hi.y_nstride = 0; lo.res_nstride = hi.res_nstride = 0;
+            const int rc = dispatch<T>(lo, st, true);     // t256 % cus == 0 there: no further split
+            if (rc != TLXMI_OK) return rc;
+            return dispatch<T>(hi, st, false);
+        }
+    }
     if (best >= 5) {
         Gemm256Args g;
+        g.debug = 0;
         g.x = a.x; g.w = a.w; g.y = a.y; g.scale = a.scale; g.shift = a.shift; g.res = a.res;
         g.M = a.M; g.Cout = a.Cout; g.x_ld = a.x_ld; g.y_ld = a.y_ld; g.res_ld = a.res_ld;
         g.kchunks = a.kchunks; g.ksteps = a.Kp_bytes / 64; g.Kp_bytes = a.Kp_bytes;
         g.act = a.act; g.act_param = a.act_param; g.flags = a.flags; g.mtiles = g.ntiles = 0;
         g.x_bytes = a.x_bytes; g.w_bytes = a.w_bytes; g.y_bytes = a.y_bytes;
         g.res_bytes = a.res ? (unsigned)((long long)a.M * a.res_ld * (long long)sizeof(T)) : 0u;
+        if (best == 8) {
+            g.ksteps = a.Kp_bytes / 128;
+            if (gemm_stream_ok(sizeof(T) == 2 ? TLXMI_F16 : TLXMI_F32, g))
+                return launch_gemm_stream(sizeof(T) == 2 ? TLXMI_F16 : TLXMI_F32, g, st, cus);
+            best = 7;
+        }
+        if (best == 7) {
+            g.ksteps = a.Kp_bytes / 128;
+            return launch_gemm_pp(sizeof(T) == 2 ? TLXMI_F16 : TLXMI_F32, g, st);
+        }
         return launch_gemm256(sizeof(T) == 2 ? TLXMI_F16 : TLXMI_F32, best - 5, g, st);
     }
     switch (best) {

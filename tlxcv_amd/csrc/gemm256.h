@@ -21,8 +21,14 @@ struct Gemm256Args {
     int mtiles, ntiles;
     int gn;        // N-tiles per column panel of the tile walk
     unsigned x_bytes, w_bytes, y_bytes, res_bytes;
+    int debug;     // tuning builds only
 };
 
 int launch_gemm256(int dtype, int variant, const Gemm256Args& a, hipStream_t st);
+// gemm_pp.hip: 256 x 256 tile, two wave groups in antiphase; a.ksteps = packed pitch / 128
+int launch_gemm_pp(int dtype, const Gemm256Args& a, hipStream_t st);
+// gemm_stream.hip: persistent version (one workgroup per CU walks its tiles as one K-tile stream)
+bool gemm_stream_ok(int dtype, const Gemm256Args& a);
+int launch_gemm_stream(int dtype, const Gemm256Args& a, hipStream_t st, int cus);
 
 }  // namespace tlxmi

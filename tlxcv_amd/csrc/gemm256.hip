@@ -161,6 +161,8 @@ __global__ __launch_bounds__(WGN * 128, 2) void gemm256_kernel(const Gemm256Args
     const int g = lane >> 4, px = lane & 15;
     const bool res_after = (a.flags & TLXMI_EPI_RES_AFTER_ACT) != 0;
     const __amdgpu_buffer_rsrc_t ysrd = srd(a.y, a.y_bytes), rsrd = srd(a.res ? a.res : a.y, a.res ? a.res_bytes : 0u);
+    auto epi = [&](auto act_tag) {
+    constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
     for (int cp = 0; cp < CI / 2; ++cp) {
         const int ch0 = bn0 + wave_n0 + 32 * cp + 8 * g;
@@ -207,19 +209,16 @@ __global__ __launch_bounds__(WGN * 128, 2) void gemm256_kernel(const Gemm256Args
                     for (int e = 0; e < 8; ++e) v[e] += rv[e];
                 }
             }
-            if (a.act == TLXMI_ACT_RELU) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-            } else if (sizeof(T) == 2 && a.act == TLXMI_ACT_GELU) {
+            if constexpr (ACT == TLXMI_ACT_GELU && sizeof(T) == 2) {
 #pragma unroll
                 for (int e = 0; e < 8; e += 2) {
                     const f32x2v g2 = gelu_fast2(f32x2v{v[e], v[e + 1]});
                     v[e] = g2[0];
                     v[e + 1] = g2[1];
                 }
-            } else if (a.act != TLXMI_ACT_NONE) {
+            } else if constexpr (ACT != TLXMI_ACT_NONE) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e], a.act, a.act_param);
+                for (int e = 0; e < 8; ++e) v[e] = apply_act_t<ACT>(v[e], a.act_param);
             }
             if (a.res && res_after) {
 #pragma unroll
@@ -240,6 +239,8 @@ __global__ __launch_bounds__(WGN * 128, 2) void gemm256_kernel(const Gemm256Args
             }
         }
     }
+    };
+    TLXMI_DISPATCH_ACT(a.act, epi)
 }
 
 // Called by conv_igemm.hip's dispatcher.  Preconditions (checked there): 1x1, stride 1, no padding, dense

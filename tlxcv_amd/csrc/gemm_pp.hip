@@ -1,0 +1,344 @@
+// 256 x 256 tile GEMM, two wave groups in antiphase ("ping-pong") — the MFMA-bound Linear layers of
+// ViT / Swin (qkv, proj, fc1, fc2; reference vision_transformer.py:81-87,112-123):
+//     Y[m][n] = act( (sum_k X[m][k] * Wp[n][k]) * scale[n] + shift[n] (+ R[m][n]) )
+// Same operands, filter packing and epilogue semantics as conv_igemm.hip's 1x1 path.
+//
+// 512 threads = 8 waves = 2 groups (wr = wid>>2) x 4 (wc = wid&3); one wave of each group per SIMD.
+// K advances in tiles of 128 B (64 halves / 32 floats).  A K tile in LDS is four 16-KiB "half tiles"
+// (X rows 0-127, X rows 128-255, W rows 0-127, W rows 128-255; 128-B rows, chunk c of row r in slot
+// c ^ ((r>>1)&7)); two K tiles are resident (128 KiB).  A wave owns the 2 x 2 quadrants
+//     X half h rows 64*wr .. +63   x   W half g rows 32*wc .. +31          (h, g in {0,1})
+// and one K tile is four phases, one quadrant (16 MFMAs) each:
+//     p0: read X0 + W0 frags (12 ds_read_b128), quadrant (0,0)     p1: read W1 (4), quadrant (0,1)
+//     p2: read X1 (8), quadrant (1,1)                              p3: no reads, quadrant (1,0)
+// Every phase is  [LDS reads | 2 LDS-DMA pieces | counted vmcnt] barrier [16 MFMAs] barrier, and group 1
+// runs one barrier behind group 0: while one wave of a SIMD issues its MFMAs the other one issues its reads
+// and DMA, so the MFMA pipe never waits for a load segment (a lock-step block alternates between the two).
+// DMA order per thread (one half tile = 2 pieces per phase):
+//     p0(kt): W1(kt+1)   p1(kt): X1(kt+1)   p2(kt): X0(kt+2)   p3(kt): W0(kt+2)
+// i.e. a half tile is re-filled >= 2 phases after its last read (the other group's reads are retired by
+// then) and lands >= 4 phases before its first read; vmcnt(8) after the issue in p0, p1 and p3 retires
+// exactly the half tiles the NEXT phase reads (the wait sits before a barrier every wave passes before
+// that read).  K tiles past the end are fetched at an out-of-range descriptor offset (zero fill, no
+// memory traffic), which keeps the counts uniform to the last phase.
+#include "common.h"
+#include "gemm256.h"
+#include <stdlib.h>
+
+namespace tlxmi {
+
+typedef __attribute__((address_space(3))) void* lds_ptr_pp_t;
+static __device__ __forceinline__ void pp_dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds, int voff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_pp_t)lds, 16, voff, 0, 0, 0);
+}
+static __device__ __forceinline__ __amdgpu_buffer_rsrc_t pp_srd(const char* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p), 0, bytes, 0x00020000);
+}
+static __device__ __forceinline__ u32x4 pp_load16(__amdgpu_buffer_rsrc_t rsrc, int voff) {
+    return __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
+}
+static __device__ __forceinline__ void pp_store16_nt(__amdgpu_buffer_rsrc_t rsrc, u32x4 v, int voff) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff, 0, 2);
+}
+
+template <typename T> struct MmaPP;
+template <> struct MmaPP<half_t> {
+    static __device__ __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8v, a), __builtin_bit_cast(half8v, b), c, 0, 0, 0);
+    }
+};
+template <> struct MmaPP<float> {
+    static __device__ __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
+        f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bf[j], c, 0, 0, 0);
+        return c;
+    }
+};
+
+template <typename T>
+__global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
+    constexpr int ES = (int)sizeof(T);
+    constexpr int BM = 256, BN = 256;
+    constexpr int HALF = 128 * 128;            // bytes of a half tile
+    constexpr int RX0 = 0, RX1 = HALF, RW0 = 2 * HALF, RW1 = 3 * HALF;   // regions of a K tile
+    constexpr int OOB = (int)0x80000000;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = wid >> 2, wc = wid & 3;
+
+    // block -> tile: blocks sharing an XCD (id % 8) take consecutive tiles, N tiles fastest
+    int tile_m, tile_n;
+    {
+        const int nb = a.mtiles * a.ntiles, id = blockIdx.x;
+        const int xcd = id & 7, qd = nb >> 3, rm = nb & 7;
+        const int L = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (id >> 3);
+        tile_m = L / a.ntiles;
+        tile_n = L - tile_m * a.ntiles;
+    }
+    const int bm0 = tile_m * BM, bn0 = tile_n * BN;
+    if (a.debug >> 8) {   // experiment: first-round blocks start out of phase
+        if ((int)blockIdx.x < 256) {
+            const unsigned ph = (blockIdx.x * 2654435761u) >> 29;
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(), wait = (unsigned long long)ph * (unsigned)(a.debug >> 8);
+            while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+        }
+    }
+    const __amdgpu_buffer_rsrc_t xsrd = pp_srd(a.x, a.x_bytes), wsrd = pp_srd(a.w, a.w_bytes);
+
+    // ---- loader: a piece = 8 rows x 128 B (one wave instruction); wave w fills pieces w and w+8 of a half
+    // tile; lane l -> row 8*piece + (l>>3), slot (l&7).  (row>>1)&7 = (4*(w&1) + (l>>4)) & 7 for both pieces.
+    const int lrow = lane >> 3;
+    const int lc = (lane & 7) ^ ((4 * (wid & 1) + (lane >> 4)) & 7);   // logical K chunk behind this lane's slot
+    int xo[2][2], wo[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m = bm0 + 128 * h + 8 * (wid + 8 * j) + lrow;
+            xo[h][j] = m < a.M ? m * a.x_ld * ES : OOB;
+            const int rho = 128 * h + 8 * (wid + 8 * j) + lrow;    // LDS row; holds channel perm(rho) (conv_igemm.hip)
+            const int n = (rho & ~31) | (((rho >> 2) & 3) << 3) | (((rho >> 4) & 1) << 2) | (rho & 3);
+            wo[h][j] = (bn0 + n) * a.Kp_bytes;
+        }
+    char* const lbase = smem + wid * 1024;
+    auto stage_x = [&](int h, int kt) {
+        const int q = kt * 8 + lc;
+        char* b = lbase + ((kt & 1) << 16) + (h ? RX1 : RX0);
+        const bool in = q < a.kchunks;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) pp_dma16(xsrd, b + j * 8192, in ? xo[h][j] + q * 16 : OOB);
+    };
+    auto stage_w = [&](int g, int kt) {
+        const int q = kt * 8 + lc;
+        char* b = lbase + ((kt & 1) << 16) + (g ? RW1 : RW0);
+        const bool in = q * 16 < a.Kp_bytes;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) pp_dma16(wsrd, b + j * 8192, in ? wo[g][j] + q * 16 : OOB);
+    };
+
+    // ---- fragment reads: lane (frow, fg) reads row frow of a 16-row sub-tile, 16-byte chunk 4*ksub + fg
+    const int frow = lane & 15, fg = lane >> 4;
+    const int foff = frow * 128 + ((fg ^ ((frow >> 1) & 7)) << 4);
+    const int xf0 = wr * 64 * 128 + foff, wf0 = wc * 32 * 128 + foff;   // ksub 1 = same offset ^ 64
+
+    f32x4 acc[4][8];   // [2*g + ci][4*h + pi]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    u32x4 xf[4][2], w0f[2][2], w1f[2][2];
+    auto read_x = [&](const char* kb, int region) {
+#pragma unroll
+        for (int pi = 0; pi < 4; ++pi) {
+            xf[pi][0] = *reinterpret_cast<const u32x4*>(kb + region + pi * 2048 + xf0);
+            xf[pi][1] = *reinterpret_cast<const u32x4*>(kb + region + pi * 2048 + (xf0 ^ 64));
+        }
+    };
+    auto read_w = [&](const char* kb, int region, u32x4 (&wf)[2][2]) {
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci) {
+            wf[ci][0] = *reinterpret_cast<const u32x4*>(kb + region + ci * 2048 + wf0);
+            wf[ci][1] = *reinterpret_cast<const u32x4*>(kb + region + ci * 2048 + (wf0 ^ 64));
+        }
+    };
+#define TLXMI_PP_MMA(H, G, WF)                                                                       \
+    {                                                                                                \
+        __builtin_amdgcn_s_setprio(1);                                                               \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                             \
+        _Pragma("unroll") for (int pi = 0; pi < 4; ++pi)                                             \
+        _Pragma("unroll") for (int ci = 0; ci < 2; ++ci)                                             \
+            acc[2 * G + ci][4 * H + pi] = MmaPP<T>::run(WF[ci][ks], xf[pi][ks], acc[2 * G + ci][4 * H + pi]); \
+        __builtin_amdgcn_s_setprio(0);                                                               \
+    }
+#define TLXMI_PP_SYNC()                       \
+    __builtin_amdgcn_sched_barrier(0);        \
+    __builtin_amdgcn_s_barrier();             \
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- prologue: X0 W0 W1 X1 of K tile 0, X0 W0 of K tile 1; scale / shift table behind the ring
+    float sc_t = 1.f, sh_t = 0.f;
+    if (t < BN) {
+        const int ch = bn0 + t < a.Cout ? bn0 + t : a.Cout - 1;
+        if (a.scale) sc_t = a.scale[ch];
+        if (a.shift) sh_t = a.shift[ch];
+    }
+    __builtin_amdgcn_sched_barrier(0);   // these two loads are older than every DMA: their wait leaves the DMAs in flight
+    stage_x(0, 0);
+    stage_w(0, 0);
+    stage_w(1, 0);
+    stage_x(1, 0);
+    stage_x(0, 1);
+    stage_w(0, 1);
+    float* sbuf = reinterpret_cast<float*>(smem + 2 * 4 * HALF);
+    if (t < BN) {
+        sbuf[t] = sc_t;
+        sbuf[BN + t] = sh_t;
+    }
+    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");   // X0(0), W0(0) landed (this wave's pieces)
+    TLXMI_PP_SYNC();
+    if (wr == 1) { TLXMI_PP_SYNC(); }   // group 1 runs one barrier behind
+
+    const int ks = a.ksteps;
+    for (int kt = 0; kt < ks; ++kt) {
+        const char* kb = smem + ((kt & 1) << 16);
+        // p0
+        read_x(kb, RX0);
+        read_w(kb, RW0, w0f);
+        stage_w(1, kt + 1);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // W1(kt)
+        TLXMI_PP_SYNC();
+        TLXMI_PP_MMA(0, 0, w0f);
+        TLXMI_PP_SYNC();
+        // p1
+        read_w(kb, RW1, w1f);
+        stage_x(1, kt + 1);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // X1(kt)
+        TLXMI_PP_SYNC();
+        TLXMI_PP_MMA(0, 1, w1f);
+        TLXMI_PP_SYNC();
+        // p2
+        read_x(kb, RX1);
+        stage_x(0, kt + 2);
+        TLXMI_PP_SYNC();
+        TLXMI_PP_MMA(1, 1, w1f);
+        TLXMI_PP_SYNC();
+        // p3
+        stage_w(0, kt + 2);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // X0(kt+1), W0(kt+1)
+        TLXMI_PP_SYNC();
+        TLXMI_PP_MMA(1, 0, w0f);
+        TLXMI_PP_SYNC();
+    }
+    if (wr == 0) { TLXMI_PP_SYNC(); }   // barrier counts match again
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero-fill DMAs of the tail
+#undef TLXMI_PP_MMA
+#undef TLXMI_PP_SYNC
+
+    if (a.debug & 1) {   // ablation: no epilogue
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(acc[i][j]));
+        return;
+    }
+    // ---- epilogue from registers: lane (fg, px) owns channels 128g + 32wc + 8fg .. +7 of pixel row
+    // 128h + 64wr + 16pi + px (the filter rows are permuted so that two MFMA sub-tiles give 8 neighbours)
+    const int px = lane & 15;
+    const bool res_after = (a.flags & TLXMI_EPI_RES_AFTER_ACT) != 0;
+    const __amdgpu_buffer_rsrc_t ysrd = pp_srd(a.y, a.y_bytes), rsrd = pp_srd(a.res ? a.res : a.y, a.res ? a.res_bytes : 0u);
+    auto epi = [&](auto act_tag) {
+        constexpr int ACT = decltype(act_tag)::value;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int col = 128 * g + 32 * wc + 8 * fg;
+            const int ch0 = bn0 + col;
+            if (ch0 >= a.Cout) continue;      // Cout is a multiple of 8 on this path
+            float sc[8], sf[8];
+            {
+                const f32x4 s0 = *reinterpret_cast<const f32x4*>(sbuf + col), s1 = *reinterpret_cast<const f32x4*>(sbuf + col + 4);
+                const f32x4 h0 = *reinterpret_cast<const f32x4*>(sbuf + BN + col), h1 = *reinterpret_cast<const f32x4*>(sbuf + BN + col + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { sc[e] = s0[e]; sc[4 + e] = s1[e]; sf[e] = h0[e]; sf[4 + e] = h1[e]; }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                u32x4 rr[4][ES / 2];
+                if (a.res) {
+#pragma unroll
+                    for (int pi = 0; pi < 4; ++pi) {
+                        const int m = bm0 + 128 * h + 64 * wr + pi * 16 + px;
+                        const int ro = m < a.M ? (m * a.res_ld + ch0) * ES : OOB;
+#pragma unroll
+                        for (int hh = 0; hh < ES / 2; ++hh) rr[pi][hh] = pp_load16(rsrd, ro + 16 * hh);
+                    }
+                }
+#pragma unroll
+                for (int pi = 0; pi < 4; ++pi) {
+                    const int m = bm0 + 128 * h + 64 * wr + pi * 16 + px;
+                    float v[8], rv[8];
+#pragma unroll
+                    for (int bb = 0; bb < 4; ++bb) {
+                        v[bb] = acc[2 * g][4 * h + pi][bb] * sc[bb] + sf[bb];
+                        v[4 + bb] = acc[2 * g + 1][4 * h + pi][bb] * sc[4 + bb] + sf[4 + bb];
+                    }
+                    if (a.res) {
+                        if constexpr (ES == 2) {
+                            const half8v hv = __builtin_bit_cast(half8v, rr[pi][0]);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) rv[e] = (float)hv[e];
+                        } else {
+                            const f32x4 r0 = __builtin_bit_cast(f32x4, rr[pi][0]), r1 = __builtin_bit_cast(f32x4, rr[pi][ES / 2 - 1]);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { rv[e] = r0[e]; rv[4 + e] = r1[e]; }
+                        }
+                        if (!res_after) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] += rv[e];
+                        }
+                    }
+                    if constexpr (ACT == TLXMI_ACT_GELU && sizeof(T) == 2) {
+#pragma unroll
+                        for (int e = 0; e < 8; e += 2) {
+                            const f32x2v g2 = gelu_fast2(f32x2v{v[e], v[e + 1]});
+                            v[e] = g2[0];
+                            v[e + 1] = g2[1];
+                        }
+                    } else if constexpr (ACT != TLXMI_ACT_NONE) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = apply_act_t<ACT>(v[e], a.act_param);
+                    }
+                    if (a.res && res_after) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += rv[e];
+                    }
+                    const int yo = m < a.M ? (m * a.y_ld + ch0) * ES : OOB;   // OOB stores are dropped by the range check
+                    if constexpr (ES == 2) {
+                        half8v hv;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) hv[e] = (half_t)v[e];
+                        pp_store16_nt(ysrd, __builtin_bit_cast(u32x4, hv), yo);
+                    } else {
+                        f32x4 f0, f1;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { f0[e] = v[e]; f1[e] = v[4 + e]; }
+                        pp_store16_nt(ysrd, __builtin_bit_cast(u32x4, f0), yo);
+                        pp_store16_nt(ysrd, __builtin_bit_cast(u32x4, f1), yo + 16);
+                    }
+                }
+            }
+        }
+    };
+    TLXMI_DISPATCH_ACT(a.act, epi)
+}
+
+// Preconditions as launch_gemm256 (checked by conv_igemm.hip's dispatcher); a.ksteps = packed pitch / 128.
+template <typename T> static int launch_pp_t(const Gemm256Args& a0, hipStream_t st, bool& raised) {
+    Gemm256Args a = a0;
+    { static const int dbg = [] { const char* e = getenv("TLXMI_DEBUG"); return e ? atoi(e) : 0; }(); a.debug = dbg; }
+    a.mtiles = (a.M + 255) / 256;
+    a.ntiles = (a.Cout + 255) / 256;
+    a.gn = a.ntiles;
+    const size_t lds = (size_t)8 * 128 * 128 + 2 * 256 * sizeof(float);
+    const void* fn = reinterpret_cast<const void*>(&gemm_pp_kernel<T>);
+    if (!raised) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(TLXMI_ERR_LAUNCH, "gemm_pp: cannot raise LDS limit: %s", hipGetErrorString(e));
+        raised = true;
+    }
+    void* args[] = {&a};
+    hipError_t e = hipLaunchKernel(fn, dim3((unsigned)(a.mtiles * a.ntiles)), dim3(512), args, lds, st);
+    if (e != hipSuccess) return fail(TLXMI_ERR_LAUNCH, "gemm_pp: HIP launch failed: %s", hipGetErrorString(e));
+    return TLXMI_OK;
+}
+
+int launch_gemm_pp(int dtype, const Gemm256Args& a, hipStream_t st) {
+    static bool raised[2] = {false, false};
+    if (dtype == TLXMI_F16) return launch_pp_t<half_t>(a, st, raised[0]);
+    return launch_pp_t<float>(a, st, raised[1]);
+}
+
+}  // namespace tlxmi

@@ -1,0 +1,468 @@
+// Persistent 256 x 256 tile GEMM: gemm_pp.hip's two-group antiphase K loop run as ONE continuous stream
+// of K tiles over all the output tiles of a workgroup (one workgroup per CU), for the Linear layers of
+// ViT / Swin (reference vision_transformer.py:81-87,112-123; swin_transformer.py:202-226,258-300):
+//     Y[m][n] = act( (sum_k X[m][k] * Wp[n][k]) * scale[n] + shift[n] + R[m][n] )
+//
+// Why: with K = 768 an output tile is only 12 K tiles (~20 us of MFMA work) and the per-tile costs of a
+// one-tile-per-workgroup launch — store drain before the workgroup may retire, workgroup launch, first DMA
+// latency, epilogue — were 35-40 % of the time (measured: tools/conv_micro.py qkv, TLXMI_DEBUG=1).  Here
+//   * the LDS-DMA stream never stops: the loads of the next output tile's first two K tiles are issued
+//     during the last two K tiles of the current one (cursor A = stream position + 1 for the W1/X1 half
+//     tiles, cursor B = position + 2 for X0/W0, each with its own row offsets);
+//   * the epilogue is cut into the four quadrants of the wave tile and each quarter runs in the load
+//     segment right after the phase that finished it (E00 in p1 of the last K tile, E01 in p2, E11 in p3,
+//     E10 in p0 of the next tile's first K tile), i.e. under the other wave group's MFMAs;
+//   * nothing waits for a store: gfx950 has one in-order counter for loads, stores and LDS-DMA, so each
+//     counted wait allows for the stores issued after its target (vmcnt up to 8 + 4*S + 2), and every
+//     store batch has >= 4 phases before a wait depends on it;
+//   * the residual is not an epilogue input: it is added into the accumulators in the middle of the tile
+//     (half a quadrant per K tile, K tiles 1..9), loads issued one K tile ahead — a load in the epilogue
+//     would have to wait for the stores before it (same counter);
+//   * scale / shift of the next tile arrive by LDS-DMA in a double-buffered table (a null array reads a
+//     constant block), accumulators are not zeroed (the first MFMA of a tile takes C = 0).
+// Layout of a K tile in LDS, wave->quadrant map, fragment reads, channel permutation: gemm_pp.hip.
+//
+// In-order VMEM sequence of one wave around a tile boundary (L = last K tile of a tile; D = 2 DMA pieces,
+// S = the stores of a quadrant (8 for fp16, 16 for fp32), T = 2 table pieces), and the counted waits:
+//     p0(L)   D W1(L+1)                        wait W1(L)          : 8
+//     p1(L)   D X1(L+1), S00                   wait X1(L)          : 8 + S
+//     p2(L)   D X0(L+2), T, S01
+//     p3(L)   D W0(L+2), S11                   wait X0,W0(L+1)     : 8 + 3S + T
+//     p0(L+1) S10, D W1(L+2)                   wait W1(L+1)        : 8 + 4S + T
+//     p1(L+1) D X1(L+2)                        wait X1(L+1)        : 8 + 4S + T
+//     p2(L+1) D X0(L+3)
+//     p3(L+1) D W0(L+3)                        wait X0,W0(L+2)     : 8 + 2S
+//     p0(L+2) ...                              wait W1(L+2)        : 8      (steady state)
+// (a count = number of operations issued after the target; counts above 63 are clamped, which only waits
+// for more).  A K tile that issues residual loads (R = 2 for fp16) at p0 uses 8 + R in its waits.
+#include "common.h"
+#include "gemm256.h"
+#include <stdlib.h>
+
+namespace tlxmi {
+
+typedef __attribute__((address_space(3))) void* lds_ptr_gs_t;
+static __device__ __forceinline__ void gs_dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds, int voff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_gs_t)lds, 16, voff, 0, 0, 0);
+}
+static __device__ __forceinline__ __amdgpu_buffer_rsrc_t gs_srd(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+static __device__ __forceinline__ u32x4 gs_load16(__amdgpu_buffer_rsrc_t rsrc, int voff) {
+    return __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
+}
+static __device__ __forceinline__ void gs_store16_nt(__amdgpu_buffer_rsrc_t rsrc, u32x4 v, int voff) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff, 0, 2);
+}
+static __device__ __forceinline__ void gs_store16_wb(__amdgpu_buffer_rsrc_t rsrc, u32x4 v, int voff) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff, 0, 0);
+}
+
+__device__ __attribute__((aligned(16))) float g_ones4[4] = {1.f, 1.f, 1.f, 1.f};
+
+template <typename T> struct MmaGS;
+template <> struct MmaGS<half_t> {
+    static __device__ __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8v, a), __builtin_bit_cast(half8v, b), c, 0, 0, 0);
+    }
+};
+template <> struct MmaGS<float> {
+    static __device__ __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
+        f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bf[j], c, 0, 0, 0);
+        return c;
+    }
+};
+
+enum { GS_K0_FIRST = 0, GS_K0_AFTER, GS_INTERIOR, GS_LAST, GS_R0, GS_RC = GS_R0 + 8 };   // GS_R0 + r: residual step r
+
+template <int N> __device__ __forceinline__ void gs_vmcnt() {
+    constexpr int C = N > 63 ? 63 : N;
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C) : "memory");
+}
+
+// ACT: TLXMI_ACT_NONE / RELU / GELU (other activations, and exact-erf GELU in fp32, stay on gemm_pp.hip).
+// RES: a.res is added (before the activation; a.scale must be null) — needs >= 11 K tiles.
+template <typename T, int ACT, bool RES>
+__global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
+    constexpr int ES = (int)sizeof(T);
+    constexpr int HALF = 128 * 128;            // bytes of a half tile
+    constexpr int RX0 = 0, RX1 = HALF, RW0 = 2 * HALF, RW1 = 3 * HALF;   // regions of a K tile
+    constexpr int TABLE = 8 * HALF;            // two tables of 8 x 256 B behind the two K tiles
+    constexpr int OOB = (int)0x80000000;
+    constexpr int S = ES == 2 ? 8 : 16, R = ES, TT = 2;   // R: loads of one residual step (2 pixel rows x 8 channels per lane)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = wid >> 2, wc = wid & 3;
+    const int nb = a.mtiles * a.ntiles;
+    const int n_mine = ((int)blockIdx.x < nb) ? (nb - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+
+    // i-th tile of this workgroup -> origin.  Virtual block id = blockIdx + i*grid (grid is a multiple of 8,
+    // so the id keeps its XCD); ids sharing an XCD walk consecutive tiles, N tiles fastest.
+    auto tile_origin = [&](int i, int& bm0, int& bn0) -> bool {
+        if (i >= n_mine) return false;
+        const int id = (int)blockIdx.x + i * (int)gridDim.x;
+        const int xcd = id & 7, qd = nb >> 3, rm = nb & 7;
+        const int L = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (id >> 3);
+        const int tm = L / a.ntiles;
+        bm0 = tm * 256;
+        bn0 = (L - tm * a.ntiles) * 256;
+        return true;
+    };
+
+    const __amdgpu_buffer_rsrc_t xsrd = gs_srd(a.x, a.x_bytes), wsrd = gs_srd(a.w, a.w_bytes);
+    const __amdgpu_buffer_rsrc_t ysrd = gs_srd(a.y, a.y_bytes);
+    const __amdgpu_buffer_rsrc_t rsrd = gs_srd(a.res ? a.res : a.y, a.res ? a.res_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t hsrd = gs_srd(a.shift, a.shift ? (unsigned)a.Cout * 4u : 0u);   // null: zero fill
+    const __amdgpu_buffer_rsrc_t ssrd = a.scale ? gs_srd(a.scale, (unsigned)a.Cout * 4u) : gs_srd(g_ones4, 16u);
+
+    // ---- loader (gemm_pp.hip): piece = 8 rows x 128 B; wave w fills pieces w, w+8 of a half tile
+    const int lrow = lane >> 3;
+    const int lc = (lane & 7) ^ ((4 * (wid & 1) + (lane >> 4)) & 7);
+    // Row offsets of cursor A (halves X1, W1) and cursor B (X0, W0) for piece `wid`; piece `wid + 8` is 64 rows
+    // further (a wave-uniform stride).  Rows past M and filter rows past the padded Cout fail the
+    // descriptors' range checks (zero fill); a cursor past the last tile is out of range altogether.
+    int xa, wa, xb, wb;
+    const int x64 = 64 * a.x_ld * ES, w64 = 64 * a.Kp_bytes;
+    auto set_rows = [&](int i, int half, int& xo, int& wo) {
+        int bm0 = 0, bn0 = 0;
+        const bool ok = tile_origin(i, bm0, bn0);
+        const int row = 128 * half + 8 * wid + lrow;
+        const int n = (row & ~31) | (((row >> 2) & 3) << 3) | (((row >> 4) & 1) << 2) | (row & 3);
+        xo = ok ? (bm0 + row) * a.x_ld * ES : OOB;
+        wo = ok ? (bn0 + n) * a.Kp_bytes : OOB;
+    };
+    char* const lbase = smem + wid * 1024;
+    // (an offset that is out of range stays out of range after the small additions: x_bytes, w_bytes < 2^31)
+    auto dma_x = [&](int region, int par, int xo, int kt) {
+        const int q = kt * 8 + lc;
+        const int off = (q < a.kchunks && xo >= 0) ? xo + q * 16 : OOB;
+        char* b = lbase + (par << 16) + region;
+        gs_dma16(xsrd, b, off);
+        gs_dma16(xsrd, b + 8192, off >= 0 ? off + x64 : OOB);
+    };
+    auto dma_w = [&](int region, int par, int wo, int kt) {
+        const int q = kt * 8 + lc;
+        const int off = (q * 16 < a.Kp_bytes && wo >= 0) ? wo + q * 16 : OOB;
+        char* b = lbase + (par << 16) + region;
+        gs_dma16(wsrd, b, off);
+        gs_dma16(wsrd, b + 8192, off >= 0 ? off + w64 : OOB);
+    };
+    // scale / shift table of tile i -> table (i & 1): wave w brings channels 32w..32w+31, [shift 32][scale 32]
+    auto dma_table = [&](int i) {
+        int bm0 = 0, bn0 = 0;
+        const bool ok = tile_origin(i, bm0, bn0);
+        char* dst = smem + TABLE + (i & 1) * 2048 + wid * 256;
+        if (lane < 8) {
+            const int off = ok ? (bn0 + 32 * wid + 4 * lane) * 4 : OOB;
+            gs_dma16(hsrd, dst, off);
+            gs_dma16(ssrd, dst + 128, a.scale ? off : 0);
+        }
+    };
+
+    // ---- fragment reads (gemm_pp.hip)
+    const int frow = lane & 15, fg = lane >> 4;
+    const int foff = frow * 128 + ((fg ^ ((frow >> 1) & 7)) << 4);
+    const int xf0 = wr * 64 * 128 + foff, wf0 = wc * 32 * 128 + foff;
+
+    f32x4 acc[4][8];   // [2*g + ci][4*h + pi]
+    u32x4 xf[4][2], w0f[2][2], w1f[2][2];
+    u32x4 rr[R];       // residual step in flight (RES)
+    auto read_x = [&](const char* kb, int region) {
+#pragma unroll
+        for (int pi = 0; pi < 4; ++pi) {
+            xf[pi][0] = *reinterpret_cast<const u32x4*>(kb + region + pi * 2048 + xf0);
+            xf[pi][1] = *reinterpret_cast<const u32x4*>(kb + region + pi * 2048 + (xf0 ^ 64));
+        }
+    };
+    auto read_w = [&](const char* kb, int region, u32x4 (&wf)[2][2]) {
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci) {
+            wf[ci][0] = *reinterpret_cast<const u32x4*>(kb + region + ci * 2048 + wf0);
+            wf[ci][1] = *reinterpret_cast<const u32x4*>(kb + region + ci * 2048 + (wf0 ^ 64));
+        }
+    };
+
+    // ---- quadrant epilogue: lane (fg, px) owns channels 128g + 32wc + 8fg .. +7 of pixel rows
+    // 128h + 64wr + 16pi + px.  Always S stores (suppressed ones go to an out-of-range offset).
+    auto epi = [&](auto h_tag, auto g_tag, int bm0, int bn0, int tpar, bool live) {
+        constexpr int H = decltype(h_tag)::value, G = decltype(g_tag)::value;
+        int px = frow;
+        asm volatile("" : "+v"(px));   // offsets are recomputed here, not kept live across the K loop
+        const int col = 128 * G + 32 * wc + 8 * fg;
+        const int ch0 = bn0 + col;
+        const bool chok = live && ch0 < a.Cout && !(a.debug & 2);      // Cout is a multiple of 8 on this path
+        if (a.debug & 1) {   // ablation: stores without the arithmetic
+#pragma unroll
+            for (int pi = 0; pi < 4 * (ES / 2); ++pi) gs_store16_nt(ysrd, __builtin_bit_cast(u32x4, acc[2 * G][4 * H + (pi & 3)]), OOB);
+            return;
+        }
+        const float* tb = reinterpret_cast<const float*>(smem + TABLE + tpar * 2048 + (4 * G + wc) * 256) + 8 * fg;
+        const f32x4 h0 = *reinterpret_cast<const f32x4*>(tb), h1 = *reinterpret_cast<const f32x4*>(tb + 4);
+        f32x4 s0 = f32x4{1.f, 1.f, 1.f, 1.f}, s1 = s0;
+        if constexpr (!RES) {   // a residual implies scale == nullptr
+            s0 = *reinterpret_cast<const f32x4*>(tb + 32);
+            s1 = *reinterpret_cast<const f32x4*>(tb + 36);
+        }
+#pragma unroll
+        for (int pi = 0; pi < 4; ++pi) {
+            const int m = bm0 + 128 * H + 64 * wr + 16 * pi + px;
+            float v[8];
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+                if constexpr (RES) {
+                    v[bb] = acc[2 * G][4 * H + pi][bb] + h0[bb];
+                    v[4 + bb] = acc[2 * G + 1][4 * H + pi][bb] + h1[bb];
+                } else {
+                    v[bb] = acc[2 * G][4 * H + pi][bb] * s0[bb] + h0[bb];
+                    v[4 + bb] = acc[2 * G + 1][4 * H + pi][bb] * s1[bb] + h1[bb];
+                }
+            }
+            if constexpr (ACT == TLXMI_ACT_GELU && ES == 2) {
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    const f32x2v g2 = gelu_fast2(f32x2v{v[e], v[e + 1]});
+                    v[e] = g2[0];
+                    v[e + 1] = g2[1];
+                }
+            } else if constexpr (ACT != TLXMI_ACT_NONE) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = apply_act_t<ACT>(v[e], a.act_param);
+            }
+            const int yo = (chok && m < a.M) ? (m * a.y_ld + ch0) * ES : OOB;   // out-of-range stores are dropped
+            if constexpr (ES == 2) {
+                half8v hv;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) hv[e] = (half_t)v[e];
+                if (a.debug & 4) gs_store16_wb(ysrd, __builtin_bit_cast(u32x4, hv), yo);
+                else gs_store16_nt(ysrd, __builtin_bit_cast(u32x4, hv), yo);
+            } else {
+                f32x4 f0, f1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { f0[e] = v[e]; f1[e] = v[4 + e]; }
+                gs_store16_nt(ysrd, __builtin_bit_cast(u32x4, f0), yo);
+                gs_store16_nt(ysrd, __builtin_bit_cast(u32x4, f1), yo + 16);
+            }
+        }
+    };
+    // Residual step r = 0..7 covers quadrant (r>>1) in the phase order (0,0) (0,1) (1,1) (1,0), pixel sub-tiles
+    // 2*(r&1), 2*(r&1)+1: R loads now, added into the accumulators one K tile later.
+    auto res_load = [&](auto r_tag, int bm0, int bn0) {
+        constexpr int RS = decltype(r_tag)::value, Q = RS >> 1, H = (Q >> 1), G = (Q == 1 || Q == 2) ? 1 : 0, P0 = 2 * (RS & 1);
+        int px = frow;
+        asm volatile("" : "+v"(px));
+        const int ch0 = bn0 + 128 * G + 32 * wc + 8 * fg;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int m = bm0 + 128 * H + 64 * wr + 16 * (P0 + p) + px;
+            const int ro = (m < a.M && ch0 < a.Cout) ? (m * a.res_ld + ch0) * ES : OOB;
+#pragma unroll
+            for (int hh = 0; hh < ES / 2; ++hh) rr[p * (ES / 2) + hh] = gs_load16(rsrd, ro + 16 * hh);
+        }
+    };
+    auto res_add = [&](auto r_tag) {
+        constexpr int RS = decltype(r_tag)::value, Q = RS >> 1, H = (Q >> 1), G = (Q == 1 || Q == 2) ? 1 : 0, P0 = 2 * (RS & 1);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            float rv[8];
+            if constexpr (ES == 2) {
+                const half8v hv = __builtin_bit_cast(half8v, rr[p]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) rv[e] = (float)hv[e];
+            } else {
+                const f32x4 r0 = __builtin_bit_cast(f32x4, rr[2 * p]), r1 = __builtin_bit_cast(f32x4, rr[2 * p + (ES / 2 - 1)]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { rv[e] = r0[e]; rv[4 + e] = r1[e]; }
+            }
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+                acc[2 * G][4 * H + P0 + p][bb] += rv[bb];
+                acc[2 * G + 1][4 * H + P0 + p][bb] += rv[4 + bb];
+            }
+        }
+    };
+
+#define GS_SYNC()                          \
+    __builtin_amdgcn_sched_barrier(0);     \
+    __builtin_amdgcn_s_barrier();          \
+    __builtin_amdgcn_sched_barrier(0);
+// one quadrant x one K tile; ZERO: the accumulators start from 0 (first K tile of an output tile)
+#define GS_MMA(H, G, WF, ZERO)                                                                              \
+    {                                                                                                       \
+        __builtin_amdgcn_s_setprio(1);                                                                      \
+        _Pragma("unroll") for (int pi = 0; pi < 4; ++pi)                                                    \
+        _Pragma("unroll") for (int ci = 0; ci < 2; ++ci)                                                    \
+            acc[2 * G + ci][4 * H + pi] = MmaGS<T>::run(WF[ci][0], xf[pi][0],                               \
+                                                        (ZERO) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[2 * G + ci][4 * H + pi]); \
+        _Pragma("unroll") for (int pi = 0; pi < 4; ++pi)                                                    \
+        _Pragma("unroll") for (int ci = 0; ci < 2; ++ci)                                                    \
+            acc[2 * G + ci][4 * H + pi] = MmaGS<T>::run(WF[ci][1], xf[pi][1], acc[2 * G + ci][4 * H + pi]); \
+        __builtin_amdgcn_s_setprio(0);                                                                      \
+    }
+
+    const int ks = a.ksteps;
+    // stream state: compute side (tile ordinal ci_, buffer parity cpar) and the two DMA cursors
+    int cpar = 0;
+    int ia = 0, kta = 1, para = 1;    // cursor A: next (W1, X1) to stage = stream position 1
+    int ib = 0, ktb = 2, parb = 0;    // cursor B: next (X0, W0) to stage = stream position 2
+    auto adv_a = [&]() {
+        para ^= 1;
+        if (++kta == ks) { kta = 0; ++ia; set_rows(ia, 1, xa, wa); }
+    };
+    auto adv_b = [&]() {
+        parb ^= 1;
+        if (++ktb >= ks) { ktb -= ks; ++ib; set_rows(ib, 0, xb, wb); }
+    };
+
+    // ---- prologue: table of tile 0; X0 W0 W1 X1 of K tile 0; X0 W0 of K tile 1 (ks >= 2)
+    set_rows(0, 1, xa, wa);
+    set_rows(0, 0, xb, wb);
+    dma_table(0);
+    dma_x(RX0, 0, xb, 0);
+    dma_w(RW0, 0, wb, 0);
+    dma_w(RW1, 0, wa, 0);
+    dma_x(RX1, 0, xa, 0);
+    dma_x(RX0, 1, xb, 1);
+    dma_w(RW0, 1, wb, 1);
+    if (ks == 2) { ktb = 0; ib = 1; set_rows(1, 0, xb, wb); }
+    gs_vmcnt<8>();
+    GS_SYNC();
+    if (wr == 1) { GS_SYNC(); }   // group 1 runs one barrier behind
+
+    int bm0 = 0, bn0 = 0, pbm0 = 0, pbn0 = 0;
+
+    auto ktile = [&](auto mode_tag, int i) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        constexpr bool K0 = MODE == GS_K0_FIRST || MODE == GS_K0_AFTER;
+        constexpr bool RI = MODE >= GS_R0 && MODE < GS_RC;   // issues residual loads
+        constexpr int RQ = RI ? R : 0;
+        const char* kb = smem + (cpar << 16);
+        // ---- p0: quadrant (0,0)
+        read_x(kb, RX0);
+        read_w(kb, RW0, w0f);
+        if constexpr (MODE == GS_K0_AFTER) epi(IntTag<1>{}, IntTag<0>{}, pbm0, pbn0, (i - 1) & 1, true);
+        if constexpr (MODE > GS_R0 && MODE <= GS_RC) res_add(IntTag<MODE - GS_R0 - 1>{});
+        if constexpr (RI) {
+            __builtin_amdgcn_sched_barrier(0);   // the new loads re-use the registers just consumed
+            res_load(IntTag<MODE - GS_R0>{}, bm0, bn0);
+        }
+        dma_w(RW1, para, wa, kta);
+        gs_vmcnt<(MODE == GS_K0_AFTER ? 8 + 4 * S + TT : 8 + RQ)>();
+        GS_SYNC();
+        GS_MMA(0, 0, w0f, K0);
+        GS_SYNC();
+        // ---- p1: quadrant (0,1)
+        read_w(kb, RW1, w1f);
+        dma_x(RX1, para, xa, kta);
+        adv_a();
+        if constexpr (MODE == GS_LAST) epi(IntTag<0>{}, IntTag<0>{}, bm0, bn0, i & 1, true);
+        gs_vmcnt<(MODE == GS_K0_AFTER ? 8 + 4 * S + TT : MODE == GS_LAST ? 8 + S : 8 + RQ)>();
+        GS_SYNC();
+        GS_MMA(0, 1, w1f, K0);
+        GS_SYNC();
+        // ---- p2: quadrant (1,1)
+        read_x(kb, RX1);
+        dma_x(RX0, parb, xb, ktb);
+        if constexpr (MODE == GS_LAST) {
+            dma_table(i + 1);
+            epi(IntTag<0>{}, IntTag<1>{}, bm0, bn0, i & 1, true);
+        }
+        GS_SYNC();
+        GS_MMA(1, 1, w1f, K0);
+        GS_SYNC();
+        // ---- p3: quadrant (1,0)
+        dma_w(RW0, parb, wb, ktb);
+        adv_b();
+        if constexpr (MODE == GS_LAST) epi(IntTag<1>{}, IntTag<1>{}, bm0, bn0, i & 1, true);
+        gs_vmcnt<(MODE == GS_K0_AFTER ? 8 + 2 * S : MODE == GS_LAST ? 8 + 3 * S + TT : 8 + RQ)>();
+        GS_SYNC();
+        GS_MMA(1, 0, w0f, K0);
+        GS_SYNC();
+        cpar ^= 1;
+    };
+
+    for (int i = 0; i < n_mine; ++i) {
+        pbm0 = bm0;
+        pbn0 = bn0;
+        tile_origin(i, bm0, bn0);
+        if (i == 0) ktile(IntTag<GS_K0_FIRST>{}, i);
+        else ktile(IntTag<GS_K0_AFTER>{}, i);
+        int kt = 1;
+        if constexpr (RES) {
+            ktile(IntTag<GS_R0>{}, i);
+            ktile(IntTag<GS_R0 + 1>{}, i);
+            ktile(IntTag<GS_R0 + 2>{}, i);
+            ktile(IntTag<GS_R0 + 3>{}, i);
+            ktile(IntTag<GS_R0 + 4>{}, i);
+            ktile(IntTag<GS_R0 + 5>{}, i);
+            ktile(IntTag<GS_R0 + 6>{}, i);
+            ktile(IntTag<GS_R0 + 7>{}, i);
+            ktile(IntTag<GS_RC>{}, i);
+            kt = 10;
+        }
+        for (; kt < ks - 1; ++kt) ktile(IntTag<GS_INTERIOR>{}, i);
+        ktile(IntTag<GS_LAST>{}, i);
+    }
+    if (wr == 0) { GS_SYNC(); }   // barrier counts match again
+    if (n_mine > 0) epi(IntTag<1>{}, IntTag<0>{}, bm0, bn0, (n_mine - 1) & 1, true);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // zero-fill DMAs of the stream's tail
+#undef GS_MMA
+#undef GS_SYNC
+}
+
+// Preconditions as launch_gemm256 (conv_igemm.hip's dispatcher) plus: a.ksteps = packed pitch / 128 >= 2;
+// with a residual: fp16, a.scale == nullptr, residual added before the activation, a.ksteps >= 11.
+template <typename T, int ACT, bool RES> static int launch_gs(const Gemm256Args& a0, hipStream_t st, int cus) {
+    Gemm256Args a = a0;
+    { static const int dbg = [] { const char* e = getenv("TLXMI_DEBUG"); return e ? atoi(e) : 0; }(); a.debug = dbg; }
+    a.mtiles = (a.M + 255) / 256;
+    a.ntiles = (a.Cout + 255) / 256;
+    a.gn = a.ntiles;
+    const size_t lds = (size_t)8 * 128 * 128 + 2 * 2048;
+    const void* fn = reinterpret_cast<const void*>(&gemm_stream_kernel<T, ACT, RES>);
+    static bool raised = false;
+    if (!raised) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(TLXMI_ERR_LAUNCH, "gemm_stream: cannot raise LDS limit: %s", hipGetErrorString(e));
+        raised = true;
+    }
+    const int tiles = a.mtiles * a.ntiles;
+    int grid = cus & ~7;            // one workgroup per CU; a multiple of 8 keeps a virtual block on its XCD
+    if (grid < 8) grid = 8;
+    if (grid > tiles) grid = tiles; // fewer tiles than CUs: one tile each (ids < tiles, mapping still bijective)
+    void* args[] = {&a};
+    hipError_t e = hipLaunchKernel(fn, dim3((unsigned)grid), dim3(512), args, lds, st);
+    if (e != hipSuccess) return fail(TLXMI_ERR_LAUNCH, "gemm_stream: HIP launch failed: %s", hipGetErrorString(e));
+    return TLXMI_OK;
+}
+
+template <typename T> static int launch_gs_t(const Gemm256Args& a, hipStream_t st, int cus) {
+    if constexpr (sizeof(T) == 2) {
+        if (a.res) {
+            if (a.act == TLXMI_ACT_RELU) return launch_gs<T, TLXMI_ACT_RELU, true>(a, st, cus);
+            return launch_gs<T, TLXMI_ACT_NONE, true>(a, st, cus);
+        }
+    }
+    if (a.act == TLXMI_ACT_RELU) return launch_gs<T, TLXMI_ACT_RELU, false>(a, st, cus);
+    if constexpr (sizeof(T) == 2) {
+        if (a.act == TLXMI_ACT_GELU) return launch_gs<T, TLXMI_ACT_GELU, false>(a, st, cus);
+    }
+    return launch_gs<T, TLXMI_ACT_NONE, false>(a, st, cus);
+}
+
+bool gemm_stream_ok(int dtype, const Gemm256Args& a) {
+    if (a.ksteps < 2) return false;
+    if (a.act != TLXMI_ACT_NONE && a.act != TLXMI_ACT_RELU && !(a.act == TLXMI_ACT_GELU && dtype == TLXMI_F16 && !a.res)) return false;
+    if (a.res && (dtype != TLXMI_F16 || a.scale != nullptr || (a.flags & TLXMI_EPI_RES_AFTER_ACT) || a.ksteps < 11)) return false;
+    return true;
+}
+
+int launch_gemm_stream(int dtype, const Gemm256Args& a, hipStream_t st, int cus) {
+    if (dtype == TLXMI_F16) return launch_gs_t<half_t>(a, st, cus);
+    return launch_gs_t<float>(a, st, cus);
+}
+
+}  // namespace tlxmi

@@ -6,24 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 from tlxcv_amd import engine as E  # noqa: E402
 
-# name: (N, H, W, Cin, Cout, k, stride, res)
-SHAPES = {
-    "expand56": (256, 56, 56, 64, 256, 1, 1, True),
-    "reduce56": (256, 56, 56, 256, 64, 1, 1, False),
-    "c3x3_14": (256, 14, 14, 256, 256, 3, 1, False),
-    "c3x3_56": (256, 56, 56, 64, 64, 3, 1, False),
-    "expand14": (256, 14, 14, 256, 1024, 1, 1, True),
-    "expand28": (256, 28, 28, 128, 512, 1, 1, True),
-    "expand7": (256, 7, 7, 512, 2048, 1, 1, True),
-    "reduce14": (256, 14, 14, 1024, 256, 1, 1, False),
-    "c3x3_28": (256, 28, 28, 128, 128, 3, 1, False),
-    "c3x3_7": (256, 7, 7, 512, 512, 3, 1, False),
-    "trans56": (256, 56, 56, 64, 256, 1, 1, False),
-    "qkv": (50432, 1, 1, 768, 2304, 1, 1, False),
-    "proj": (50432, 1, 1, 768, 768, 1, 1, True),
-    "fc1": (50432, 1, 1, 768, 3072, 1, 1, False),
-    "fc2": (50432, 1, 1, 3072, 768, 1, 1, True),
-}
+from tools.conv_micro_shapes import SHAPES  # noqa: E402
+
 names = sys.argv[1].split(",") if len(sys.argv) > 1 else list(SHAPES)
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 dev = torch.device("cuda:0")
