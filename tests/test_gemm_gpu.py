@@ -1,0 +1,97 @@
+"""The 256 x 256 GEMM kernels behind tlxmi_conv2d (gemm_pp.hip = candidate 7, gemm_stream.hip = candidate 8;
+Linear layers of reference vision_transformer.py:81-87,112-123) against the CPU oracle, one candidate
+forced at a time through TLXMI_TILE — the dispatcher would otherwise pick them only for large layers.
+
+Edge cases of the tiling and of the persistent K-tile stream: row tails (M % 256), channel tails
+(Cout % 256, Cout not a multiple of 256 at all), 2 / 3 / odd / many K tiles, a K tail inside the last
+128-byte tile, more tiles than CUs (several tiles per workgroup, unequal counts), fewer tiles than CUs,
+bias / BatchNorm scale / residual / activation combinations, and the tail split of the dispatcher.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import functional as OF
+from tlxcv_amd import engine as E
+from util import rnd, q16, tol
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def force_tile():
+    def set_tile(t):
+        if t is None:
+            os.environ.pop("TLXMI_TILE", None)
+        else:
+            os.environ["TLXMI_TILE"] = str(t)
+    yield set_tile
+    os.environ.pop("TLXMI_TILE", None)
+
+
+def run_linear(dev, dtype, M, K, Cout, bias=True, scale=False, res=False, act=E.ACT_NONE, seed=0):
+    rng = np.random.default_rng(seed)
+    x = rnd(rng, (M, K))
+    w = rnd(rng, (Cout, K), (1.0 / K) ** 0.5)
+    b = rnd(rng, (Cout,), 0.2) if bias else None
+    sc = torch.from_numpy(rng.uniform(0.5, 1.5, Cout).astype(np.float32)) if scale else None
+    r = rnd(rng, (M, Cout)) if res else None
+    if dtype == torch.float16:
+        x, w = q16(x), q16(w)
+        r = q16(r) if r is not None else None
+    # oracle: the 1x1 convolution restatement with M as the pixel axis
+    want = OF.conv_bn_act(x.t().reshape(1, K, M, 1), w.reshape(Cout, K, 1, 1), sc, b,
+                          r.t().reshape(1, Cout, M, 1) if r is not None else None, act, 0.0, (1, 1), (0, 0), 1, 1, False)
+    want = want.reshape(Cout, M).t()
+    pk = E.PackedFilter(w.reshape(Cout, K, 1, 1).to(dev), dtype)
+    xe = x.to(dtype).to(dev).view(M, 1, 1, K)
+    re_ = r.to(dtype).to(dev).view(M, 1, 1, Cout) if r is not None else None
+    got = E.conv2d(xe, pk, 1, 0, 1, sc.to(dev) if sc is not None else None, b.to(dev) if b is not None else None, re_, act)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(got.view(M, Cout).float().cpu(), want, **tol(dtype))
+
+
+# (M, K, Cout): K in elements
+SHAPES = [
+    (256, 128, 256),        # one tile, 2 K tiles (fp16) — fewer tiles than CUs
+    (300, 192, 256),        # row tail, 3 K tiles
+    (1000, 200, 264),       # row tail, channel tail (Cout % 256 = 8), K tail inside the last tile
+    (513, 448, 512),        # 7 K tiles (fp16), 3 x 2 tiles
+    (3 * 256, 768, 768),    # ViT proj shape at small M: 12 K tiles (residual path of the stream kernel)
+    (70 * 256 + 17, 128, 1024),   # 284 tiles > 256 CUs: two tiles for some workgroups, one for the rest
+    (256 * 20, 704, 3072),  # 240 tiles, 11 K tiles (smallest residual-capable stream)
+]
+
+
+@pytest.mark.parametrize("tile", [7, 8], ids=["pp", "stream"])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32], ids=["fp16", "fp32"])
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_linear_bias(dev, force_tile, tile, dtype, shape):
+    force_tile(tile)
+    run_linear(dev, dtype, *shape)
+
+
+@pytest.mark.parametrize("tile", [7, 8], ids=["pp", "stream"])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32], ids=["fp16", "fp32"])
+@pytest.mark.parametrize("epi", ["none", "gelu", "relu", "res", "res_relu", "bn_relu", "bn_res", "nobias_res"])
+def test_linear_epilogues(dev, force_tile, tile, dtype, epi):
+    force_tile(tile)
+    kw = dict(bias=epi != "nobias_res", scale=epi.startswith("bn"), res="res" in epi,
+              act=E.ACT_GELU if epi == "gelu" else E.ACT_RELU if "relu" in epi else E.ACT_NONE)
+    run_linear(dev, dtype, 2 * 256 + 40, 768, 768, seed=3, **kw)
+
+
+@pytest.mark.parametrize("tile", [7, 8], ids=["pp", "stream"])
+def test_many_tiles_per_workgroup(dev, force_tile, tile):
+    # 197 x 3 tiles of the ViT-B proj / fc2 layers at batch 256: 2-3 tiles per workgroup with a residual
+    force_tile(tile)
+    run_linear(dev, torch.float16, 50432, 768, 768, res=True, seed=5)
+
+
+def test_auto_dispatch_tail_split(dev, force_tile):
+    # 197 x 12 tiles = 9 rounds + 60: the dispatcher sends 192 row tiles to the 256 x 256 kernel and the last
+    # 1280 rows to small tiles; the seam must be invisible
+    force_tile(None)
+    run_linear(dev, torch.float16, 50432, 768, 3072, act=E.ACT_GELU, seed=7)

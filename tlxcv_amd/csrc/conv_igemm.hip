@@ -59,8 +59,6 @@ struct ConvArgs {
     unsigned y_bytes;           // extent of y when it may be written through a descriptor (0: plain stores)
     int store_policy;           // 0 plain, 16 sc1 (write-through, line dropped from L2), 2 nt
     int sb_off;                 // LDS byte offset of the block's scale/shift table (2 x BN floats)
-    int first_wave;             // blocks resident at launch (CUs x blocks/CU); they start out of phase, see below
-    unsigned stagger;           // 100 MHz ticks per phase step (0: no stagger)
 };
 
 __device__ __attribute__((aligned(16))) unsigned g_zero_page[4];  // source of padding / tail chunks
@@ -161,16 +159,6 @@ __global__ __launch_bounds__(WGM * 128) void conv_igemm_kernel(const ConvArgs a)
         tile_n = grp * a.gn + rem % gn_here;
     }
     const int bm0 = tile_m * BM, bn0 = tile_n * BN;
-
-    // Blocks of the first round all start together and, tiles being equal work, would all reach their
-    // store phase together: the whole chip then alternates between an MFMA phase with idle HBM and a write
-    // burst with idle MFMAs.  Delaying each first-round block by a pseudo-random eighth of a tile time
-    // spreads the store phases of later rounds uniformly (co-resident blocks compute while others store).
-    if (a.stagger && (int)blockIdx.x < a.first_wave) {
-        const unsigned ph = (blockIdx.x * 2654435761u) >> 29;
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(), wait = (unsigned long long)ph * a.stagger;
-        while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
-    }
 
     // Buffer descriptors: 32-bit per-lane byte offsets, and the hardware range check supplies the
     // zeros of padding taps / tail rows / tail K chunks (offset OOB) with no select on the data path.
@@ -526,16 +514,6 @@ template <typename T, int BM, int BN, int WGM, int STAGES> static int launch(con
     b.sb_off = (int)lds;
     lds += 2 * BN * sizeof(float);
     const long grid = (long)b.mtiles * b.ntiles;
-    {
-        static const int pct = [] { const char* e = getenv("TLXMI_STAGGER"); return e ? atoi(e) : 0; }();
-        int per_cu = (int)((160 * 1024) / lds);
-        const int reg_cap = WGM == 4 ? 1 : (BM == 128 && BN == 128) ? 3 : ((BM == 64 && BN == 64) ? 8 : 5);
-        if (per_cu > reg_cap) per_cu = reg_cap;
-        b.first_wave = num_cus() * per_cu;
-        // tile time estimate: MFMA work of one tile at ~60% of a CU's share (5.1 TFLOP/s per CU at 2.1 GHz)
-        const double tile_ns = 2.0 * BM * BN * (double)a.kchunks * (16 / (int)sizeof(T)) / (5100.0 / per_cu);
-        b.stagger = (pct > 0 && grid > 2 * b.first_wave) ? (unsigned)(tile_ns / 10.0 / 8.0 * pct / 100.0) : 0u;
-    }
     const bool is1x1 = a.R == 1 && a.S == 1 && a.ph == 0 && a.pw == 0;
     const bool resp = a.res && a.vec_io && !a.strided_n;
     const void* fns[4] = {reinterpret_cast<const void*>(&conv_igemm_kernel<T, BM, BN, false, WGM, STAGES, false>),
@@ -619,11 +597,10 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
         const float score = quant * fill * cands[i].eff;
         if (score > best_score) { best_score = score; best = i; }
     }
-    // tuning aid: TLXMI_TILE=<candidate>; with TLXMI_TILE_DYNAMIC set the variable is re-read on every call
-    static const bool dyn = getenv("TLXMI_TILE_DYNAMIC") != nullptr;
-    static const int forced0 = [] { const char* e = getenv("TLXMI_TILE"); return e ? atoi(e) : -1; }();
-    int forced = forced0;
-    if (dyn) { const char* e = getenv("TLXMI_TILE"); forced = e ? atoi(e) : -1; }
+    // tuning / test aid: TLXMI_TILE=<candidate> forces a tile shape (read on every call, so one process can
+    // compare candidates: tools/ab_tiles.py, tests/test_gemm_gpu.py)
+    int forced = -1;
+    { const char* e = getenv("TLXMI_TILE"); if (e && *e) forced = atoi(e); }
     if (forced >= 0 && forced < NC && !(cands[forced].bn == 128 && a.Cout <= 64) && (forced < 5 || gemm256_ok)) best = forced;
     if (best >= 7 && tail_split) {
         // rows of the full rounds (whole M tiles) -> this candidate; the rest -> best small-tile candidate

@@ -79,13 +79,6 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
         tile_n = L - tile_m * a.ntiles;
     }
     const int bm0 = tile_m * BM, bn0 = tile_n * BN;
-    if (a.debug >> 8) {   // experiment: first-round blocks start out of phase
-        if ((int)blockIdx.x < 256) {
-            const unsigned ph = (blockIdx.x * 2654435761u) >> 29;
-            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(), wait = (unsigned long long)ph * (unsigned)(a.debug >> 8);
-            while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
-        }
-    }
     const __amdgpu_buffer_rsrc_t xsrd = pp_srd(a.x, a.x_bytes), wsrd = pp_srd(a.w, a.w_bytes);
 
     // ---- loader: a piece = 8 rows x 128 B (one wave instruction); wave w fills pieces w and w+8 of a half

@@ -4,7 +4,6 @@ import os
 import statistics
 import sys
 
-os.environ["TLXMI_TILE_DYNAMIC"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 from tlxcv_amd import engine as E  # noqa: E402
