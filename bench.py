@@ -171,7 +171,7 @@ def main():
             "peak": HBM_PEAK_GBS if hbm_bound else MFMA_F16_PEAK_TF,
             "unit": "GB/s" if hbm_bound else "TFLOP/s",
             "frac": round(gbs / HBM_PEAK_GBS if hbm_bound else tfs / MFMA_F16_PEAK_TF, 4), "traffic": traffic,
-            "kernel": "conv_igemm_kernel (all instantiations; every conv / linear launch of one forward)",
+            "kernel": "tlxmi_conv2d kernel family: conv_igemm_kernel, gemm_pp_kernel, gemm_stream_kernel, gemm256_kernel (all instantiations; every conv / linear launch of one forward)",
             "launches_per_step": nl // nprobe, "avg_launch_us": round(per_launch_us, 2),
             "alg_bytes_per_launch": int(alg_bytes / nl), "alg_flops_per_launch": int(flops / nl),
             "hbm_gbs": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),

@@ -558,8 +558,15 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
                             a.vec_io && a.Cout % 8 == 0 && a.y_bytes != 0 && a.Cout >= 256 && a.ktiles >= 2 &&
                             (!a.res || (long long)a.M * a.res_ld * (long long)sizeof(T) < (1ll << 31));
     if (!gemm256_ok) cands[5].eff = cands[6].eff = cands[7].eff = cands[8].eff = 0.f;
+    cands[5].eff = 0.f;   // superseded by candidate 7 (same tile, antiphase wave groups); kept for A/B runs (TLXMI_TILE=5)
     if (obi >= 0.0015 || a.ktiles < 4) cands[4].eff = 0.f;
-    if (obi >= 0.0015) cands[5].eff = cands[6].eff = cands[7].eff = cands[8].eff = 0.f;
+    // regimes by output bytes per FLOP (tools/ab_tiles.py sweep over the ResNet-50 / ViT-B / Swin-B layer shapes):
+    // the 256-row GEMM kernels win up to ~0.005 (256x256) / ~0.01 (256x128, two workgroups per CU); beyond that
+    // the layer is HBM / latency-bound and wants many small resident blocks
+    if (obi >= 0.005) cands[7].eff = cands[8].eff = 0.f;
+    if (obi >= 0.010) cands[6].eff = 0.f;
+    if (obi >= 0.012) { cands[0].eff = 0.65f; cands[1].eff = 0.80f; cands[2].eff = 0.85f; cands[3].eff = 1.00f; }
+    else if (obi >= 0.0015) { cands[0].eff = 0.85f; cands[1].eff = 0.90f; cands[2].eff = 1.00f; cands[3].eff = 0.90f; }
     if (!allow_stream) cands[7].eff = cands[8].eff = 0.f;
     // the persistent kernel hides the plain epilogue but not the GELU arithmetic (measured: fc1 of ViT-B)
     if (a.act == TLXMI_ACT_GELU) cands[8].eff = 0.f;
@@ -572,8 +579,6 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
     const int cus = num_cus();
     const long full_rounds = t256 / cus;
     const bool tail_split = gemm256_ok && full_rounds >= 1 && (t256 % cus) != 0 && 4 * (t256 % cus) <= cus;
-    if (obi >= 0.012) { cands[0].eff = 0.65f; cands[1].eff = 0.80f; cands[2].eff = 0.85f; cands[3].eff = 1.00f; }
-    else if (obi >= 0.0015) { cands[0].eff = 0.85f; cands[1].eff = 0.90f; cands[2].eff = 1.00f; cands[3].eff = 0.90f; }
     int best = 0;
     float best_score = -1.f;
     for (int i = 0; i < NC; ++i) {

@@ -25,7 +25,7 @@ for nm in names:
     sh = torch.zeros(Co, device=dev)
     Ho = (H + 2 * (k // 2) - k) // st + 1
     r = (torch.randn((N, Ho, Ho if H > 1 else 1, Co), generator=g)).half().to(dev) if res else None
-    act = E.ACT_GELU if nm == "fc1" else (E.ACT_NONE if lin else E.ACT_RELU)
+    act = E.ACT_GELU if nm.endswith("fc1") else (E.ACT_NONE if lin else E.ACT_RELU)
     times = {t: [] for t in tiles}
     for rd in range(rounds + 1):
         for t in tiles:

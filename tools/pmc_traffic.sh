@@ -20,12 +20,12 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     s = 0.0; k = 0
     for f in glob.glob(f"gpurun_out/traffic_{wl}/{c}/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
-            if ("conv_igemm" in row["Kernel_Name"] or "gemm256" in row["Kernel_Name"]) and row["Counter_Name"] == c:
+            if any(k in row["Kernel_Name"] for k in ("conv_igemm", "gemm256", "gemm_pp", "gemm_stream")) and row["Counter_Name"] == c:
                 s += float(row["Counter_Value"]); k += 1
     tot[c] = s; n[c] = k
 launches = n["FETCH_SIZE"]
 fetch_kb, write_kb = tot["FETCH_SIZE"], tot["WRITE_SIZE"]
-res = {"workload": wl, "kernel": "conv_igemm_kernel + gemm256_kernel (all instantiations)", "launches": launches,
+res = {"workload": wl, "kernel": "conv_igemm_kernel + gemm256 / gemm_pp / gemm_stream kernels (all instantiations)", "launches": launches,
        "FETCH_SIZE_KB_raw_per_launch": fetch_kb / max(launches, 1), "WRITE_SIZE_KB_per_launch": write_kb / max(n["WRITE_SIZE"], 1),
        "gfx950_fetch_correction": 2.0,
        "hbm_bytes_per_launch": (2.0 * fetch_kb / max(launches, 1) + write_kb / max(n["WRITE_SIZE"], 1)) * 1024}
