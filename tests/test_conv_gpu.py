@@ -150,3 +150,30 @@ def test_space_to_depth_stem_equals_plain_conv(dev, dtype, k, s, p, b, H):
         torch.testing.assert_close(engine_to_nchw(got), want, **tol(dtype))
     finally:
         tlxcv_amd.set_precision("fp16")
+
+
+# ---- conv_halo.hip (thin inputs, stride 1): forced on / off through TLXMI_HALO, both against the oracle
+HALO_CASES = [
+    # (N, Cin, Cout, k, pad, H, W, res, act)
+    (2, 64, 64, 3, 1, 56, 56, False, 1),      # ResNet layer1 3x3 (resnet.py:142-156)
+    (1, 64, 64, 3, 1, 56, 56, True, 1),       # BasicBlock conv2 + identity (resnet.py:90-106)
+    (1, 64, 128, 3, 1, 40, 52, False, 0),     # two channel tiles, Wo does not divide 256
+    (1, 64, 72, 3, 1, 33, 47, True, 3),       # channel tail, ragged last tile, leaky
+    (1, 64, 64, 3, 0, 36, 36, False, 1),      # no padding
+    (1, 32, 64, 3, 1, 64, 64, False, 3),      # 64 bytes per pixel (darknet.py:54-58)
+    (2, 16, 64, 4, 0, 67, 67, False, 1),      # space-to-depth stem geometry: 4x4 taps over 16 channels
+    (1, 16, 32, 2, 0, 65, 65, False, 2),      # 3x3 stride-2 stem after space-to-depth: 2x2 taps (mobilenetv1.py:79-88)
+    (1, 12, 64, 4, 0, 115, 115, False, 1),    # ResNet stem exactly (12 real channels padded to 16)
+]
+
+
+@pytest.mark.parametrize("halo", ["1", "0"], ids=["halo", "igemm"])
+@pytest.mark.parametrize("cfg", HALO_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_thin_input_stride1(dev, cfg, halo):
+    import os
+    N, Cin, Cout, k, pad, H, W, res, act = cfg
+    os.environ["TLXMI_HALO"] = halo
+    try:
+        run_case(dev, torch.float16, N, Cin, Cout, k, 1, pad, H, W, act=act, act_param=0.1, with_res=res, seed=11)
+    finally:
+        os.environ.pop("TLXMI_HALO", None)

@@ -28,6 +28,7 @@
 // the same for every piece a lane loads (one im2col position per lane per step).
 #include "common.h"
 #include "gemm256.h"
+#include "conv_halo.h"
 #include <stdlib.h>
 
 namespace tlxmi {
@@ -542,6 +543,35 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
     // The shape efficiency depends on the regime (measured on MI355X, tools/conv_micro.py sweep): layers
     // that move many output/residual bytes per FLOP (the 1x1 "expand" convs with a skip connection) are
     // latency/HBM-bound and want many small resident blocks; MFMA-bound layers want the 128x128 tile.
+    // Thin inputs (<= 128 bytes per pixel), stride 1, few output channels: the gather of every tap through LDS is
+    // the bound; conv_halo.hip loads the input rows once and keeps the filters in registers.
+    if constexpr (sizeof(T) == 2) {
+        const int PB = a.C * 2;
+        int forced_h = -1;
+        { const char* e = getenv("TLXMI_HALO"); if (e && *e) forced_h = atoi(e); }   // 0: off (A/B runs)
+        if (forced_h != 0 && a.sh == 1 && a.sw == 1 && a.dh == 1 && a.dw == 1 && (a.R > 1 || a.S > 1) && conv_halo_shape_ok(a.R, a.S, PB) &&
+            conv_halo_act_ok(a.act) && !a.strided_n && a.vec_io && a.Cout % 8 == 0 && a.Cout <= 128 && a.y_bytes != 0 &&
+            a.HoWo >= 1024 && (!a.res || (long long)a.M * a.res_ld * 2 < (1ll << 31))) {
+            HaloArgs h;
+            h.x = a.x; h.w = a.w; h.y = a.y; h.scale = a.scale; h.shift = a.shift; h.res = a.res;
+            h.N = a.N; h.H = a.H; h.W = a.W; h.Cout = a.Cout; h.R = a.R; h.S = a.S; h.ph = a.ph; h.pw = a.pw;
+            h.Ho = a.Ho; h.Wo = a.Wo; h.HoWo = a.HoWo; h.x_ld = a.x_ld; h.y_ld = a.y_ld; h.res_ld = a.res_ld;
+            h.PB = PB; h.Kp_bytes = a.Kp_bytes; h.act = a.act; h.act_param = a.act_param; h.flags = a.flags;
+            h.tpi = (a.HoWo + 255) / 256;
+            h.ntn = (a.Cout + 63) / 64; h.nt = 0;
+            h.PW = a.Wo + a.S - 1;
+            const int span = (a.Wo - 1 + 255) / a.Wo + 1;          // output rows a tile of 256 consecutive pixels can touch
+            const int ppp = 1024 / PB;
+            h.PWp = (h.PW + ppp - 1) / ppp * ppp;
+            // ring: the rows of a tile (span + R - 1) plus the rows the next tile adds (<= span, or a whole first
+            // tile of the next image) must fit
+            h.nring = 8;
+            while (h.nring < 2 * (span + a.R - 1)) h.nring *= 2;
+            h.x_bytes = a.x_bytes; h.w_bytes = a.w_bytes; h.y_bytes = a.y_bytes;
+            h.res_bytes = a.res ? (unsigned)((long long)a.M * a.res_ld * 2) : 0u;
+            if ((long)h.nring * h.PWp * PB <= 160 * 1024) return launch_conv_halo(h, st, num_cus());
+        }
+    }
     struct Cand { int bm, bn; float eff; };
     const double flops = 2.0 * a.M * (double)a.Cout * a.kchunks * (16 / (int)sizeof(T));
     const double obytes = (double)a.M * a.Cout * sizeof(T) * (a.res ? 2.0 : 1.0);

@@ -18,7 +18,7 @@ for tag in "abcde":
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(f"gpurun_out/pmc2/{tag}/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
-            if "conv_igemm" in row["Kernel_Name"] or "attn_mfma" in row["Kernel_Name"]:
+            if any(k in row["Kernel_Name"] for k in ("conv_igemm", "attn_mfma", "conv_halo", "gemm_pp", "gemm_stream")):
                 agg[row["Grid_Size"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
     for g, cs in agg.items():
         print(tag, g, {c: round(sum(v)/len(v)) for c, v in cs.items()})
