@@ -18,7 +18,7 @@ struct HaloArgs {
     int act;
     float act_param;
     unsigned flags;
-    int tpi;                  // tiles (256 consecutive output pixels) per image
+    int tpi;                  // tiles (conv_halo_tile_pixels consecutive output pixels) per image
     int ntn;                  // channel tiles (64 channels), one launch each
     int nt;                   // channel tile of this launch
     int PW;                   // patch width in pixels = Wo + S - 1
@@ -28,7 +28,7 @@ struct HaloArgs {
     int debug;                // tuning builds only
 };
 
-bool conv_halo_shape_ok(int R, int S, int PB);
+int conv_halo_tile_pixels(int R, int S, int PB);   // 0: no instantiation
 bool conv_halo_act_ok(int act);
 int launch_conv_halo(const HaloArgs& a, hipStream_t st, int cus);
 

@@ -5,7 +5,7 @@
 // Why not the implicit GEMM: conv_igemm.hip gathers every tap of every pixel from L2 into LDS, R*S times
 // the input (16x for the stem, 9x for a 3x3), and with only 64 output channels per input byte those layers
 // are bound by that L2 -> LDS fill (measured 434 / 535 TFLOP/s, 19 B/clk/CU of fill).  Here
-//   * a tile is 256 consecutive output pixels of one image x 64 channels; a workgroup walks a contiguous
+//   * a tile is 256 or 512 consecutive output pixels of one image x 64 channels; a workgroup walks a contiguous
 //     range of tiles and keeps the input rows it needs in an LDS ring of NRING rows ((W + 2*pad) pixels, zero
 //     padding included): every input row is brought in ONCE per workgroup by LDS-DMA (the R-1 halo rows two
 //     consecutive tiles share stay in the ring), the rows the next tile adds are fetched while this tile is
@@ -42,8 +42,11 @@ static __device__ __forceinline__ void ch_store16_nt(__amdgpu_buffer_rsrc_t rsrc
 }
 
 // R x S taps, PB = bytes per input pixel (C * 2); S * PB must be a multiple of 64 (one MFMA K slice)
-template <int R, int S, int PB>
+// PI = MFMA pixel sub-tiles per wave: a tile is TP = 64 * PI consecutive pixels (8 where the filter registers
+// leave room: per-tile overhead halves)
+template <int R, int S, int PB, int PI>
 __global__ __launch_bounds__(512) void conv_halo_kernel(const HaloArgs a) {
+    constexpr int TP = 64 * PI;          // pixels of a tile
     constexpr int KR = S * PB / 64;      // K slices per filter row
     constexpr int NKK = R * KR;          // K slices in all
     constexpr int OOB = (int)0x80000000;
@@ -73,8 +76,8 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const HaloArgs a) {
         const int L = tl.ok ? t_lo + i : t_lo;
         tl.n = L / a.tpi;
         const int tt = L - tl.n * a.tpi;
-        tl.m0 = tt * 256;
-        tl.npx = a.HoWo - tl.m0 < 256 ? a.HoWo - tl.m0 : 256;
+        tl.m0 = tt * TP;
+        tl.npx = a.HoWo - tl.m0 < TP ? a.HoWo - tl.m0 : TP;
         tl.oy0 = tl.m0 / a.Wo;
         tl.nr = (tl.m0 + tl.npx - 1) / a.Wo - tl.oy0 + R;
         return tl;
@@ -165,10 +168,10 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const HaloArgs a) {
         if (!(a.debug & 1)) prefetch(nxt);
 
         // ring slot (for filter row 0) and byte inside the row of this lane's pixel of each sub-tile
-        int sq[4], bx[4];
+        int sq[PI], bx[PI];
 #pragma unroll
-        for (int pi = 0; pi < 4; ++pi) {
-            int pt = pg * 64 + pi * 16 + frow;
+        for (int pi = 0; pi < PI; ++pi) {
+            int pt = pg * (16 * PI) + pi * 16 + frow;
             pt = pt < cur.npx ? pt : cur.npx - 1;      // pixels past the tile read a valid row, never stored
             const int m = cur.m0 + pt;
             const int oy = (int)(((float)m + 0.5f) * inv_wo);
@@ -177,23 +180,23 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const HaloArgs a) {
             bx[pi] = (ox << PSH) + fg * 16;
         }
         const char* pb = smem;
-        f32x4 acc[2][4];
+        f32x4 acc[2][PI];
 #pragma unroll
         for (int ci = 0; ci < 2; ++ci)
 #pragma unroll
-            for (int pi = 0; pi < 4; ++pi) acc[ci][pi] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int pi = 0; pi < PI; ++pi) acc[ci][pi] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < ((a.debug & 4) ? 1 : R); ++r) {
-            int bq[4];
+            int bq[PI];
 #pragma unroll
-            for (int pi = 0; pi < 4; ++pi) bq[pi] = ((sq[pi] + r) & rmask) * row_bytes + bx[pi];
+            for (int pi = 0; pi < PI; ++pi) bq[pi] = ((sq[pi] + r) & rmask) * row_bytes + bx[pi];
             if constexpr (PB == 128) {
                 // one pixel = one 128-byte line = two K slices: the swizzle is computed once per line
 #pragma unroll
                 for (int sx = 0; sx < S; ++sx) {
-                    u32x4 xf[2][4];
+                    u32x4 xf[2][PI];
 #pragma unroll
-                    for (int pi = 0; pi < 4; ++pi) {
+                    for (int pi = 0; pi < PI; ++pi) {
                         const int b = bq[pi] + sx * 128;
                         const int phys = b ^ (((b >> 7) & 7) << 4);
                         xf[0][pi] = *reinterpret_cast<const u32x4*>(pb + phys);
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const HaloArgs a) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
 #pragma unroll
-                        for (int pi = 0; pi < 4; ++pi)
+                        for (int pi = 0; pi < PI; ++pi)
 #pragma unroll
                             for (int ci = 0; ci < 2; ++ci)
                                 acc[ci][pi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
@@ -211,15 +214,15 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const HaloArgs a) {
             } else {
 #pragma unroll
                 for (int kr = 0; kr < KR; ++kr) {
-                    u32x4 xf[4];
+                    u32x4 xf[PI];
 #pragma unroll
-                    for (int pi = 0; pi < 4; ++pi) {
+                    for (int pi = 0; pi < PI; ++pi) {
                         const int b = bq[pi] + kr * 64;
                         const int phys = b ^ (((b >> 7) & 7) << 4);
                         xf[pi] = *reinterpret_cast<const u32x4*>(pb + phys);
                     }
 #pragma unroll
-                    for (int pi = 0; pi < 4; ++pi)
+                    for (int pi = 0; pi < PI; ++pi)
 #pragma unroll
                         for (int ci = 0; ci < 2; ++ci)
                             acc[ci][pi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
@@ -235,19 +238,20 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const HaloArgs a) {
         // ---- epilogue: lane (g = fg, px = frow) owns channels 64nt + 32cg + 8g .. +7 of pixel 64pg + 16pi + px
         const int ch0 = a.nt * 64 + cg * 32 + 8 * fg;
         const bool chok = ch0 < a.Cout;     // Cout is a multiple of 8 on this path
-        // all residual loads before the first store: a load behind a store would wait for it (in-order counter)
+        // residual loads (four sub-tiles at a time) before the stores of those sub-tiles: a load behind a store
+        // would wait for it (in-order counter)
         u32x4 rr[4];
-        if (a.res) {
 #pragma unroll
-            for (int pi = 0; pi < 4; ++pi) {
-                const int pt = pg * 64 + pi * 16 + frow;
-                const int mg = cur.n * a.HoWo + cur.m0 + pt;
-                rr[pi] = ch_load16(rsrd, (chok && pt < cur.npx) ? (mg * a.res_ld + ch0) * 2 : OOB);
+        for (int pi = 0; pi < PI; ++pi) {
+            if ((pi & 3) == 0 && a.res) {
+#pragma unroll
+                for (int p2 = 0; p2 < 4; ++p2) {
+                    const int pt2 = pg * (16 * PI) + (pi + p2) * 16 + frow;
+                    const int mg2 = cur.n * a.HoWo + cur.m0 + pt2;
+                    rr[p2] = ch_load16(rsrd, (chok && pt2 < cur.npx) ? (mg2 * a.res_ld + ch0) * 2 : OOB);
+                }
             }
-        }
-#pragma unroll
-        for (int pi = 0; pi < 4; ++pi) {
-            const int pt = pg * 64 + pi * 16 + frow;
+            const int pt = pg * (16 * PI) + pi * 16 + frow;
             const bool ok = chok && pt < cur.npx;
             const int mg = cur.n * a.HoWo + cur.m0 + pt;
             float v[8];
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const HaloArgs a) {
             }
             float rv[8];
             if (a.res) {
-                const half8v hv = __builtin_bit_cast(half8v, rr[pi]);
+                const half8v hv = __builtin_bit_cast(half8v, rr[pi & 3]);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) rv[e] = (float)hv[e];
                 if (!res_after) {
@@ -299,8 +303,8 @@ bool conv_halo_act_ok(int act) {
            act == TLXMI_ACT_HARDSWISH;
 }
 
-template <int R, int S, int PB> static int launch_halo_t(const HaloArgs& a, hipStream_t st, int cus) {
-    const void* fn = reinterpret_cast<const void*>(&conv_halo_kernel<R, S, PB>);
+template <int R, int S, int PB, int PI> static int launch_halo_t(const HaloArgs& a, hipStream_t st, int cus) {
+    const void* fn = reinterpret_cast<const void*>(&conv_halo_kernel<R, S, PB, PI>);
     const size_t lds = (size_t)a.nring * a.PWp * PB;
     static bool raised = false;
     if (!raised) {
@@ -324,16 +328,18 @@ template <int R, int S, int PB> static int launch_halo_t(const HaloArgs& a, hipS
     return TLXMI_OK;
 }
 
-// Shapes with a compiled instantiation (R, S, bytes per pixel)
-bool conv_halo_shape_ok(int R, int S, int PB) {
-    return (R == 3 && S == 3 && (PB == 128 || PB == 64)) || (R == 4 && S == 4 && PB == 32) || (R == 2 && S == 2 && PB == 32);
+// Shapes with a compiled instantiation (R, S, bytes per pixel); returns the pixels of a tile, 0 if none
+int conv_halo_tile_pixels(int R, int S, int PB) {
+    if (R == 3 && S == 3 && PB == 128) return 256;
+    if ((R == 3 && S == 3 && PB == 64) || (R == 4 && S == 4 && PB == 32) || (R == 2 && S == 2 && PB == 32)) return 512;
+    return 0;
 }
 
 int launch_conv_halo(const HaloArgs& a, hipStream_t st, int cus) {
-    if (a.R == 3 && a.S == 3 && a.PB == 128) return launch_halo_t<3, 3, 128>(a, st, cus);
-    if (a.R == 3 && a.S == 3 && a.PB == 64) return launch_halo_t<3, 3, 64>(a, st, cus);
-    if (a.R == 4 && a.S == 4 && a.PB == 32) return launch_halo_t<4, 4, 32>(a, st, cus);
-    if (a.R == 2 && a.S == 2 && a.PB == 32) return launch_halo_t<2, 2, 32>(a, st, cus);
+    if (a.R == 3 && a.S == 3 && a.PB == 128) return launch_halo_t<3, 3, 128, 4>(a, st, cus);
+    if (a.R == 3 && a.S == 3 && a.PB == 64) return launch_halo_t<3, 3, 64, 8>(a, st, cus);
+    if (a.R == 4 && a.S == 4 && a.PB == 32) return launch_halo_t<4, 4, 32, 8>(a, st, cus);
+    if (a.R == 2 && a.S == 2 && a.PB == 32) return launch_halo_t<2, 2, 32, 8>(a, st, cus);
     return fail(TLXMI_ERR_UNSUPPORTED, "conv_halo: no instantiation for %dx%d taps, %d bytes per pixel", a.R, a.S, a.PB);
 }
 

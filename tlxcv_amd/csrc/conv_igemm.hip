@@ -549,7 +549,7 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
         const int PB = a.C * 2;
         int forced_h = -1;
         { const char* e = getenv("TLXMI_HALO"); if (e && *e) forced_h = atoi(e); }   // 0: off (A/B runs)
-        if (forced_h != 0 && a.sh == 1 && a.sw == 1 && a.dh == 1 && a.dw == 1 && (a.R > 1 || a.S > 1) && conv_halo_shape_ok(a.R, a.S, PB) &&
+        if (forced_h != 0 && a.sh == 1 && a.sw == 1 && a.dh == 1 && a.dw == 1 && (a.R > 1 || a.S > 1) && conv_halo_tile_pixels(a.R, a.S, PB) > 0 &&
             conv_halo_act_ok(a.act) && !a.strided_n && a.vec_io && a.Cout % 8 == 0 && a.Cout <= 128 && a.y_bytes != 0 &&
             a.HoWo >= 1024 && (!a.res || (long long)a.M * a.res_ld * 2 < (1ll << 31))) {
             HaloArgs h;
@@ -557,10 +557,11 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
             h.N = a.N; h.H = a.H; h.W = a.W; h.Cout = a.Cout; h.R = a.R; h.S = a.S; h.ph = a.ph; h.pw = a.pw;
             h.Ho = a.Ho; h.Wo = a.Wo; h.HoWo = a.HoWo; h.x_ld = a.x_ld; h.y_ld = a.y_ld; h.res_ld = a.res_ld;
             h.PB = PB; h.Kp_bytes = a.Kp_bytes; h.act = a.act; h.act_param = a.act_param; h.flags = a.flags;
-            h.tpi = (a.HoWo + 255) / 256;
+            const int tp = conv_halo_tile_pixels(a.R, a.S, PB);
+            h.tpi = (a.HoWo + tp - 1) / tp;
             h.ntn = (a.Cout + 63) / 64; h.nt = 0;
             h.PW = a.Wo + a.S - 1;
-            const int span = (a.Wo - 1 + 255) / a.Wo + 1;          // output rows a tile of 256 consecutive pixels can touch
+            const int span = (a.Wo - 1 + tp - 1) / a.Wo + 1;       // output rows a tile of tp consecutive pixels can touch
             const int ppp = 1024 / PB;
             h.PWp = (h.PW + ppp - 1) / ppp * ppp;
             // ring: the rows of a tile (span + R - 1) plus the rows the next tile adds (<= span, or a whole first
