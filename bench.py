@@ -164,7 +164,8 @@ def main():
         traffic = None
         tj = os.path.join(REPO, "profiles", "r01", f"traffic_{a.workload}.json")
         if os.path.exists(tj) and a.batch == (128 if a.workload == "swin_b" else 256):
-            traffic = int(json.load(open(tj))["hbm_bytes_per_launch"])
+            tjd = json.load(open(tj))      # bytes per forward over the kernel family -> per conv2d / linear launch
+            traffic = int(tjd["hbm_bytes_per_forward"] / (nl // nprobe)) if "hbm_bytes_per_forward" in tjd else int(tjd["hbm_bytes_per_launch"])
         line["roofline"] = {
             "bound": "hbm" if hbm_bound else "mfma",
             "achieved": round(gbs if hbm_bound else tfs, 1),

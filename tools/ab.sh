@@ -1,2 +1,3 @@
-echo "--- halo tests"; timeout -k 10 300 python -m pytest tests/test_conv_gpu.py -m gpu -q -x -k "thin_input or resnet50_conv" 2>&1 | tail -4
-for h in 0 1; do echo "--- TLXMI_HALO=$h"; TLXMI_HALO=$h timeout -k 10 100 python tools/conv_micro.py c3x3_56,stem 20; done
+timeout -k 10 300 python3 tools/layer_times.py vit_b16 256 > gpurun_out/layers_vit_b16.txt 2>&1
+timeout -k 10 300 python3 tools/layer_times.py swin_b 128 > gpurun_out/layers_swin_b.txt 2>&1
+tail -2 gpurun_out/layers_swin_b.txt

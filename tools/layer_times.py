@@ -10,7 +10,8 @@ from tlxcv_amd import engine as E, seeded, models  # noqa: E402
 wl = sys.argv[1] if len(sys.argv) > 1 else "resnet50"
 bs = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 dev = torch.device("cuda:0")
-m = getattr(models, wl)()
+ctor = {"vit_b16": "vit_base_patch16_224", "swin_b": "swintransformer_base_patch4_window7_224"}.get(wl, wl)
+m = getattr(models, ctor)()
 m.load_dict(seeded.fill(seeded.shapes_of(m), 1))
 m = m.to(dev).set_eval()
 x = torch.from_numpy(seeded.image_batch(32, 0)).to(dev).repeat(bs // 32, 1, 1, 1).contiguous()

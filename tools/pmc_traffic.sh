@@ -12,23 +12,28 @@ for c in FETCH_SIZE WRITE_SIZE; do
   echo "pass $c rc=$?"
 done
 python3 - "$WL" <<'PY'
-import csv, glob, json, sys, collections
+import csv, glob, json, sys
 wl = sys.argv[1]
-tot = {}
-n = {}
+FAMILY = ("conv_igemm", "gemm256", "gemm_pp", "gemm_stream", "conv_halo")
+tot, n, fwd = {}, {}, {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    s = 0.0; k = 0
-    for f in glob.glob(f"gpurun_out/traffic_{wl}/{c}/**/*counter_collection.csv", recursive=True):
-        for row in csv.DictReader(open(f)):
-            if any(k in row["Kernel_Name"] for k in ("conv_igemm", "gemm256", "gemm_pp", "gemm_stream")) and row["Counter_Name"] == c:
+    s = 0.0; k = 0; f = 0
+    for fn in glob.glob(f"gpurun_out/traffic_{wl}/{c}/**/*counter_collection.csv", recursive=True):
+        for row in csv.DictReader(open(fn)):
+            if row["Counter_Name"] != c:
+                continue
+            if any(t in row["Kernel_Name"] for t in FAMILY):
                 s += float(row["Counter_Value"]); k += 1
-    tot[c] = s; n[c] = k
-launches = n["FETCH_SIZE"]
-fetch_kb, write_kb = tot["FETCH_SIZE"], tot["WRITE_SIZE"]
-res = {"workload": wl, "kernel": "conv_igemm_kernel + gemm256 / gemm_pp / gemm_stream kernels (all instantiations)", "launches": launches,
-       "FETCH_SIZE_KB_raw_per_launch": fetch_kb / max(launches, 1), "WRITE_SIZE_KB_per_launch": write_kb / max(n["WRITE_SIZE"], 1),
+            elif "nchw_to_nhwc" in row["Kernel_Name"]:
+                f += 1          # exactly one layout transform per forward: counts the forwards of the run
+    tot[c] = s; n[c] = k; fwd[c] = f
+forwards = max(fwd["FETCH_SIZE"], 1)
+fetch_kb, write_kb = tot["FETCH_SIZE"] / forwards, tot["WRITE_SIZE"] / max(fwd["WRITE_SIZE"], 1)
+res = {"workload": wl, "kernel": "tlxmi_conv2d kernel family (conv_igemm, conv_halo, gemm_pp, gemm_stream, gemm256; all instantiations)",
+       "forwards": forwards, "kernel_launches_per_forward": n["FETCH_SIZE"] / forwards,
+       "FETCH_SIZE_KB_raw_per_forward": fetch_kb, "WRITE_SIZE_KB_per_forward": write_kb,
        "gfx950_fetch_correction": 2.0,
-       "hbm_bytes_per_launch": (2.0 * fetch_kb / max(launches, 1) + write_kb / max(n["WRITE_SIZE"], 1)) * 1024}
+       "hbm_bytes_per_forward": (2.0 * fetch_kb + write_kb) * 1024}
 print(json.dumps(res))
 open(f"gpurun_out/traffic_{wl}/traffic.json", "w").write(json.dumps(res, indent=1))
 PY
