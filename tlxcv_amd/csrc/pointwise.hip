@@ -65,22 +65,23 @@ __global__ void nchw_to_nhwc_kernel(const TS* __restrict__ src, TD* __restrict__
     }
 }
 
-// NCHW -> NHWC with a b x b space-to-depth fold: channel (ph*b+pw)*C + c of output pixel (h2, w2)
+// NCHW -> NHWC with a b x b space-to-depth fold: channel (ph*b+pw)*C + c of output pixel (h2, w2).
+// One workgroup = 128 consecutive output pixels of one output row (the row / image indices are wave-uniform,
+// no per-thread division); a thread writes all chunks of its pixel, so a wave's stores cover whole rows of
+// Cpad channels and its loads walk b*C short runs of one input row each.
 template <typename TS, typename TD>
-__global__ void nchw_to_nhwc_s2d_kernel(const TS* __restrict__ src, TD* __restrict__ dst, int N, int C, int H, int W,
-                                        int b, int Cpad) {
+__global__ __launch_bounds__(128) void nchw_to_nhwc_s2d_kernel(const TS* __restrict__ src, TD* __restrict__ dst, int N, int C,
+                                                              int H, int W, int b, int Cpad, int cb) {
     constexpr int V = Chunk<TD>::N;
     const int H2 = H / b, W2 = W / b;
-    const long HW = (long)H * W, P = (long)N * H2 * W2;
-    const int nch = Cpad / V, Cs = b * b * C;
-    const long total = P * nch;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long p = i % P;
-        const int cg = (int)(i / P);
-        const int w2 = (int)(p % W2);
-        const long t = p / W2;
-        const int h2 = (int)(t % H2);
-        const long n = t / H2;
+    const int row = blockIdx.x / cb, w2 = (blockIdx.x - row * cb) * 128 + threadIdx.x;   // row = n*H2 + h2
+    if (w2 >= W2) return;
+    const int n = row / H2, h2 = row - n * H2;
+    const long HW = (long)H * W;
+    const int Cs = b * b * C;
+    const TS* sp = src + (long)n * C * HW + (long)(h2 * b) * W + w2 * b;
+    TD* dp = dst + ((long)row * W2 + w2) * Cpad;
+    for (int cg = 0; cg < Cpad / V; ++cg) {
         float v[V];
 #pragma unroll
         for (int e = 0; e < V; ++e) {
@@ -88,11 +89,11 @@ __global__ void nchw_to_nhwc_s2d_kernel(const TS* __restrict__ src, TD* __restri
             float x = 0.f;
             if (ch < Cs) {
                 const int c = ch % C, q = ch / C, pw = q % b, ph = q / b;
-                x = (float)src[(n * C + c) * HW + (long)(h2 * b + ph) * W + (w2 * b + pw)];
+                x = (float)sp[c * HW + (long)ph * W + pw];
             }
             v[e] = x;
         }
-        Chunk<TD>::store(dst + p * Cpad + cg * V, v);
+        Chunk<TD>::store(dp + cg * V, v);
     }
 }
 
@@ -373,17 +374,19 @@ extern "C" int tlxmi_nchw_to_nhwc_s2d(const void* src, int sdt, void* dst, int d
                   TLXMI_ERR_BAD_ARG, "nchw_to_nhwc_s2d: H=%d W=%d must be multiples of b=%d, Cpad >= b*b*C", H, W, b);
     TLXMI_REQUIRE(Cpad % VECN(ddt) == 0 && aligned16(dst), TLXMI_ERR_ALIGNMENT,
                   "nchw_to_nhwc_s2d: Cpad=%d must be a whole number of 16-byte chunks", Cpad);
-    const long work = (long)N * (H / b) * (W / b) * (Cpad / VECN(ddt));
-    dim3 g(grid_for(work)), blk(256);
+    const int cb = (W / b + 127) / 128;
+    const long blocks = (long)N * (H / b) * cb;
+    TLXMI_REQUIRE(blocks < (1l << 31), TLXMI_ERR_UNSUPPORTED, "nchw_to_nhwc_s2d: too many rows");
+    dim3 g((unsigned)blocks), blk(128);
     hipStream_t st = as_stream(stream);
     if (sdt == TLXMI_F32 && ddt == TLXMI_F16)
-        hipLaunchKernelGGL((nchw_to_nhwc_s2d_kernel<float, half_t>), g, blk, 0, st, (const float*)src, (half_t*)dst, N, C, H, W, b, Cpad);
+        hipLaunchKernelGGL((nchw_to_nhwc_s2d_kernel<float, half_t>), g, blk, 0, st, (const float*)src, (half_t*)dst, N, C, H, W, b, Cpad, cb);
     else if (sdt == TLXMI_F32 && ddt == TLXMI_F32)
-        hipLaunchKernelGGL((nchw_to_nhwc_s2d_kernel<float, float>), g, blk, 0, st, (const float*)src, (float*)dst, N, C, H, W, b, Cpad);
+        hipLaunchKernelGGL((nchw_to_nhwc_s2d_kernel<float, float>), g, blk, 0, st, (const float*)src, (float*)dst, N, C, H, W, b, Cpad, cb);
     else if (sdt == TLXMI_F16 && ddt == TLXMI_F16)
-        hipLaunchKernelGGL((nchw_to_nhwc_s2d_kernel<half_t, half_t>), g, blk, 0, st, (const half_t*)src, (half_t*)dst, N, C, H, W, b, Cpad);
+        hipLaunchKernelGGL((nchw_to_nhwc_s2d_kernel<half_t, half_t>), g, blk, 0, st, (const half_t*)src, (half_t*)dst, N, C, H, W, b, Cpad, cb);
     else
-        hipLaunchKernelGGL((nchw_to_nhwc_s2d_kernel<half_t, float>), g, blk, 0, st, (const half_t*)src, (float*)dst, N, C, H, W, b, Cpad);
+        hipLaunchKernelGGL((nchw_to_nhwc_s2d_kernel<half_t, float>), g, blk, 0, st, (const half_t*)src, (float*)dst, N, C, H, W, b, Cpad, cb);
     return check_launch("nchw_to_nhwc_s2d");
 }
 

@@ -1,3 +1,2 @@
-timeout -k 10 300 python3 tools/layer_times.py vit_b16 256 > gpurun_out/layers_vit_b16.txt 2>&1
-timeout -k 10 300 python3 tools/layer_times.py swin_b 128 > gpurun_out/layers_swin_b.txt 2>&1
-tail -2 gpurun_out/layers_swin_b.txt
+timeout -k 10 300 python -m pytest tests/test_conv_gpu.py tests/test_resnet_gpu.py tests/test_vit_gpu.py -m gpu -q -x 2>&1 | tail -3
+timeout -k 10 200 python tools/layer_times.py resnet50 256 2>&1 | tail -1
