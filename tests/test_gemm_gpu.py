@@ -95,3 +95,42 @@ def test_auto_dispatch_tail_split(dev, force_tile):
     # 1280 rows to small tiles; the seam must be invisible
     force_tile(None)
     run_linear(dev, torch.float16, 50432, 768, 3072, act=E.ACT_GELU, seed=7)
+
+
+# ---- LayerNorm folded into the following Linear (tlxmi_row_stats + tlxmi_linear_ln)
+@pytest.mark.parametrize("act", [E.ACT_NONE, E.ACT_GELU], ids=["none", "gelu"])
+@pytest.mark.parametrize("shape", [(197 * 3, 768, 2304), (300, 192, 576), (1000, 128, 512), (77, 384, 1536)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_linear_ln(dev, shape, act):
+    import torch.nn.functional as F
+    M, K, Cout = shape
+    rng = np.random.default_rng(21)
+    x = q16(rnd(rng, (M, K)) * 1.5 + rnd(rng, (M, 1)) * 0.7)         # rows with a non-zero mean
+    w = rnd(rng, (Cout, K), (1.0 / K) ** 0.5)
+    b = rnd(rng, (Cout,), 0.2)
+    gamma = torch.from_numpy(rng.uniform(0.5, 1.5, K).astype(np.float32))
+    beta = rnd(rng, (K,), 0.3)
+    eps = 1e-6
+    want = F.linear(F.layer_norm(x, (K,), gamma, beta, eps), w, b)    # vision_transformer.py:144-159 on torch-CPU fp32
+    if act == E.ACT_GELU:
+        want = F.gelu(want)
+    prep = E.LinearLN(w.to(dev), b.to(dev), gamma.to(dev), beta.to(dev), torch.float16)
+    got = E.linear_ln(x.half().to(dev), prep, eps, act)
+    torch.cuda.synchronize()
+    # the fused form rounds W*gamma to fp16 (the two-launch form rounds LN(x) instead): same size of error
+    torch.testing.assert_close(got.float().cpu(), want, atol=6e-3, rtol=6e-3)
+
+
+def test_row_stats(dev):
+    rng = np.random.default_rng(22)
+    x = q16(rnd(rng, (1000, 768)) * 2.0 + 0.5)
+    stats = torch.empty((1000, 2), dtype=torch.float32, device=dev)
+    from tlxcv_amd import _lib
+    import ctypes as C
+    xd = x.half().to(dev)
+    _lib.call("tlxmi_row_stats", C.c_void_p(xd.data_ptr()), 0, 1000, 768, 768, C.c_float(1e-5), C.c_void_p(stats.data_ptr()), None)
+    torch.cuda.synchronize()
+    mean = x.mean(1)
+    rstd = 1.0 / torch.sqrt(x.var(1, unbiased=False) + 1e-5)
+    torch.testing.assert_close(stats[:, 0].cpu(), rstd, atol=1e-5, rtol=1e-5)
+    torch.testing.assert_close(stats[:, 1].cpu(), -mean * rstd, atol=1e-5, rtol=1e-5)

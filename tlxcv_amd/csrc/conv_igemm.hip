@@ -662,6 +662,7 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
     if (best >= 5) {
         Gemm256Args g;
         g.debug = 0;
+        g.rowstats = nullptr;
         g.x = a.x; g.w = a.w; g.y = a.y; g.scale = a.scale; g.shift = a.shift; g.res = a.res;
         g.M = a.M; g.Cout = a.Cout; g.x_ld = a.x_ld; g.y_ld = a.y_ld; g.res_ld = a.res_ld;
         g.kchunks = a.kchunks; g.ksteps = a.Kp_bytes / 64; g.Kp_bytes = a.Kp_bytes;
@@ -754,6 +755,41 @@ extern "C" int tlxmi_conv2d(const tlxmi_conv2d_desc* d, const void* x, const voi
     const int rc = d->dtype == TLXMI_F16 ? dispatch<half_t>(a, as_stream(stream)) : dispatch<float>(a, as_stream(stream));
     if (rc != TLXMI_OK) return rc;
     return check_launch("conv2d");
+}
+
+// LayerNorm + Linear in one launch (vision_transformer.py:144-159 norm1 -> attn.qkv, norm2 -> mlp.fc1;
+// swin_transformer.py:258-300): with W' = W * gamma (packed), c1[n] = sum_k W'[n][k], c2[n] = bias[n] + sum_k W[n][k] * beta[k]
+// and the row statistics (a, b) = (rstd, -mean * rstd) of tlxmi_row_stats,
+//     Linear(LN(x))[m][n] = a[m] * (x . W'[n]) + b[m] * c1[n] + c2[n]
+// so the normalised activations are never written: the GEMM reads the raw rows, the epilogue applies the row
+// affine.  Runs on the 256 x 256 GEMM kernel (gemm_pp.hip); shapes it does not take return UNSUPPORTED and the
+// caller keeps tlxmi_layernorm + tlxmi_conv2d.
+extern "C" int tlxmi_linear_ln(int dtype, int64_t rows, int K, int Cout, int x_ld, int y_ld, const void* x,
+                               const void* w_packed, const float* c1, const float* c2, const float* rowstats, int act,
+                               void* y, void* stream) {
+    TLXMI_REQUIRE(x && w_packed && y && c1 && c2 && rowstats, TLXMI_ERR_BAD_ARG, "linear_ln: null buffer");
+    TLXMI_REQUIRE(dtype == TLXMI_F16 || dtype == TLXMI_F32, TLXMI_ERR_BAD_ARG, "linear_ln: bad dtype %d", dtype);
+    TLXMI_REQUIRE(rows > 0 && K > 0 && Cout > 0 && x_ld >= K && y_ld >= Cout, TLXMI_ERR_BAD_ARG, "linear_ln: bad extent");
+    TLXMI_REQUIRE(act >= TLXMI_ACT_NONE && act <= TLXMI_ACT_SILU, TLXMI_ERR_BAD_ARG, "linear_ln: bad act %d", act);
+    const int es = (int)elt_size(dtype);
+    TLXMI_REQUIRE((K * es) % 16 == 0 && (x_ld * es) % 16 == 0 && (y_ld * es) % 16 == 0 && aligned16(x) && aligned16(w_packed) && aligned16(y),
+                  TLXMI_ERR_ALIGNMENT, "linear_ln: rows must be whole 16-byte chunks");
+    const long long xb = (long long)rows * x_ld * es, yb = (long long)rows * y_ld * es;
+    const int kchunks = K * es / 16, ktiles = (kchunks + 7) / 8;
+    if (!(Cout % 8 == 0 && Cout >= 64 && ktiles >= 2 && xb < (1ll << 31) && yb < (1ll << 31) && rows < (1ll << 31)))
+        return fail(TLXMI_ERR_UNSUPPORTED, "linear_ln: shape %lld x %d -> %d is outside the 256 x 256 GEMM kernel", (long long)rows, K, Cout);
+    Gemm256Args g;
+    g.debug = 0;
+    g.x = (const char*)x; g.w = (const char*)w_packed; g.y = (char*)y; g.scale = c1; g.shift = c2; g.res = nullptr;
+    g.rowstats = rowstats;
+    g.M = (int)rows; g.Cout = Cout; g.x_ld = x_ld; g.y_ld = y_ld; g.res_ld = 0;
+    g.kchunks = kchunks; g.Kp_bytes = ktiles * 128; g.ksteps = ktiles;
+    g.act = act; g.act_param = 0.f; g.flags = 0; g.mtiles = g.ntiles = 0; g.gn = 1;
+    g.x_bytes = (unsigned)xb; g.y_bytes = (unsigned)yb; g.res_bytes = 0;
+    g.w_bytes = (unsigned)(((size_t)(Cout + 127) / 128 * 128) * (size_t)g.Kp_bytes);
+    const int rc = launch_gemm_pp(dtype, g, as_stream(stream));
+    if (rc != TLXMI_OK) return rc;
+    return check_launch("linear_ln");
 }
 
 // ------------------------------------------------------------------------------------------

@@ -11,6 +11,7 @@ struct Gemm256Args {
     const float* scale;
     const float* shift;
     const char* res;
+    const float* rowstats;   // [M][2] per-row (a, b): y = act(acc * a + b * scale[n] + shift[n]) (LayerNorm folded into the Linear)
     int M, Cout, x_ld, y_ld, res_ld;
     int kchunks;   // true 16-byte chunks per row
     int ksteps;    // 64-byte steps (packed pitch / 64)

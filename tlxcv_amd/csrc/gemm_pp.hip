@@ -159,7 +159,16 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
         if (a.scale) sc_t = a.scale[ch];
         if (a.shift) sh_t = a.shift[ch];
     }
-    __builtin_amdgcn_sched_barrier(0);   // these two loads are older than every DMA: their wait leaves the DMAs in flight
+    // row statistics of the wave's 8 pixel sub-tiles (LayerNorm folded in): loaded here, used in the epilogue
+    float2 rowab[2][4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int pi = 0; pi < 4; ++pi) {
+            const int m = bm0 + 128 * h + 64 * wr + 16 * pi + (lane & 15);
+            rowab[h][pi] = (a.rowstats && m < a.M) ? *reinterpret_cast<const float2*>(a.rowstats + 2 * (size_t)m) : make_float2(1.f, 0.f);
+        }
+    __builtin_amdgcn_sched_barrier(0);   // these loads are older than every DMA: their wait leaves the DMAs in flight
     stage_x(0, 0);
     stage_w(0, 0);
     stage_w(1, 0);
@@ -253,10 +262,19 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
                 for (int pi = 0; pi < 4; ++pi) {
                     const int m = bm0 + 128 * h + 64 * wr + pi * 16 + px;
                     float v[8], rv[8];
+                    if (a.rowstats) {   // LayerNorm folded in: row scale, row offset times the filter-row sums, shift
+                        const float2 ab = rowab[h][pi];
 #pragma unroll
-                    for (int bb = 0; bb < 4; ++bb) {
-                        v[bb] = acc[2 * g][4 * h + pi][bb] * sc[bb] + sf[bb];
-                        v[4 + bb] = acc[2 * g + 1][4 * h + pi][bb] * sc[4 + bb] + sf[4 + bb];
+                        for (int bb = 0; bb < 4; ++bb) {
+                            v[bb] = acc[2 * g][4 * h + pi][bb] * ab.x + (ab.y * sc[bb] + sf[bb]);
+                            v[4 + bb] = acc[2 * g + 1][4 * h + pi][bb] * ab.x + (ab.y * sc[4 + bb] + sf[4 + bb]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int bb = 0; bb < 4; ++bb) {
+                            v[bb] = acc[2 * g][4 * h + pi][bb] * sc[bb] + sf[bb];
+                            v[4 + bb] = acc[2 * g + 1][4 * h + pi][bb] * sc[4 + bb] + sf[4 + bb];
+                        }
                     }
                     if (a.res) {
                         if constexpr (ES == 2) {

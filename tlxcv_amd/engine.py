@@ -6,6 +6,7 @@ hands `tensor.data_ptr()` and the current HIP stream to libtlxmi.so.  Activation
 parity dtype.  There is deliberately no CPU branch: a CPU tensor raises.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -254,6 +255,58 @@ def linear(x, pk, bias=None, res=None, act=ACT_NONE, out=None):
         o4 = out.view(rows, 1, 1, pk.Cout)
     y = conv2d(x4, pk, shift=bias, res=r4, act=act, out=o4)
     return y.view(*shp[:-1], pk.Cout)
+
+
+_cus = {}
+
+
+def linear_ln_supported(K, Cout, dtype, rows=None, device=None):
+    """Shapes tlxmi_linear_ln takes (the 256 x 256 GEMM kernel); fp16 only — the fp32 parity mode keeps the
+    reference's order of operations (LayerNorm output rounded, then the Linear).  With `rows` given, also
+    requires the one-workgroup-per-CU launch to fill its last round (the fused call has no tail split):
+    measured on ViT-B/16 +1 % end to end; a 3.06-round shape (Swin-B stage 3 fc1) would lose 25 %."""
+    if os.environ.get("TLXMI_LNFUSE", "1") == "0":      # A/B aid
+        return False
+    if not (dtype == torch.float16 and Cout % 8 == 0 and Cout >= 256 and K % 8 == 0 and K * 2 >= 256):
+        return False
+    if rows is not None:
+        idx = torch.cuda.current_device() if device is None or device.index is None else device.index
+        if idx not in _cus:
+            _cus[idx] = torch.cuda.get_device_properties(idx).multi_processor_count
+        tiles = ((rows + 255) // 256) * ((Cout + 255) // 256)
+        rounds = (tiles + _cus[idx] - 1) // _cus[idx]
+        if tiles < 0.85 * rounds * _cus[idx]:
+            return False
+    return True
+
+
+class LinearLN:
+    """LayerNorm folded into the Linear that follows it (include/tlxmi.h, tlxmi_linear_ln): packed W * gamma,
+    c1 = row sums of the packed values, c2 = bias + W @ beta."""
+
+    def __init__(self, w_out_in, bias, gamma, beta, dtype):
+        w = w_out_in.detach().float()
+        g, b = gamma.detach().float().to(w.device), beta.detach().float().to(w.device)
+        wg = w * g[None, :]
+        self.pk = PackedFilter(wg.view(w.shape[0], w.shape[1], 1, 1).contiguous(), dtype)
+        self.c1 = wg.to(dtype).float().sum(dim=1).contiguous()
+        self.c2 = (w @ b + (bias.detach().float().to(w.device) if bias is not None else 0.0)).contiguous()
+        self.K, self.Cout = w.shape[1], w.shape[0]
+
+
+def linear_ln(x, prep, eps, act=ACT_NONE):
+    """act(Linear(LayerNorm(x))) for x (..., K): row statistics kernel + one GEMM on the raw rows."""
+    need_gpu(x, "input")
+    shp = x.shape
+    if not x.is_contiguous():
+        x = x.contiguous()
+    rows = x.numel() // shp[-1]
+    stats = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
+    y = torch.empty((*shp[:-1], prep.Cout), dtype=x.dtype, device=x.device)
+    _lib.call("tlxmi_row_stats", _p(x), dt_code(x.dtype), rows, prep.K, prep.K, C.c_float(eps), _p(stats), _stream())
+    _lib.call("tlxmi_linear_ln", dt_code(x.dtype), rows, prep.K, prep.Cout, prep.K, prep.Cout, _p(x), _p(prep.pk.buf),
+              _p(prep.c1), _p(prep.c2), _p(stats), act, _p(y), _stream())
+    return y
 
 
 def dwconv2d(x, w_rsc, stride=1, padding=0, dilation=1, scale=None, shift=None, act=ACT_NONE, act_param=0.0):

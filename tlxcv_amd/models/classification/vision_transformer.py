@@ -58,8 +58,9 @@ class Mlp(nn.Module):
         self.fc2 = nn.Linear(in_features=hidden_features, out_features=out_features)
         self.drop = nn.Dropout(drop)
 
-    def run(self, x, res=None):
-        h = self.fc1.run(x, act=self.act.ACT)          # bias + GELU in the GEMM epilogue
+    def run(self, x, res=None, norm=None):
+        # bias + GELU in the GEMM epilogue; `norm` (Block.norm2) folded into the same GEMM
+        h = self.fc1.run_ln(x, norm, act=self.act.ACT) if norm is not None else self.fc1.run(x, act=self.act.ACT)
         return self.fc2.run(h, res=res, out=res)       # bias + residual, written in place
 
     def forward(self, x):
@@ -80,8 +81,9 @@ class Attention(nn.Module):
         self.proj = nn.Linear(in_features=dim, out_features=dim)
         self.proj_drop = nn.Dropout(proj_drop)
 
-    def run(self, x, res=None):
-        qkv = self.qkv.run(x)                                          # (B, N, 3*C), packed [3][heads][hd]
+    def run(self, x, res=None, norm=None):
+        # (B, N, 3*C), packed [3][heads][hd]; `norm` (Block.norm1) folded into the qkv GEMM
+        qkv = self.qkv.run_ln(x, norm) if norm is not None else self.qkv.run(x)
         a = E.attention(qkv, self.num_heads, self.scale)               # softmax(q k^T * scale) v, heads merged
         return self.proj.run(a, res=res, out=res)
 
@@ -111,8 +113,8 @@ class Block(nn.Module):
 
     def run_inplace(self, x):
         """x (B, N, C) engine dtype, updated in place: x += attn(norm1(x)); x += mlp(norm2(x))."""
-        self.attn.run(self.norm1(x), res=x)
-        self.mlp.run(self.norm2(x), res=x)
+        self.attn.run(x, res=x, norm=self.norm1)
+        self.mlp.run(x, res=x, norm=self.norm2)
         return x
 
     def forward(self, x):
