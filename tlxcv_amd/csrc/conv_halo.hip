@@ -13,9 +13,11 @@
 //     K slice (tap s .. s+S-1, all channels) of filter row r is one contiguous span starting at pixel (y+r, x);
 //   * the filters live in registers: a wave owns 32 output channels, 2 x (R*S*C*2/64) MFMA A-fragments
 //     (144 VGPRs for 3x3x64), loaded once per workgroup — no filter traffic, no LDS reads for A;
-//   * one workgroup per CU; one barrier per tile; waves run free inside a tile (4 ds_read_b128 per 8 MFMAs),
-//     the two waves of a SIMD overlap each other.
-// 8 waves = 4 pixel groups (64 pixels = 4 MFMA sub-tiles) x 2 channel groups (32 channels = 2 sub-tiles).
+//   * one workgroup per CU, two wave groups in alternation: tile i is computed by group i & 1 (4 waves = 2
+//     pixel halves x 2 channel halves, one wave per SIMD) while the other group runs the epilogue of tile i-1
+//     and issues the row DMAs of tile i+2 — the MFMA pipe is fed by one group while the other does its VALU /
+//     memory work (with all 8 waves in lock step the pipe idled through every epilogue and staging phase:
+//     7.5 us per 256 pixels of which 4.4 in the MFMA loop).  One barrier per tile.
 // A ring row is padded to a whole number of 1-KiB DMA pieces (PWp pixels), so a piece never straddles rows:
 // row / validity / base offset of a piece are wave-uniform, a lane adds constants.  LDS lines of 128 B are
 // XOR-swizzled: physical 16-byte slot = slot ^ (line & 7), applied on the DMA source side and on the
@@ -42,11 +44,11 @@ static __device__ __forceinline__ void ch_store16_nt(__amdgpu_buffer_rsrc_t rsrc
 }
 
 // R x S taps, PB = bytes per input pixel (C * 2); S * PB must be a multiple of 64 (one MFMA K slice)
-// PI = MFMA pixel sub-tiles per wave: a tile is TP = 64 * PI consecutive pixels (8 where the filter registers
-// leave room: per-tile overhead halves)
-template <int R, int S, int PB, int PI>
+// PI = MFMA pixel sub-tiles per wave: a tile is TP = 32 * PI consecutive pixels (8 where the filter registers
+// leave room)
+template <int R, int S, int PB, int PI, bool RES>
 __global__ __launch_bounds__(512) void conv_halo_kernel(const HaloArgs a) {
-    constexpr int TP = 64 * PI;          // pixels of a tile
+    constexpr int TP = 32 * PI;          // pixels of a tile (2 pixel halves x PI sub-tiles of 16)
     constexpr int KR = S * PB / 64;      // K slices per filter row
     constexpr int NKK = R * KR;          // K slices in all
     constexpr int OOB = (int)0x80000000;
@@ -55,7 +57,8 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const HaloArgs a) {
 
     const int t = threadIdx.x, lane = t & 63;
     const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int pg = wid & 3, cg = wid >> 2;
+    const int grp = wid >> 2;                   // wave group: computes the tiles i with (i & 1) == grp
+    const int pg = wid & 1, cg = (wid >> 1) & 1;  // pixel half, channel half inside the group
     const int frow = lane & 15, fg = lane >> 4;
 
     const __amdgpu_buffer_rsrc_t xsrd = ch_srd(a.x, a.x_bytes), wsrd = ch_srd(a.w, a.w_bytes);
@@ -69,17 +72,20 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const HaloArgs a) {
     const int n_mine = t_hi - t_lo;
     const float inv_wo = 1.0f / (float)a.Wo;
 
+    // Tile geometry without integer division (a scalar s32 division is ~20 dependent instructions and a tile needs
+    // three): x / d = floor((x + 0.5) * (1 / d)) is exact for the sizes here (x < 2^20, d < 2^12).
+    const float inv_tpi = 1.0f / (float)a.tpi;
     struct Tile { int n, m0, npx, oy0, nr; bool ok; };
     auto tile_at = [&](int i) {
         Tile tl;
         tl.ok = i < n_mine;
         const int L = tl.ok ? t_lo + i : t_lo;
-        tl.n = L / a.tpi;
+        tl.n = (int)(((float)L + 0.5f) * inv_tpi);
         const int tt = L - tl.n * a.tpi;
         tl.m0 = tt * TP;
         tl.npx = a.HoWo - tl.m0 < TP ? a.HoWo - tl.m0 : TP;
-        tl.oy0 = tl.m0 / a.Wo;
-        tl.nr = (tl.m0 + tl.npx - 1) / a.Wo - tl.oy0 + R;
+        tl.oy0 = (int)(((float)tl.m0 + 0.5f) * inv_wo);
+        tl.nr = (int)(((float)(tl.m0 + tl.npx - 1) + 0.5f) * inv_wo) - tl.oy0 + R;
         return tl;
     };
 
@@ -94,8 +100,9 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const HaloArgs a) {
     const int row_bytes = a.PWp << PSH;
     const int rmask = a.nring - 1;                    // nring is a power of two
     // rows [lo, hi) of image n -> ring slots slot0, slot0+1, ... (mod nring); rows outside the image are zero rows
+    const int w4 = wid & 3, py_w = w4 / PR, pc_w = w4 - py_w * PR;
     auto load_rows = [&](int n, int lo, int hi, int slot0) {
-        int py = wid / PR, pc = wid - py * PR;       // wave `wid` takes pieces wid, wid + 8, ...
+        int py = py_w, pc = pc_w;                     // wave w of the staging group takes pieces w, w + 4, ...
         while (py < hi - lo) {
             const int iy = lo + py;
             const int x0 = pc * PPP - a.pw;           // input column of the piece's first pixel
@@ -103,14 +110,14 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const HaloArgs a) {
             const bool in = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
             const int rowoff = ((n * a.H + iy) * a.W + x0) * a.x_ld * 2;
             ch_dma16(xsrd, smem + ((slot0 + py) & rmask) * row_bytes + (pc << 10), in ? rowoff + loff : OOB);
-            pc += 8;
+            pc += 4;
             while (pc >= PR) { pc -= PR; ++py; }
         }
     };
     // ring state: `cursor` = next free slot; rows [.., have_hi) of image `img_ld` are loaded, row base_iy_ld sits in
     // slot base_slot_ld.  The tile being computed may still belong to the image before (cur_base_*).
     int cursor = 0, img_ld = -1, have_hi = 0, base_iy_ld = 0, base_slot_ld = 0;
-    auto prefetch = [&](const Tile& tl) {
+    auto prefetch = [&](const Tile& tl, bool issue) {   // every wave tracks the ring; only the staging group issues
         if (!tl.ok) return;
         const int iy0 = tl.oy0 - a.ph;
         int lo = have_hi;
@@ -122,7 +129,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const HaloArgs a) {
         }
         const int hi = iy0 + tl.nr;
         if (hi > lo) {
-            load_rows(tl.n, lo, hi, cursor);
+            if (issue) load_rows(tl.n, lo, hi, cursor);
             cursor = (cursor + hi - lo) & rmask;
             have_hi = hi;
         }
@@ -131,7 +138,6 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const HaloArgs a) {
     // ---- filters and scale / shift of a channel tile -> registers.  MFMA D row i of sub-tile ci is channel
     // 8*(i>>2) + 4*ci + (i&3) of the wave's 32, so that lane group g owns channels 8g .. 8g+7 (epilogue).
     u32x4 wreg[2][NKK];
-    float sc[8], sf[8];
     auto load_filters = [&](int nt) {
         const int cbase = nt * 64 + cg * 32;
 #pragma unroll
@@ -141,159 +147,179 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const HaloArgs a) {
 #pragma unroll
             for (int kk = 0; kk < NKK; ++kk) wreg[ci][kk] = ch_load16(wsrd, woff + kk * 64);
         }
-        const int ch0 = cbase + 8 * fg;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int ch = ch0 + e < a.Cout ? ch0 + e : a.Cout - 1;
-            sc[e] = a.scale ? a.scale[ch] : 1.f;
-            sf[e] = a.shift ? a.shift[ch] : 0.f;
+        // scale / shift of the launch's 64 channels -> LDS table behind the ring (read back in the epilogues)
+        if (t < 64) {
+            const int ch = nt * 64 + t < a.Cout ? nt * 64 + t : a.Cout - 1;
+            float* tb = reinterpret_cast<float*>(smem + a.nring * row_bytes);
+            tb[t] = a.scale ? a.scale[ch] : 1.f;
+            tb[64 + t] = a.shift ? a.shift[ch] : 0.f;
         }
     };
 
-    Tile cur = tile_at(0);
-    prefetch(cur);
-    int cur_base_iy = base_iy_ld, cur_base_slot = base_slot_ld;
+    // ---- prologue: rows of tiles 0 (group 0 issues) and 1 (group 1), filters; everything landed before the loop
+    // (a wait on a filter register inside it would also drain row DMAs and stores: one in-order counter; the
+    // builtin, not inline asm, so that the compiler's own wait insertion sees it)
+    int q0_iy, q0_slot, q1_iy = 0, q1_slot = 0, q2_iy = 0, q2_slot = 0;   // ring mapping of tiles p, p+1, p+2
+    Tile tprev = tile_at(0), tcur = tprev, tnx1 = tile_at(1);   // tiles p-1, p, p+1 of phase p (each computed once)
+    prefetch(tcur, grp == 0);
+    q0_iy = base_iy_ld; q0_slot = base_slot_ld;
+    prefetch(tnx1, grp == 1);
+    q1_iy = base_iy_ld; q1_slot = base_slot_ld;
     load_filters(a.nt);
-    // everything above has landed before the loop: no wait on a filter register is left inside it (a wait
-    // there would also drain the row DMAs and the stores of the previous tile — one in-order counter).
-    // The builtin, not inline asm: the compiler's own wait insertion must see this wait.
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
     __builtin_amdgcn_s_barrier();
 
     const bool res_after = (a.flags & TLXMI_EPI_RES_AFTER_ACT) != 0;
-    for (int i = 0; i < n_mine; ++i) {
-        // rows the next tile adds (a new image: all of its rows) go to the slots after the newest row: every wave
-        // is past the last reader of what they overwrite (barrier below), and advance + rows of this tile <= nring
-        const Tile nxt = tile_at(i + 1);
-        if (!(a.debug & 1)) prefetch(nxt);
+    const int ch0 = a.nt * 64 + cg * 32 + 8 * fg;     // lane (g = fg, px = frow) owns channels ch0 .. ch0+7
+    const bool chok = ch0 < a.Cout;                   // Cout is a multiple of 8 on this path
+    f32x4 acc[2][PI];
 
-        // ring slot (for filter row 0) and byte inside the row of this lane's pixel of each sub-tile
-        int sq[PI], bx[PI];
+    // phase p: group p & 1 computes tile p; the other group finishes tile p-1 and stages the rows of tile p+2
+    for (int p = 0; p <= n_mine; ++p) {
+        const Tile nx2 = tile_at(p + 2);
+        if (grp == (p & 1)) {
+            prefetch(nx2, false);
+            if (p < n_mine) {
+                const Tile cur = tcur;
+                // ring slot (for filter row 0) and byte inside the row of this lane's pixel of each sub-tile
+                int sq[PI], bx[PI];
 #pragma unroll
-        for (int pi = 0; pi < PI; ++pi) {
-            int pt = pg * (16 * PI) + pi * 16 + frow;
-            pt = pt < cur.npx ? pt : cur.npx - 1;      // pixels past the tile read a valid row, never stored
-            const int m = cur.m0 + pt;
-            const int oy = (int)(((float)m + 0.5f) * inv_wo);
-            const int ox = m - oy * a.Wo;
-            sq[pi] = cur_base_slot + (oy - a.ph - cur_base_iy);
-            bx[pi] = (ox << PSH) + fg * 16;
-        }
-        const char* pb = smem;
-        f32x4 acc[2][PI];
-#pragma unroll
-        for (int ci = 0; ci < 2; ++ci)
-#pragma unroll
-            for (int pi = 0; pi < PI; ++pi) acc[ci][pi] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int r = 0; r < ((a.debug & 4) ? 1 : R); ++r) {
-            int bq[PI];
-#pragma unroll
-            for (int pi = 0; pi < PI; ++pi) bq[pi] = ((sq[pi] + r) & rmask) * row_bytes + bx[pi];
-            if constexpr (PB == 128) {
-                // one pixel = one 128-byte line = two K slices: the swizzle is computed once per line
-#pragma unroll
-                for (int sx = 0; sx < S; ++sx) {
-                    u32x4 xf[2][PI];
-#pragma unroll
-                    for (int pi = 0; pi < PI; ++pi) {
-                        const int b = bq[pi] + sx * 128;
-                        const int phys = b ^ (((b >> 7) & 7) << 4);
-                        xf[0][pi] = *reinterpret_cast<const u32x4*>(pb + phys);
-                        xf[1][pi] = *reinterpret_cast<const u32x4*>(pb + (phys ^ 64));
-                    }
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-#pragma unroll
-                        for (int pi = 0; pi < PI; ++pi)
-#pragma unroll
-                            for (int ci = 0; ci < 2; ++ci)
-                                acc[ci][pi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
-                                    __builtin_bit_cast(half8v, wreg[ci][r * KR + 2 * sx + j]), __builtin_bit_cast(half8v, xf[j][pi]), acc[ci][pi], 0, 0, 0);
+                for (int pi = 0; pi < PI; ++pi) {
+                    int pt = pg * (16 * PI) + pi * 16 + frow;
+                    pt = pt < cur.npx ? pt : cur.npx - 1;      // pixels past the tile read a valid row, never stored
+                    const int m = cur.m0 + pt;
+                    const int oy = (int)(((float)m + 0.5f) * inv_wo);
+                    const int ox = m - oy * a.Wo;
+                    sq[pi] = q0_slot + (oy - a.ph - q0_iy);
+                    bx[pi] = (ox << PSH) + fg * 16;
                 }
-            } else {
+                const char* pb = smem;
 #pragma unroll
-                for (int kr = 0; kr < KR; ++kr) {
-                    u32x4 xf[PI];
+                for (int ci = 0; ci < 2; ++ci)
 #pragma unroll
-                    for (int pi = 0; pi < PI; ++pi) {
-                        const int b = bq[pi] + kr * 64;
-                        const int phys = b ^ (((b >> 7) & 7) << 4);
-                        xf[pi] = *reinterpret_cast<const u32x4*>(pb + phys);
+                    for (int pi = 0; pi < PI; ++pi) acc[ci][pi] = f32x4{0.f, 0.f, 0.f, 0.f};
+                // K slices in order (filter row r, slice kr of its S*PB bytes), software-pipelined over two fragment
+                // buffers: only one wave per SIMD computes, so the reads of slice k+1 are in flight under the MFMAs
+                // of slice k.  128-byte pixels: the two slices of a line differ by an XOR of 64 in the address.
+                u32x4 xf[2][PI];
+                int phys[PI];
+                auto fetch = [&](auto k_tag, u32x4 (&dst)[PI]) {
+                    constexpr int K = decltype(k_tag)::value, r = K / KR, kr = K % KR;
+                    if constexpr (PB == 128) {
+                        if constexpr ((kr & 1) == 0) {
+#pragma unroll
+                            for (int pi = 0; pi < PI; ++pi) {
+                                const int b = ((sq[pi] + r) & rmask) * row_bytes + bx[pi] + (kr >> 1) * 128;
+                                phys[pi] = b ^ (((b >> 7) & 7) << 4);
+                                dst[pi] = *reinterpret_cast<const u32x4*>(pb + phys[pi]);
+                            }
+                        } else {
+#pragma unroll
+                            for (int pi = 0; pi < PI; ++pi) dst[pi] = *reinterpret_cast<const u32x4*>(pb + (phys[pi] ^ 64));
+                        }
+                    } else {
+#pragma unroll
+                        for (int pi = 0; pi < PI; ++pi) {
+                            const int b = ((sq[pi] + r) & rmask) * row_bytes + bx[pi] + kr * 64;
+                            dst[pi] = *reinterpret_cast<const u32x4*>(pb + (b ^ (((b >> 7) & 7) << 4)));
+                        }
                     }
+                };
+                auto mma = [&](auto k_tag, const u32x4 (&src)[PI]) {
+                    constexpr int K = decltype(k_tag)::value;
 #pragma unroll
                     for (int pi = 0; pi < PI; ++pi)
 #pragma unroll
                         for (int ci = 0; ci < 2; ++ci)
                             acc[ci][pi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
-                                __builtin_bit_cast(half8v, wreg[ci][r * KR + kr]), __builtin_bit_cast(half8v, xf[pi]), acc[ci][pi], 0, 0, 0);
+                                __builtin_bit_cast(half8v, wreg[ci][K]), __builtin_bit_cast(half8v, src[pi]), acc[ci][pi], 0, 0, 0);
+                };
+                fetch(IntTag<0>{}, xf[0]);
+                auto steps = [&](auto self, auto k_tag) -> void {
+                    constexpr int K = decltype(k_tag)::value;
+                    if constexpr (K < NKK) {
+                        if constexpr (K + 1 < NKK) fetch(IntTag<K + 1>{}, xf[(K + 1) & 1]);
+                        mma(k_tag, xf[K & 1]);
+                        self(self, IntTag<K + 1>{});
+                    }
+                };
+                steps(steps, IntTag<0>{});
+            }
+        } else {
+            // rows of tile p+2 first (its DMAs are the oldest operations of this phase), then the epilogue
+            if (!(a.debug & 1)) prefetch(nx2, true); else prefetch(nx2, false);
+            if (p >= 1) {
+                const Tile cur = tprev;
+                // residual loads (four sub-tiles at a time) before the stores of those sub-tiles: a load behind a
+                // store would wait for it (in-order counter)
+                u32x4 rr[4];
+#pragma unroll
+                for (int pi = 0; pi < PI; ++pi) {
+                    if (RES && (pi & 3) == 0) {
+#pragma unroll
+                        for (int p2 = 0; p2 < 4; ++p2) {
+                            const int pt2 = pg * (16 * PI) + (pi + p2) * 16 + frow;
+                            const int mg2 = cur.n * a.HoWo + cur.m0 + pt2;
+                            rr[p2] = ch_load16(rsrd, (chok && pt2 < cur.npx) ? (mg2 * a.res_ld + ch0) * 2 : OOB);
+                        }
+                    }
+                    const int pt = pg * (16 * PI) + pi * 16 + frow;
+                    const bool ok = chok && pt < cur.npx;
+                    const int mg = cur.n * a.HoWo + cur.m0 + pt;
+                    float v[8];
+                    {
+                        const float* tb = reinterpret_cast<const float*>(smem + a.nring * row_bytes) + cg * 32 + 8 * fg;
+                        const f32x4 s0 = *reinterpret_cast<const f32x4*>(tb), s1 = *reinterpret_cast<const f32x4*>(tb + 4);
+                        const f32x4 h0 = *reinterpret_cast<const f32x4*>(tb + 64), h1 = *reinterpret_cast<const f32x4*>(tb + 68);
+#pragma unroll
+                        for (int bb = 0; bb < 4; ++bb) {
+                            v[bb] = acc[0][pi][bb] * s0[bb] + h0[bb];
+                            v[4 + bb] = acc[1][pi][bb] * s1[bb] + h1[bb];
+                        }
+                    }
+                    float rv[8];
+                    if constexpr (RES) {
+                        const half8v hv = __builtin_bit_cast(half8v, rr[pi & 3]);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) rv[e] = (float)hv[e];
+                        if (!res_after) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] += rv[e];
+                        }
+                    }
+                    if (a.act == TLXMI_ACT_RELU) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                    } else if (a.act == TLXMI_ACT_LEAKY) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = v[e] >= 0.f ? v[e] : v[e] * a.act_param;
+                    } else if (a.act == TLXMI_ACT_RELU6) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = fminf(fmaxf(v[e], 0.f), 6.f);
+                    } else if (a.act == TLXMI_ACT_HARDSWISH) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = v[e] * fminf(fmaxf(v[e] + 3.f, 0.f), 6.f) * (1.f / 6.f);
+                    }
+                    if (RES && res_after) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += rv[e];
+                    }
+                    half8v hv;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) hv[e] = (half_t)v[e];
+                    ch_store16_nt(ysrd, __builtin_bit_cast(u32x4, hv), (ok && !(a.debug & 2)) ? (mg * a.y_ld + ch0) * 2 : OOB);
                 }
             }
+            // the rows of tile p+2 have landed; the PI stores just issued (and nothing else) may stay in flight
+            if (p >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PI) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        // the next tile's rows have landed (these DMAs are older than anything else this wave has in flight except
-        // the previous tile's stores); after the barrier nobody reads the rows only this tile needed
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        q2_iy = base_iy_ld; q2_slot = base_slot_ld;
+        // after the barrier: nobody reads the rows only tile p needed, tile p+2's rows are visible to every wave
         __builtin_amdgcn_s_barrier();
-
-        // ---- epilogue: lane (g = fg, px = frow) owns channels 64nt + 32cg + 8g .. +7 of pixel 64pg + 16pi + px
-        const int ch0 = a.nt * 64 + cg * 32 + 8 * fg;
-        const bool chok = ch0 < a.Cout;     // Cout is a multiple of 8 on this path
-        // residual loads (four sub-tiles at a time) before the stores of those sub-tiles: a load behind a store
-        // would wait for it (in-order counter)
-        u32x4 rr[4];
-#pragma unroll
-        for (int pi = 0; pi < PI; ++pi) {
-            if ((pi & 3) == 0 && a.res) {
-#pragma unroll
-                for (int p2 = 0; p2 < 4; ++p2) {
-                    const int pt2 = pg * (16 * PI) + (pi + p2) * 16 + frow;
-                    const int mg2 = cur.n * a.HoWo + cur.m0 + pt2;
-                    rr[p2] = ch_load16(rsrd, (chok && pt2 < cur.npx) ? (mg2 * a.res_ld + ch0) * 2 : OOB);
-                }
-            }
-            const int pt = pg * (16 * PI) + pi * 16 + frow;
-            const bool ok = chok && pt < cur.npx;
-            const int mg = cur.n * a.HoWo + cur.m0 + pt;
-            float v[8];
-#pragma unroll
-            for (int bb = 0; bb < 4; ++bb) {
-                v[bb] = acc[0][pi][bb] * sc[bb] + sf[bb];
-                v[4 + bb] = acc[1][pi][bb] * sc[4 + bb] + sf[4 + bb];
-            }
-            float rv[8];
-            if (a.res) {
-                const half8v hv = __builtin_bit_cast(half8v, rr[pi & 3]);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) rv[e] = (float)hv[e];
-                if (!res_after) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += rv[e];
-                }
-            }
-            if (a.act == TLXMI_ACT_RELU) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-            } else if (a.act == TLXMI_ACT_LEAKY) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = v[e] >= 0.f ? v[e] : v[e] * a.act_param;
-            } else if (a.act == TLXMI_ACT_RELU6) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = fminf(fmaxf(v[e], 0.f), 6.f);
-            } else if (a.act == TLXMI_ACT_HARDSWISH) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = v[e] * fminf(fmaxf(v[e] + 3.f, 0.f), 6.f) * (1.f / 6.f);
-            }
-            if (a.res && res_after) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += rv[e];
-            }
-            half8v hv;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) hv[e] = (half_t)v[e];
-            ch_store16_nt(ysrd, __builtin_bit_cast(u32x4, hv), (ok && !(a.debug & 2)) ? (mg * a.y_ld + ch0) * 2 : OOB);
-        }
-        cur = nxt;
-        if (cur.ok && cur.n == img_ld) { cur_base_iy = base_iy_ld; cur_base_slot = base_slot_ld; }
+        q0_iy = q1_iy; q0_slot = q1_slot;
+        q1_iy = q2_iy; q1_slot = q2_slot;
+        tprev = tcur; tcur = tnx1; tnx1 = nx2;
     }
 }
 
@@ -303,9 +329,9 @@ bool conv_halo_act_ok(int act) {
            act == TLXMI_ACT_HARDSWISH;
 }
 
-template <int R, int S, int PB, int PI> static int launch_halo_t(const HaloArgs& a, hipStream_t st, int cus) {
-    const void* fn = reinterpret_cast<const void*>(&conv_halo_kernel<R, S, PB, PI>);
-    const size_t lds = (size_t)a.nring * a.PWp * PB;
+template <int R, int S, int PB, int PI, bool RES> static int launch_halo_r(const HaloArgs& a, hipStream_t st, int cus) {
+    const void* fn = reinterpret_cast<const void*>(&conv_halo_kernel<R, S, PB, PI, RES>);
+    const size_t lds = (size_t)a.nring * a.PWp * PB + 512;   // ring + scale / shift table
     static bool raised = false;
     if (!raised) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -328,10 +354,14 @@ template <int R, int S, int PB, int PI> static int launch_halo_t(const HaloArgs&
     return TLXMI_OK;
 }
 
+template <int R, int S, int PB, int PI> static int launch_halo_t(const HaloArgs& a, hipStream_t st, int cus) {
+    return a.res ? launch_halo_r<R, S, PB, PI, true>(a, st, cus) : launch_halo_r<R, S, PB, PI, false>(a, st, cus);
+}
+
 // Shapes with a compiled instantiation (R, S, bytes per pixel); returns the pixels of a tile, 0 if none
 int conv_halo_tile_pixels(int R, int S, int PB) {
-    if (R == 3 && S == 3 && PB == 128) return 256;
-    if ((R == 3 && S == 3 && PB == 64) || (R == 4 && S == 4 && PB == 32) || (R == 2 && S == 2 && PB == 32)) return 512;
+    if (R == 3 && S == 3 && PB == 128) return 128;
+    if ((R == 3 && S == 3 && PB == 64) || (R == 4 && S == 4 && PB == 32) || (R == 2 && S == 2 && PB == 32)) return 256;
     return 0;
 }
 

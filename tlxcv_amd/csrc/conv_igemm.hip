@@ -564,13 +564,13 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
             const int span = (a.Wo - 1 + tp - 1) / a.Wo + 1;       // output rows a tile of tp consecutive pixels can touch
             const int ppp = 1024 / PB;
             h.PWp = (h.PW + ppp - 1) / ppp * ppp;
-            // ring: the rows of a tile (span + R - 1) plus the rows the next tile adds (<= span, or a whole first
-            // tile of the next image) must fit
+            // ring: tile p is read while tile p+1 is resident and tile p+2 lands — the rows of a tile (span + R - 1)
+            // plus those two later tiles add (<= span each, or a whole first tile of the next image) must fit
             h.nring = 8;
-            while (h.nring < 2 * (span + a.R - 1)) h.nring *= 2;
+            while (h.nring < 2 * (span + a.R - 1) + span) h.nring *= 2;
             h.x_bytes = a.x_bytes; h.w_bytes = a.w_bytes; h.y_bytes = a.y_bytes;
             h.res_bytes = a.res ? (unsigned)((long long)a.M * a.res_ld * 2) : 0u;
-            if ((long)h.nring * h.PWp * PB <= 160 * 1024) return launch_conv_halo(h, st, num_cus());
+            if ((long)h.nring * h.PWp * PB + 512 <= 160 * 1024) return launch_conv_halo(h, st, num_cus());
         }
     }
     struct Cand { int bm, bn; float eff; };
