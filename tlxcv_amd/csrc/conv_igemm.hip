@@ -592,11 +592,12 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
     cands[5].eff = 0.f;   // superseded by candidate 7 (same tile, antiphase wave groups); kept for A/B runs (TLXMI_TILE=5)
     if (obi >= 0.0015 || a.ktiles < 4) cands[4].eff = 0.f;
     // regimes by output bytes per FLOP (tools/ab_tiles.py sweep over the ResNet-50 / ViT-B / Swin-B layer shapes):
-    // the 256-row GEMM kernels win up to ~0.005 (256x256) / ~0.01 (256x128, two workgroups per CU); beyond that
+    // the 256-row GEMM kernels win up to ~0.005 (256x256) / ~0.02 (256x128, two workgroups per CU); beyond that
     // the layer is HBM / latency-bound and wants many small resident blocks
     if (obi >= 0.005) cands[7].eff = cands[8].eff = 0.f;
-    if (obi >= 0.010) cands[6].eff = 0.f;
-    if (obi >= 0.012) { cands[0].eff = 0.65f; cands[1].eff = 0.80f; cands[2].eff = 0.85f; cands[3].eff = 1.00f; }
+    if (obi >= 0.020) cands[6].eff = 0.f;
+    if (obi >= 0.020 || (obi >= 0.010 && a.ktiles == 1)) { cands[0].eff = 0.65f; cands[1].eff = 0.80f; cands[2].eff = 0.85f; cands[3].eff = 1.00f; }   // 64 -> 256 (+ skip) at 56x56: one K step
+    else if (obi >= 0.010) { cands[0].eff = 1.00f; cands[1].eff = 0.95f; cands[2].eff = 0.95f; cands[3].eff = 0.85f; }   // 128 -> 512 + skip at 28x28
     else if (obi >= 0.0015) { cands[0].eff = 0.85f; cands[1].eff = 0.90f; cands[2].eff = 1.00f; cands[3].eff = 0.90f; }
     if (!allow_stream) cands[7].eff = cands[8].eff = 0.f;
     // the persistent kernel hides the plain epilogue but not the GELU arithmetic (measured: fc1 of ViT-B)
