@@ -182,6 +182,18 @@ int tlxmi_layernorm(const void* x, const float* gamma, const float* beta, void* 
                     int64_t rows, int C, int x_ld, int y_ld, float eps, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * LayerNorm fused with Swin's window plumbing, SwinTransformerBlock.forward swin_transformer.py:315-335:
+ *   layernorm_window_partition: win = window_partition(roll(norm1(x), -shift))          (:315-324)
+ *   window_reverse_layernorm:   sum = res + roll(window_reverse(win), +shift); y = norm2(sum)   (:327-335)
+ * x / res / sum / y: [B][H][W][C] dense; win: [B*nW][ws*ws][C]; same index map as tlxmi_window_partition.
+ * ---------------------------------------------------------------------------------------- */
+int tlxmi_layernorm_window_partition(const void* x, const float* gamma, const float* beta, void* win, int dtype,
+                                     int B, int H, int W, int C, int ws, int shift, float eps, void* stream);
+int tlxmi_window_reverse_layernorm(const void* win, const void* res, const float* gamma, const float* beta,
+                                   void* sum, void* y, int dtype, int B, int H, int W, int C, int ws, int shift,
+                                   float eps, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * LayerNorm folded into the Linear that follows it (vision_transformer.py:144-159 norm1 -> attn.qkv,
  * norm2 -> mlp.fc1; swin_transformer.py:258-300).  tlxmi_row_stats writes stats[row] = (rstd, -mean*rstd)
  * (biased variance, eps as nn.LayerNorm); tlxmi_linear_ln computes

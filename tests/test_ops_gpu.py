@@ -153,6 +153,33 @@ def test_window_partition_reverse(dev, dtype, shift):
 
 
 @DT
+@pytest.mark.parametrize("shift", [0, 3])
+@pytest.mark.parametrize("geom", [(2, 14, 14, 128, 7), (1, 28, 56, 512, 7), (3, 7, 7, 1024, 7)], ids=lambda g: "x".join(map(str, g)))
+def test_layernorm_fused_with_window_plumbing(dev, dtype, shift, geom):
+    """norm1 + roll + window_partition, and window_reverse + roll back + residual + norm2 (swin :315-335) in one
+    pass each, against the separate steps on the CPU."""
+    import torch.nn.functional as F
+    B, H, W, C, ws = geom
+    rng = np.random.default_rng(12)
+    x = prep(rnd(rng, (B, H, W, C)) + 0.3, dtype)
+    g = torch.from_numpy(rng.uniform(0.5, 1.5, C).astype(np.float32))
+    b = rnd(rng, (C,), 0.2)
+    part = lambda t: (torch.roll(t, (-shift, -shift), (1, 2)) if shift else t).reshape(
+        B, H // ws, ws, W // ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws, C)
+    want_win = part(F.layer_norm(x, (C,), g, b, 1e-5))
+    got_win = E.layernorm_window_partition(x.to(dtype).to(dev), g.to(dev), b.to(dev), 1e-5, ws, shift)
+    torch.testing.assert_close(got_win.float().cpu(), want_win, **(dict(atol=1e-4, rtol=1e-4) if dtype == torch.float32 else dict(atol=4e-3, rtol=4e-3)))
+    # reverse: win holds partition(a); sum = x + a, y = LN(sum)
+    a = prep(rnd(rng, (B, H, W, C)), dtype)
+    win = part(a).contiguous()
+    s_got, y_got = E.window_reverse_layernorm(win.to(dtype).to(dev), x.to(dtype).to(dev), g.to(dev), b.to(dev), 1e-5, ws, shift)
+    s_want = prep(x + a, dtype)                      # the sum is stored in the engine dtype before norm2 reads it
+    torch.testing.assert_close(s_got.float().cpu(), s_want, **tol(dtype))
+    y_want = F.layer_norm(s_got.float().cpu(), (C,), g, b, 1e-5)
+    torch.testing.assert_close(y_got.float().cpu(), y_want, **(dict(atol=1e-4, rtol=1e-4) if dtype == torch.float32 else dict(atol=4e-3, rtol=4e-3)))
+
+
+@DT
 def test_patch_merge_gather(dev, dtype):
     rng = np.random.default_rng(9)
     x = prep(rnd(rng, (2, 8, 6, 16)), dtype)

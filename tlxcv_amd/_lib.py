@@ -49,6 +49,8 @@ PROTOTYPES = {
     "tlxmi_affine_act": [_vp, _vp, _vp, _vp, _vp, _i, _l, _i, _i, _i, _i, _i, _f, _u, _vp],
     "tlxmi_scale_channels": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "tlxmi_layernorm": [_vp, _vp, _vp, _vp, _i, _l, _i, _i, _i, _f, _vp],
+    "tlxmi_layernorm_window_partition": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp],
+    "tlxmi_window_reverse_layernorm": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp],
     "tlxmi_row_stats": [_vp, _i, _l, _i, _i, _f, _vp, _vp],
     "tlxmi_linear_ln": [_i, _l, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
     "tlxmi_attention": [C.POINTER(AttnDesc), _vp, _vp, _vp, _vp, _vp],

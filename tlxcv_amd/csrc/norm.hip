@@ -15,10 +15,30 @@ template <int LPR> __device__ __forceinline__ float group_sum(float v) {
     return v;
 }
 
+// Swin window map (swin_transformer.py:85-116, 317-333): image row r = (b, hs, wsft) in unshifted coordinates
+// sits at window row ((b*nW + (h/ws)*nWw + w/ws)*ws*ws + (h%ws)*ws + w%ws) with (h, w) = (hs, wsft) rolled by
+// -shift.  mode 0: none; 1: the OUTPUT row is the window row (LayerNorm + roll + window_partition in one pass);
+// 2: the INPUT row is the window row, `res` (image order) is added, the sum is written to `sum_out` (image
+// order) and normalised into y (window_reverse + roll back + residual + LayerNorm in one pass).
+struct WinMap { int mode, H, W, ws, shift; };
+__device__ __forceinline__ long win_row(const WinMap& wm, long r) {
+    const int HW = wm.H * wm.W;
+    const long b = r / HW;
+    const int p = (int)(r - b * HW);
+    const int hs = (int)(((float)p + 0.5f) * (1.0f / (float)wm.W)), wsft = p - hs * wm.W;
+    int h = hs - wm.shift, w = wsft - wm.shift;
+    if (h < 0) h += wm.H;
+    if (w < 0) w += wm.W;
+    const int nWw = wm.W / wm.ws, nW = (wm.H / wm.ws) * nWw;
+    const int wh = (int)(((float)h + 0.5f) * (1.0f / (float)wm.ws)), ww = (int)(((float)w + 0.5f) * (1.0f / (float)wm.ws));
+    return (b * nW + wh * nWw + ww) * (long)(wm.ws * wm.ws) + (h - wh * wm.ws) * wm.ws + (w - ww * wm.ws);
+}
+
 template <typename T, int NCH, int RW, int LPR>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, T* __restrict__ y, long rows,
-                                                        int C, int x_ld, int y_ld, float eps, float* __restrict__ stats) {
+                                                        int C, int x_ld, int y_ld, float eps, float* __restrict__ stats,
+                                                        const WinMap wm, const T* __restrict__ res, T* __restrict__ sum_out) {
     constexpr int V = 16 / (int)sizeof(T);
     constexpr int GPW = 64 / LPR;                    // row groups per wave
     const int lane = threadIdx.x & (LPR - 1);
@@ -28,15 +48,40 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
     // all RW x NCH 16-byte loads of this wave are issued before the first reduction: the kernel is a
     // pure HBM stream and needs the bytes in flight, not the arithmetic
     u32x4 raw[RW][NCH];
+    long wrow[RW];      // window row of image row row0 + r (modes 1, 2)
 #pragma unroll
-    for (int r = 0; r < RW; ++r)
+    for (int r = 0; r < RW; ++r) {
+        wrow[r] = (wm.mode != 0 && row0 + r < rows) ? win_row(wm, row0 + r) : 0;
+        const long srow = wm.mode == 2 ? wrow[r] : row0 + r;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int ch = lane + LPR * i;
             raw[r][i] = u32x4{0u, 0u, 0u, 0u};
             if (ch < nch && row0 + r < rows)
-                raw[r][i] = *reinterpret_cast<const u32x4*>(x + (row0 + r) * x_ld + ch * V);
+                raw[r][i] = *reinterpret_cast<const u32x4*>(x + srow * x_ld + ch * V);
         }
+    }
+    if (wm.mode == 2) {   // + residual (image order), rounded to T as the two-kernel path stores it, written out
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int ch = lane + LPR * i;
+                if (ch < nch && row0 + r < rows) {
+                    const u32x4 rv = *reinterpret_cast<const u32x4*>(res + (row0 + r) * x_ld + ch * V);
+                    if constexpr (sizeof(T) == 2) {
+                        const half8v a = __builtin_bit_cast(half8v, raw[r][i]), b = __builtin_bit_cast(half8v, rv);
+                        half8v o;
+#pragma unroll
+                        for (int e = 0; e < V; ++e) o[e] = (half_t)((float)a[e] + (float)b[e]);
+                        raw[r][i] = __builtin_bit_cast(u32x4, o);
+                    } else {
+                        raw[r][i] = __builtin_bit_cast(u32x4, __builtin_bit_cast(f32x4, raw[r][i]) + __builtin_bit_cast(f32x4, rv));
+                    }
+                    *reinterpret_cast<u32x4*>(sum_out + (row0 + r) * x_ld + ch * V) = raw[r][i];
+                }
+            }
+    }
     // gamma / beta of this lane's channels: once per wave, not once per row
     float gm[NCH][V], bt[NCH][V];
 #pragma unroll
@@ -119,12 +164,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
                     half8v h;
 #pragma unroll
                     for (int e = 0; e < V; ++e) h[e] = (half_t)o[e];
-                    *reinterpret_cast<half8v*>(y + (row0 + r) * y_ld + ch * V) = h;
+                    *reinterpret_cast<half8v*>(y + (wm.mode == 1 ? wrow[r] : row0 + r) * y_ld + ch * V) = h;
                 } else {
                     f32x4 h;
 #pragma unroll
                     for (int e = 0; e < V; ++e) h[e] = o[e];
-                    *reinterpret_cast<f32x4*>(y + (row0 + r) * y_ld + ch * V) = h;
+                    *reinterpret_cast<f32x4*>(y + (wm.mode == 1 ? wrow[r] : row0 + r) * y_ld + ch * V) = h;
                 }
             }
         }
@@ -133,13 +178,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
 
 template <typename T>
 static int launch_ln(const void* x, const float* gamma, const float* beta, void* y, long rows, int C, int x_ld,
-                     int y_ld, float eps, hipStream_t st, float* stats = nullptr) {
+                     int y_ld, float eps, hipStream_t st, float* stats = nullptr, WinMap wm = WinMap{0, 1, 1, 1, 0},
+                     const void* res = nullptr, void* sum_out = nullptr) {
     constexpr int V = 16 / (int)sizeof(T);
     const int nch = C / V;
 #define LN_CASE(n, rw, lpr)                                                                                       \
     hipLaunchKernelGGL((layernorm_kernel<T, n, rw, lpr>),                                                         \
                        dim3((unsigned)((rows + 4 * rw * (64 / lpr) - 1) / (4 * rw * (64 / lpr)))), dim3(256), 0, st, \
-                       (const T*)x, gamma, beta, (T*)y, rows, C, x_ld, y_ld, eps, stats)
+                       (const T*)x, gamma, beta, (T*)y, rows, C, x_ld, y_ld, eps, stats, wm, (const T*)res, (T*)sum_out)
     if (nch <= 16) LN_CASE(1, 4, 16);
     else if (nch <= 32) LN_CASE(1, 4, 32);
     else if (nch <= 64) LN_CASE(1, 8, 64);
@@ -179,4 +225,40 @@ extern "C" int tlxmi_row_stats(const void* x, int dt, int64_t rows, int C, int x
                   "row_stats: C=%d / stride must be whole 16-byte chunks, stats 8-byte aligned", C);
     if (dt == TLXMI_F16) return launch_ln<half_t>(x, nullptr, nullptr, const_cast<void*>(x), (long)rows, C, x_ld, x_ld, eps, as_stream(stream), stats);
     return launch_ln<float>(x, nullptr, nullptr, const_cast<void*>(x), (long)rows, C, x_ld, x_ld, eps, as_stream(stream), stats);
+}
+
+// LayerNorm fused with Swin's window plumbing (swin_transformer.py:315-335):
+//   tlxmi_layernorm_window_partition: win = window_partition(roll(LN(x), -shift))      (norm1 + :316-324)
+//   tlxmi_window_reverse_layernorm:   sum = res + roll(window_reverse(win), +shift);  y = LN(sum)   (:327-335 + norm2)
+// x / res / sum / y are [B][H][W][C] dense, win is [B*nW][ws*ws][C].
+static int check_ln_window(const char* name, int dt, int B, int H, int W, int C, int ws, int shift) {
+    TLXMI_REQUIRE(dt == TLXMI_F16 || dt == TLXMI_F32, TLXMI_ERR_BAD_ARG, "%s: bad dtype", name);
+    TLXMI_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && ws > 0 && H % ws == 0 && W % ws == 0, TLXMI_ERR_BAD_ARG,
+                  "%s: H=%d W=%d must be multiples of the window %d", name, H, W, ws);
+    TLXMI_REQUIRE(shift >= 0 && shift < ws, TLXMI_ERR_BAD_ARG, "%s: shift must be in [0, window)", name);
+    TLXMI_REQUIRE(C % (16 / (int)elt_size(dt)) == 0, TLXMI_ERR_ALIGNMENT, "%s: C=%d must be whole 16-byte chunks", name, C);
+    TLXMI_REQUIRE((long)H * W < (1l << 22), TLXMI_ERR_UNSUPPORTED, "%s: image too large for the float index math", name);
+    return TLXMI_OK;
+}
+
+extern "C" int tlxmi_layernorm_window_partition(const void* x, const float* gamma, const float* beta, void* win, int dt,
+                                                int B, int H, int W, int C, int ws, int shift, float eps, void* stream) {
+    TLXMI_REQUIRE(x && win && aligned16(x) && aligned16(win), TLXMI_ERR_BAD_ARG, "layernorm_window_partition: bad buffer");
+    if (int e = check_ln_window("layernorm_window_partition", dt, B, H, W, C, ws, shift)) return e;
+    const WinMap wm{1, H, W, ws, shift};
+    const long rows = (long)B * H * W;
+    if (dt == TLXMI_F16) return launch_ln<half_t>(x, gamma, beta, win, rows, C, C, C, eps, as_stream(stream), nullptr, wm);
+    return launch_ln<float>(x, gamma, beta, win, rows, C, C, C, eps, as_stream(stream), nullptr, wm);
+}
+
+extern "C" int tlxmi_window_reverse_layernorm(const void* win, const void* res, const float* gamma, const float* beta,
+                                              void* sum, void* y, int dt, int B, int H, int W, int C, int ws, int shift,
+                                              float eps, void* stream) {
+    TLXMI_REQUIRE(win && res && sum && y && aligned16(win) && aligned16(res) && aligned16(sum) && aligned16(y), TLXMI_ERR_BAD_ARG,
+                  "window_reverse_layernorm: bad buffer");
+    if (int e = check_ln_window("window_reverse_layernorm", dt, B, H, W, C, ws, shift)) return e;
+    const WinMap wm{2, H, W, ws, shift};
+    const long rows = (long)B * H * W;
+    if (dt == TLXMI_F16) return launch_ln<half_t>(win, gamma, beta, y, rows, C, C, C, eps, as_stream(stream), nullptr, wm, res, sum);
+    return launch_ln<float>(win, gamma, beta, y, rows, C, C, C, eps, as_stream(stream), nullptr, wm, res, sum);
 }

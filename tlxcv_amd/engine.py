@@ -439,6 +439,27 @@ def window_reverse(win, B, H, W, ws, shift, res=None):
     return y
 
 
+def layernorm_window_partition(x, gamma, beta, eps, ws, shift):
+    """(B,H,W,C) -> window_partition(roll(LayerNorm(x), -shift)) as (B*nW, ws*ws, C) in one pass."""
+    need_gpu(x, "input")
+    B, H, W, Cc = x.shape
+    y = torch.empty((B * (H // ws) * (W // ws), ws * ws, Cc), dtype=x.dtype, device=x.device)
+    _lib.call("tlxmi_layernorm_window_partition", _p(x), _p(_f32(gamma)), _p(_f32(beta)), _p(y), dt_code(x.dtype), B, H, W, Cc,
+              ws, shift, C.c_float(eps), _stream())
+    return y
+
+
+def window_reverse_layernorm(win, res, gamma, beta, eps, ws, shift):
+    """sum = res + roll(window_reverse(win), +shift); returns (sum, LayerNorm(sum)), both (B,H,W,C), in one pass."""
+    need_gpu(win, "input")
+    B, H, W, Cc = res.shape
+    s = torch.empty_like(res)
+    y = torch.empty_like(res)
+    _lib.call("tlxmi_window_reverse_layernorm", _p(win), _p(res), _p(_f32(gamma)), _p(_f32(beta)), _p(s), _p(y),
+              dt_code(win.dtype), B, H, W, Cc, ws, shift, C.c_float(eps), _stream())
+    return s, y
+
+
 def patch_merge_gather(x):
     need_gpu(x, "input")
     B, H, W, Cc = x.shape

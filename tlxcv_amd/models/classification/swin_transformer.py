@@ -6,8 +6,8 @@ hard-imports `paddle`, so it is restated from its text).  Per block the referenc
 LayerNorm -> reshape -> roll -> window_partition -> qkv Linear -> scaled q k^T + relative position
 bias (+ shift mask) -> softmax -> @v -> proj -> window_reverse -> roll back -> residual -> LayerNorm
 -> Mlp -> residual (:310-337, :192-229).  Here:
-  * roll + window_partition are one index-mapping copy, window_reverse + roll back + the residual
-    add another (tlxmi_window_partition / tlxmi_window_reverse);
+  * norm1 + roll + window_partition are one pass over the rows (tlxmi_layernorm_window_partition), and so are
+    window_reverse + roll back + the residual add + norm2 (tlxmi_window_reverse_layernorm);
   * the attention core is one fused MFMA kernel on the packed qkv matrix that adds the pre-gathered
     (heads, 49, 49) bias table and the (nW, 49, 49) shift mask in registers;
   * qkv / proj / fc1(+GELU) / fc2(+residual) are the implicit-GEMM kernel with fused epilogues;
@@ -128,11 +128,15 @@ class SwinTransformerBlock(nn.Module):
         H, W = self.input_resolution
         B, L, C = x.shape
         assert L == H * W, 'input feature has wrong size'
-        h = self.norm1(x)                                                          # :315
-        win = E.window_partition(h.view(B, H, W, C), self.window_size, self.shift_size)   # :316-324
+        # norm1 + roll + window_partition in one pass (:315-324)
+        win = E.layernorm_window_partition(x.view(B, H, W, C), self.norm1.gamma.detach(), self.norm1.beta.detach(),
+                                           self.norm1.epsilon, self.window_size, self.shift_size)
         aw = self.attn.run(win, self.attn_mask)                                    # :325
-        x = E.window_reverse(aw, B, H, W, self.window_size, self.shift_size, res=x.view(B, H, W, C)).view(B, L, C)
-        self.mlp.run(self.norm2(x), res=x)                                         # :335, in place
+        # window_reverse + roll back + residual + norm2 in one pass (:327-335)
+        x, h2 = E.window_reverse_layernorm(aw, x.view(B, H, W, C), self.norm2.gamma.detach(), self.norm2.beta.detach(),
+                                           self.norm2.epsilon, self.window_size, self.shift_size)
+        x = x.view(B, L, C)
+        self.mlp.run(h2.view(B, L, C), res=x)                                      # :335, in place
         return x
 
     def forward(self, x):

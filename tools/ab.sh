@@ -1,1 +1,2 @@
-for d in 0 8 0 8; do echo "--- TLXMI_DEBUG=$d"; TLXMI_DEBUG=$d timeout -k 10 100 python tools/conv_micro.py c3x3_56,stem 30; done
+timeout -k 10 400 python -m pytest tests/test_ops_gpu.py tests/test_models_gpu.py -m gpu -q -x -k "window or swin or layernorm" 2>&1 | tail -6
+timeout -k 10 200 python bench.py --workload swin_b --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | grep -o '"value": [0-9.]*'
