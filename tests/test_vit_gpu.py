@@ -48,3 +48,19 @@ def test_wrong_image_size_asserts(dev, fp16_mode):
     m = build("vit_base_patch16_224", 2, dev)
     with pytest.raises(AssertionError, match="doesn't match"):      # vision_transformer.py:217-219
         m(torch.zeros(1, 3, 192, 192, device=dev))
+
+
+def test_vit_384_runs_the_long_sequence_attention(dev, fp32_mode):
+    """vit_base_patch16_384 (vision_transformer.py:209, 577 tokens) against the oracle restatement, fp32."""
+    from oracle import functional as OF
+    from tlxcv_amd import models
+    m = models.vit_base_patch16_384()
+    params = seeded.fill(seeded.shapes_of(m), 3)
+    m.load_dict(params)
+    m = m.to(dev).set_eval()
+    x = torch.from_numpy(seeded.image_batch(1, 5, hw=384))
+    with torch.no_grad():
+        ref = OF.vit({k: torch.from_numpy(v) for k, v in params.items()}, x, "vit_base_patch16_384").numpy()
+    y = m(x.to(dev)).cpu().numpy()
+    assert np.abs(y - ref).max() <= 1e-4
+    assert (y.argmax(1) == ref.argmax(1)).all()

@@ -6,11 +6,14 @@
 //   qkv [B][N][3][heads][hd]  ->  out [B][N][heads*hd]
 //   out[b,i,h,:] = sum_j softmax_j(scale * q_i.k_j + bias[h,i,j] + mask[b % nW,i,j]) v_j
 //
-// Two kernels:
+// Three kernels:
 //   attn_rows_kernel  — exact-fp32 arithmetic, any hd <= 128, N <= 256: K and V of one (b, head)
 //                       staged once in LDS as fp32, one wave per query row, wave-shuffle softmax.
 //                       This is the fp32 parity path and the generic fallback.
-//   attn_mfma_kernel  — fp16 throughput path (see below), hd in {32, 64}.
+//   attn_long_kernel  — any N (ViT at 384x384: 577 tokens, vision_transformer.py:209-215): one wave per
+//                       query row, keys in tiles of 64 straight from global memory / L2, running max and
+//                       sum (the usual online softmax); a coverage path, not a tuned one.
+//   attn_mfma_kernel  — fp16 throughput path (see below), hd in {32, 64}, N <= 256.
 #include "common.h"
 #include <stdlib.h>
 
@@ -94,6 +97,65 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(const AttnArgs a) {
     }
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void attn_long_kernel(const AttnArgs a) {
+    __shared__ float ps[4][64];
+    __shared__ float qs[4][128];
+    const int N = a.N, hd = a.hd;
+    const int bh = blockIdx.x, b = bh / a.heads, h = bh - b * a.heads;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int row = blockIdx.y * 4 + wv;
+    if (row >= N) return;       // wave-uniform; no block-wide barrier below
+    const long tok_ld = 3L * a.heads * hd;
+    const T* base = reinterpret_cast<const T*>(a.qkv) + (long)b * N * tok_ld + (long)h * hd;
+    const T* kb = base + (long)a.heads * hd;
+    const T* vb = base + 2L * a.heads * hd;
+    const float* bias = a.bias ? a.bias + (long)h * N * N + (long)row * N : nullptr;
+    const float* mask = (a.mask && a.nW > 0) ? a.mask + (long)(b % a.nW) * N * N + (long)row * N : nullptr;
+    for (int d = lane; d < hd; d += 64) qs[wv][d] = (float)base[row * tok_ld + d];
+    __builtin_amdgcn_wave_barrier();
+    float m = -INFINITY, l = 0.f, o0 = 0.f, o1 = 0.f;   // running max / sum; output dims lane, lane + 64
+    for (int j0 = 0; j0 < N; j0 += 64) {
+        const int j = j0 + lane;
+        float s = -INFINITY;
+        if (j < N) {
+            float acc = 0.f;
+            const T* kr = kb + j * tok_ld;
+            for (int d = 0; d < hd; ++d) acc = fmaf(qs[wv][d], (float)kr[d], acc);
+            acc *= a.scale;
+            if (bias) acc += bias[j];
+            if (mask) acc += mask[j];
+            s = acc;
+        }
+        const float mn = fmaxf(m, wave_max(s));
+        const float p = j < N ? expf(s - mn) : 0.f;
+        const float corr = expf(m - mn);     // 0 on the first tile (m = -inf)
+        l = l * corr + wave_sum(p);
+        ps[wv][lane] = p;
+        __builtin_amdgcn_wave_barrier();
+        o0 *= corr;
+        o1 *= corr;
+        const int nj = N - j0 < 64 ? N - j0 : 64;
+        for (int jj = 0; jj < nj; ++jj) {
+            const float pj = ps[wv][jj];
+            const T* vr = vb + (long)(j0 + jj) * tok_ld;
+            if (lane < hd) o0 = fmaf(pj, (float)vr[lane], o0);
+            if (lane + 64 < hd) o1 = fmaf(pj, (float)vr[lane + 64], o1);
+        }
+        __builtin_amdgcn_wave_barrier();
+        m = mn;
+    }
+    T* out = reinterpret_cast<T*>(a.out) + (long)b * N * a.heads * hd + (long)h * hd + (long)row * a.heads * hd;
+    const float inv = 1.f / l;
+    if (lane < hd) out[lane] = (T)(o0 * inv);
+    if (lane + 64 < hd) out[lane + 64] = (T)(o1 * inv);
+}
+
+template <typename T> static int launch_long(const AttnArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL((attn_long_kernel<T>), dim3(a.B * a.heads, (a.N + 3) / 4), dim3(256), 0, st, a);
+    return check_launch("attention(long)");
+}
+
 template <typename T> static int launch_rows(const AttnArgs& a, hipStream_t st) {
     const size_t lds = ((size_t)2 * a.N * (a.hd + 1) + 4 * 256 + 4 * 128) * sizeof(float);
     if (lds > 160 * 1024) return fail(TLXMI_ERR_UNSUPPORTED, "attention: N=%d hd=%d needs %zu B of LDS", a.N, a.hd, lds);
@@ -119,13 +181,15 @@ extern "C" int tlxmi_attention(const tlxmi_attn_desc* d, const void* qkv, const 
     TLXMI_REQUIRE(d && qkv && out, TLXMI_ERR_BAD_ARG, "attention: null argument");
     TLXMI_REQUIRE(d->dtype == TLXMI_F16 || d->dtype == TLXMI_F32, TLXMI_ERR_BAD_ARG, "attention: bad dtype");
     TLXMI_REQUIRE(d->B > 0 && d->Ntok > 0 && d->heads > 0 && d->hd > 0, TLXMI_ERR_BAD_ARG, "attention: bad extent");
-    TLXMI_REQUIRE(d->Ntok <= 256 && d->hd <= 128, TLXMI_ERR_UNSUPPORTED, "attention: Ntok=%d (<=256) hd=%d (<=128)", d->Ntok, d->hd);
+    TLXMI_REQUIRE(d->Ntok <= 65535 * 4 && d->hd <= 128 && (long long)d->B * d->heads < (1ll << 31), TLXMI_ERR_UNSUPPORTED,
+                  "attention: Ntok=%d hd=%d (<=128)", d->Ntok, d->hd);
     TLXMI_REQUIRE(!mask || d->nW > 0, TLXMI_ERR_BAD_ARG, "attention: mask given but nW=%d", d->nW);
     TLXMI_REQUIRE(!mask || d->B % d->nW == 0, TLXMI_ERR_BAD_ARG, "attention: B=%d not a multiple of nW=%d", d->B, d->nW);
     AttnArgs a;
     a.qkv = qkv; a.bias = bias; a.mask = mask; a.out = out;
     a.B = d->B; a.N = d->Ntok; a.heads = d->heads; a.hd = d->hd; a.nW = mask ? d->nW : 0; a.scale = d->scale;
     hipStream_t st = as_stream(stream);
+    if (d->Ntok > 256) return d->dtype == TLXMI_F32 ? launch_long<float>(a, st) : launch_long<half_t>(a, st);
     if (d->dtype == TLXMI_F32) return launch_rows<float>(a, st);
     if ((d->hd == 64 || d->hd == 32) && aligned16(qkv) && aligned16(out)) return launch_attn_mfma(a, st);
     return launch_rows<half_t>(a, st);
