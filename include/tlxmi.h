@@ -216,7 +216,7 @@ int tlxmi_linear_ln(int dtype, int64_t rows, int K, int Cout, int x_ld, int y_ld
  *   out: [B][Ntok][heads*hd]       softmax(scale * q k^T + bias + mask) v, heads re-interleaved
  *   bias: optional [heads][Ntok][Ntok] fp32 (Swin relative position bias, :205-215)
  *   mask: optional [nW][Ntok][Ntok] fp32, window index = b % nW (Swin shift mask, :216-220)
- * hd <= 128.  Ntok <= 256 runs the tuned kernels (fp16: MFMA, hd in {32, 64}); longer sequences (ViT at
+ * hd <= 128.  Ntok <= 256 runs the tuned kernels (fp16: MFMA, hd in {32, 64, 96}); longer sequences (ViT at
  * 384 x 384: 577 tokens) run a generic online-softmax kernel.
  * ---------------------------------------------------------------------------------------- */
 typedef struct tlxmi_attn_desc {

@@ -104,7 +104,8 @@ def _ref_attention(qkv, heads, scale, bias=None, mask=None):
 @DT
 @pytest.mark.parametrize("B,N,heads,hd,swin", [(3, 197, 12, 64, False), (2, 50, 3, 64, False), (8, 49, 4, 32, True),
                                                 (4, 49, 32, 32, True), (2, 16, 2, 32, False), (1, 256, 1, 64, False),
-                                                (2, 577, 3, 64, False), (4, 300, 2, 96, True), (1, 1025, 1, 128, False)])
+                                                (2, 577, 3, 64, False), (4, 300, 2, 96, True), (1, 1025, 1, 128, False),
+                                                (3, 197, 8, 96, False), (4, 49, 2, 96, True)])
 def test_attention(dev, dtype, B, N, heads, hd, swin):
     rng = np.random.default_rng(6)
     qkv = prep(rnd(rng, (B, N, 3 * heads * hd)), dtype)

@@ -13,7 +13,7 @@
 //   attn_long_kernel  — any N (ViT at 384x384: 577 tokens, vision_transformer.py:209-215): one wave per
 //                       query row, keys in tiles of 64 straight from global memory / L2, running max and
 //                       sum (the usual online softmax); a coverage path, not a tuned one.
-//   attn_mfma_kernel  — fp16 throughput path (see below), hd in {32, 64}, N <= 256.
+//   attn_mfma_kernel  — fp16 throughput path (see below), hd in {32, 64, 96}, N <= 256.
 #include "common.h"
 #include <stdlib.h>
 
@@ -191,6 +191,6 @@ extern "C" int tlxmi_attention(const tlxmi_attn_desc* d, const void* qkv, const 
     hipStream_t st = as_stream(stream);
     if (d->Ntok > 256) return d->dtype == TLXMI_F32 ? launch_long<float>(a, st) : launch_long<half_t>(a, st);
     if (d->dtype == TLXMI_F32) return launch_rows<float>(a, st);
-    if ((d->hd == 64 || d->hd == 32) && aligned16(qkv) && aligned16(out)) return launch_attn_mfma(a, st);
+    if ((d->hd == 64 || d->hd == 32 || d->hd == 96) && aligned16(qkv) && aligned16(out)) return launch_attn_mfma(a, st);
     return launch_rows<half_t>(a, st);
 }

@@ -270,6 +270,7 @@ template <int HD> static int launch_hd(const AttnArgs& a, hipStream_t st) {
 
 int launch_attn_mfma(const AttnArgs& a, hipStream_t st) {
     if (a.hd == 64) return launch_hd<64>(a, st);
+    if (a.hd == 96) return launch_hd<96>(a, st);      // vit_small_patch16_224: 768 / 8 heads (vision_transformer.py:208)
     return launch_hd<32>(a, st);
 }
 
