@@ -227,6 +227,11 @@ typedef struct tlxmi_attn_desc {
 } tlxmi_attn_desc;
 int tlxmi_attention(const tlxmi_attn_desc* d, const void* qkv, const float* bias, const float* mask,
                     void* out, void* stream);
+/* Same, with bias + mask pre-summed and padded by the caller (once per layer instead of once per forward,
+ * swin_transformer.py:205-220): comb[w][h][i][j] = bias[h][i][j] + mask[w][i][j] for i, j < Ntok, 0 elsewhere,
+ * shape [max(nW,1)][heads][NP][NP] fp32 with NP = 32 * ceil(Ntok / 32).  fp16, hd in {32, 64, 96}, Ntok <= 256;
+ * TLXMI_ERR_UNSUPPORTED otherwise (use tlxmi_attention). */
+int tlxmi_attention_comb(const tlxmi_attn_desc* d, const void* qkv, const float* comb, void* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Swin window plumbing folded into index math (swin_transformer.py:85-116, 317-333):

@@ -123,6 +123,24 @@ def test_attention(dev, dtype, B, N, heads, hd, swin):
     torch.testing.assert_close(got.float().cpu(), want, **t)
 
 
+@pytest.mark.parametrize("B,N,heads,hd,masked", [(8, 49, 4, 32, True), (4, 49, 16, 32, False), (6, 130, 2, 64, True), (2, 197, 3, 96, False)])
+def test_attention_with_presummed_table(dev, B, N, heads, hd, masked):
+    """tlxmi_attention_comb: bias + mask summed and padded by the caller (swin_transformer.py:205-220)."""
+    rng = np.random.default_rng(16)
+    qkv = q16(rnd(rng, (B, N, 3 * heads * hd)))
+    bias = rnd(rng, (heads, N, N), 0.5)
+    mask = None
+    if masked:
+        nW = 2
+        ids = torch.from_numpy(rng.integers(0, 3, (nW, N)))
+        mask = (ids.unsqueeze(1) != ids.unsqueeze(2)).float() * -100.0
+    scale = hd ** -0.5
+    want = _ref_attention(qkv, heads, scale, bias, mask)
+    tab = E.attention_table(bias.to(dev), mask.to(dev) if masked else None, N)
+    got = E.attention_comb(qkv.half().to(dev), heads, scale, tab, mask.shape[0] if masked else 0)
+    torch.testing.assert_close(got.float().cpu(), want, atol=4e-3, rtol=4e-3)
+
+
 def test_attention_softmax_is_stable_for_large_scores(dev):
     """Forces the max-subtraction path: one key dominates with a score ~ +80 (exp overflows in fp16)."""
     rng = np.random.default_rng(7)

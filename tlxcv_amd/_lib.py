@@ -54,6 +54,7 @@ PROTOTYPES = {
     "tlxmi_row_stats": [_vp, _i, _l, _i, _i, _f, _vp, _vp],
     "tlxmi_linear_ln": [_i, _l, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
     "tlxmi_attention": [C.POINTER(AttnDesc), _vp, _vp, _vp, _vp, _vp],
+    "tlxmi_attention_comb": [C.POINTER(AttnDesc), _vp, _vp, _vp, _vp],
     "tlxmi_window_partition": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "tlxmi_window_reverse": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "tlxmi_patch_merge_gather": [_vp, _vp, _i, _i, _i, _i, _i, _vp],

@@ -26,6 +26,7 @@ struct AttnArgs {
     void* out;
     int B, N, heads, hd, nW;
     float scale;
+    const float* comb;   // bias + mask pre-summed and padded: [max(nW,1)][heads][NP][NP], NP = 32 * ceil(N / 32)
 };
 
 template <typename T>
@@ -188,9 +189,27 @@ extern "C" int tlxmi_attention(const tlxmi_attn_desc* d, const void* qkv, const 
     AttnArgs a;
     a.qkv = qkv; a.bias = bias; a.mask = mask; a.out = out;
     a.B = d->B; a.N = d->Ntok; a.heads = d->heads; a.hd = d->hd; a.nW = mask ? d->nW : 0; a.scale = d->scale;
+    a.comb = nullptr;
     hipStream_t st = as_stream(stream);
     if (d->Ntok > 256) return d->dtype == TLXMI_F32 ? launch_long<float>(a, st) : launch_long<half_t>(a, st);
     if (d->dtype == TLXMI_F32) return launch_rows<float>(a, st);
     if ((d->hd == 64 || d->hd == 32 || d->hd == 96) && aligned16(qkv) && aligned16(out)) return launch_attn_mfma(a, st);
     return launch_rows<half_t>(a, st);
+}
+
+// tlxmi_attention with the relative-position bias and the shift mask handed over pre-summed and padded:
+// comb[w][h][i][j] = bias[h][i][j] + mask[w][i][j] for i, j < Ntok, 0 elsewhere, rows and columns padded to
+// NP = 32 * ceil(Ntok / 32); nW = 0 means one table per head ([1][heads][NP][NP]).  The caller builds it once per
+// layer (swin_transformer.py:205-220 computes the same sum on every forward).  fp16, hd in {32, 64, 96},
+// Ntok <= 256 only (the MFMA kernel); anything else: TLXMI_ERR_UNSUPPORTED, use tlxmi_attention.
+extern "C" int tlxmi_attention_comb(const tlxmi_attn_desc* d, const void* qkv, const float* comb, void* out, void* stream) {
+    TLXMI_REQUIRE(d && qkv && out && comb, TLXMI_ERR_BAD_ARG, "attention_comb: null argument");
+    TLXMI_REQUIRE(d->B > 0 && d->Ntok > 0 && d->heads > 0 && d->hd > 0 && d->nW >= 0, TLXMI_ERR_BAD_ARG, "attention_comb: bad extent");
+    TLXMI_REQUIRE(d->nW == 0 || d->B % d->nW == 0, TLXMI_ERR_BAD_ARG, "attention_comb: B=%d not a multiple of nW=%d", d->B, d->nW);
+    if (!(d->dtype == TLXMI_F16 && (d->hd == 64 || d->hd == 32 || d->hd == 96) && d->Ntok <= 256 && aligned16(qkv) && aligned16(out) && aligned16(comb)))
+        return fail(TLXMI_ERR_UNSUPPORTED, "attention_comb: fp16, hd in {32,64,96}, Ntok <= 256, 16-byte aligned buffers only");
+    AttnArgs a;
+    a.qkv = qkv; a.bias = nullptr; a.mask = nullptr; a.out = out; a.comb = comb;
+    a.B = d->B; a.N = d->Ntok; a.heads = d->heads; a.hd = d->hd; a.nW = d->nW; a.scale = d->scale;
+    return launch_attn_mfma(a, as_stream(stream));
 }

@@ -25,6 +25,7 @@ struct AttnArgs {
     void* out;
     int B, N, heads, hd, nW;
     float scale;
+    const float* comb;   // bias + mask pre-summed and padded: [max(nW,1)][heads][NP][NP], NP = 32 * ceil(N / 32)
 };
 
 typedef __fp16 fp16x4 __attribute__((ext_vector_type(4)));
@@ -32,7 +33,8 @@ typedef __attribute__((address_space(3))) fp16x4 lds_fp16x4;
 
 // NT = number of 16-key tiles (even), keys padded to 16*NT.  ADD = how bias + mask reach the scores:
 // 0 none (ViT: no code at all in the score loop), 1 summed once into an LDS table (Swin-sized windows),
-// 2 read from global memory per score (generic fallback).
+// 2 read from global memory per score (generic fallback), 3 one 16-byte load per key tile from the caller's
+// pre-summed, padded table (a.comb): no LDS table, no extra barrier dependency, 4 loads per lane instead of 20.
 template <int HD, int NT, int ADD>
 __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const AttnArgs a) {
     constexpr int SR = HD * 2 + 32;          // padded LDS row stride in bytes (160 / 96)
@@ -66,6 +68,23 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const AttnArgs a) {
         }
     }
 
+    // Swin-sized windows: the (N, N) relative-position bias of this head and the shift mask of this window are
+    // summed once into an LDS table (coalesced reads) instead of two dependent global gathers per score.  Their
+    // loads are issued here, ahead of the K / V staging, so that a workgroup pays ONE memory latency before its
+    // first barrier, not two (these workgroups are tiny and latency-bound: time was proportional to their count).
+    constexpr int TPT = ADD == 1 ? (NP * NP + 255) / 256 : 1;      // table values per thread (upper bound)
+    float tv[TPT];
+    const float* bias = a.bias ? a.bias + (size_t)h * N * N : nullptr;
+    const float* mask = (a.mask && a.nW > 0) ? a.mask + (size_t)(b % a.nW) * N * N : nullptr;
+    if constexpr (ADD == 1) {
+#pragma unroll
+        for (int u = 0; u < TPT; ++u) {
+            const int i = t + u * 256;
+            tv[u] = 0.f;
+            if (i < N * N) tv[u] = (bias ? bias[i] : 0.f) + (mask ? mask[i] : 0.f);
+        }
+    }
+
     // ---- stage K and V (zero rows for padded keys); loads are issued in batches ahead of the LDS writes
     constexpr int ITEMS = NP * CPR, PER = (ITEMS + 255) / 256, BATCH = PER < 4 ? PER : 4;
     for (int b0 = 0; b0 < PER; b0 += BATCH) {
@@ -91,13 +110,13 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const AttnArgs a) {
             }
         }
     }
-    // Swin-sized windows: the (N, N) relative-position bias of this head and the shift mask of this window are
-    // summed once into an LDS table (coalesced reads) instead of two dependent global gathers per score
     float* Ts = reinterpret_cast<float*>(smem + 2 * NP * SR);
-    const float* bias = a.bias ? a.bias + (size_t)h * N * N : nullptr;
-    const float* mask = (a.mask && a.nW > 0) ? a.mask + (size_t)(b % a.nW) * N * N : nullptr;
     if constexpr (ADD == 1) {
-        for (int i = t; i < N * N; i += 256) Ts[i] = (bias ? bias[i] : 0.f) + (mask ? mask[i] : 0.f);
+#pragma unroll
+        for (int u = 0; u < TPT; ++u) {
+            const int i = t + u * 256;
+            if (i < N * N) Ts[i] = tv[u];
+        }
     }
     __syncthreads();
 
@@ -134,6 +153,14 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const AttnArgs a) {
         // while the MFMAs of tile kt run
         float s[NT][4];
         float mx = -INFINITY;
+        f32x4 tb[ADD == 3 ? NT : 1];
+        if constexpr (ADD == 3) {      // rows / columns up to npc = 32 * ceil(N / 32) exist in the padded table
+            const int npc = (N + 31) & ~31;
+            const float* crow = a.comb + (((size_t)(a.nW > 0 ? b % a.nW : 0) * heads + h) * npc + query) * npc + 4 * g;
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt)
+                tb[kt] = 16 * kt < npc ? *reinterpret_cast<const f32x4*>(crow + 16 * kt) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         u32x4 kf[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) kf[ks] = *reinterpret_cast<const u32x4*>(Ks + klane + ks * 64);
@@ -159,6 +186,8 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const AttnArgs a) {
                 float v = ADD == 0 ? acc[r] : acc[r] * a.scale;
                 if constexpr (ADD == 1) {
                     if (qok && (full_tile || key < N)) v += Ts[query * N + key];
+                } else if constexpr (ADD == 3) {
+                    v += tb[kt][r];
                 } else if constexpr (ADD == 2) {
                     if (qok && (full_tile || key < N)) {
                         if (bias) v += bias[(size_t)query * N + key];
@@ -254,6 +283,7 @@ template <int HD, int NT, int ADD> static int launch_add(const AttnArgs& a, hipS
 }
 
 template <int HD, int NT> static int launch_one(const AttnArgs& a, hipStream_t st) {
+    if (a.comb) return launch_add<HD, NT, 3>(a, st);
     if (!a.bias && !(a.mask && a.nW > 0) && a.scale > 0.f) return launch_add<HD, NT, 0>(a, st);   // scale folded into exp2: needs scale > 0
     if (NT <= 4) return launch_add<HD, NT, 1>(a, st);
     return launch_add<HD, NT, 2>(a, st);

@@ -422,6 +422,30 @@ def attention(qkv, heads, scale, bias=None, mask=None):
     return out
 
 
+def attention_table(bias, mask, N):
+    """bias (heads, N, N) + mask (nW, N, N) or None -> the pre-summed, padded table of tlxmi_attention_comb:
+    (max(nW,1), heads, NP, NP) fp32, NP = 32 * ceil(N / 32).  Built once per layer (the reference adds the two on
+    every forward, swin_transformer.py:205-220)."""
+    NP = (N + 31) // 32 * 32
+    nW = mask.shape[0] if mask is not None else 1
+    t = torch.zeros((nW, bias.shape[0], NP, NP), dtype=torch.float32, device=bias.device)
+    t[:, :, :N, :N] = bias.float()[None]
+    if mask is not None:
+        t[:, :, :N, :N] += mask.float().to(bias.device)[:, None]
+    return t.contiguous()
+
+
+def attention_comb(qkv, heads, scale, table, nW):
+    """attention() with a table from attention_table(); fp16, head dim 32 / 64 / 96, N <= 256."""
+    need_gpu(qkv, "input")
+    B, N, C3 = qkv.shape
+    hd = C3 // (3 * heads)
+    out = torch.empty((B, N, heads * hd), dtype=qkv.dtype, device=qkv.device)
+    d = _lib.AttnDesc(dtype=dt_code(qkv.dtype), B=B, Ntok=N, heads=heads, hd=hd, scale=float(scale), nW=nW)
+    _lib.call("tlxmi_attention_comb", C.byref(d), _p(qkv), _p(table), _p(out), _stream())
+    return out
+
+
 def window_partition(x, ws, shift):
     """(B,H,W,C) -> (B*nW, ws*ws, C) with the cyclic shift folded in."""
     need_gpu(x, "input")

@@ -14,6 +14,8 @@ bias (+ shift mask) -> softmax -> @v -> proj -> window_reverse -> roll back -> r
   * PatchMerging's strided 2x2 gather + concat is one copy kernel, then LayerNorm and the GEMM.
 Quirks kept on purpose: the -100.0 (not -inf) mask, and the PatchMerging reduction bias (:369-370).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -84,7 +86,13 @@ class WindowAttention(nn.Module):
 
     def run(self, xw, mask=None):
         qkv = self.qkv.run(xw)                                                     # (B_, N, 3C)
-        a = E.attention(qkv, self.num_heads, self.scale, self.bias_table(), mask)  # :202-226
+        hd = self.dim // self.num_heads
+        if qkv.dtype == torch.float16 and hd in (32, 64, 96) and qkv.shape[1] <= 256 and os.environ.get("TLXMI_ATTN_COMB", "1") != "0":
+            # relative position bias + shift mask summed and padded once per layer (:205-220 adds them per forward)
+            tab = self._cached(("rpb+mask", id(mask)), lambda: E.attention_table(self.bias_table(), mask, qkv.shape[1]))
+            a = E.attention_comb(qkv, self.num_heads, self.scale, tab, 0 if mask is None else mask.shape[0])
+        else:
+            a = E.attention(qkv, self.num_heads, self.scale, self.bias_table(), mask)  # :202-226
         return self.proj.run(a)
 
     def forward(self, x, mask=None):

@@ -1,2 +1,2 @@
-timeout -k 10 600 python -m pytest tests/test_ops_gpu.py tests/test_vit_gpu.py -m gpu -q -x -k "attention or vit" 2>&1 | tail -4
-timeout -k 10 300 python tools/model_times.py vit_small_patch16_224,vit_base_patch16_224 2>&1 | grep -v amdgpu
+for c in 1 0 1 0; do echo "comb=$c"; TLXMI_ATTN_COMB=$c timeout -k 10 200 python bench.py --workload swin_b --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | grep -o '"value": [0-9.]*'; done
+timeout -k 10 200 python tools/conv_micro.py attn_swin 20 2>&1 | grep -v amdgpu
