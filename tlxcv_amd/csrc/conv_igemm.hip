@@ -788,7 +788,9 @@ extern "C" int tlxmi_linear_ln(int dtype, int64_t rows, int K, int Cout, int x_l
     g.act = act; g.act_param = 0.f; g.flags = 0; g.mtiles = g.ntiles = 0; g.gn = 1;
     g.x_bytes = (unsigned)xb; g.y_bytes = (unsigned)yb; g.res_bytes = 0;
     g.w_bytes = (unsigned)(((size_t)(Cout + 127) / 128 * 128) * (size_t)g.Kp_bytes);
-    const int rc = launch_gemm_pp(dtype, g, as_stream(stream));
+    // the persistent kernel hides the plain epilogue (not the GELU arithmetic): same choice as the dispatcher's
+    const int rc = (act != TLXMI_ACT_GELU && gemm_stream_ok(dtype, g)) ? launch_gemm_stream(dtype, g, as_stream(stream), num_cus())
+                                                                       : launch_gemm_pp(dtype, g, as_stream(stream));
     if (rc != TLXMI_OK) return rc;
     return check_launch("linear_ln");
 }

@@ -23,7 +23,7 @@
 // Layout of a K tile in LDS, wave->quadrant map, fragment reads, channel permutation: gemm_pp.hip.
 //
 // In-order VMEM sequence of one wave around a tile boundary (L = last K tile of a tile; D = 2 DMA pieces,
-// S = the stores of a quadrant (8 for fp16, 16 for fp32), T = 2 table pieces), and the counted waits:
+// S = the stores of a quadrant (8 for fp16, 16 for fp32), T = 3 table pieces), and the counted waits:
 //     p0(L)   D W1(L+1)                        wait W1(L)          : 8
 //     p1(L)   D X1(L+1), S00                   wait X1(L)          : 8 + S
 //     p2(L)   D X0(L+2), T, S01
@@ -91,7 +91,8 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
     constexpr int RX0 = 0, RX1 = HALF, RW0 = 2 * HALF, RW1 = 3 * HALF;   // regions of a K tile
     constexpr int TABLE = 8 * HALF;            // two tables of 8 x 256 B behind the two K tiles
     constexpr int OOB = (int)0x80000000;
-    constexpr int S = ES == 2 ? 8 : 16, R = ES, TT = 2;   // R: loads of one residual step (2 pixel rows x 8 channels per lane)
+    constexpr int ROWTAB = TABLE + 2 * 2048;   // two tables of 256 rows x (a, b) behind the channel tables
+    constexpr int S = ES == 2 ? 8 : 16, R = ES, TT = 3;   // R: loads of one residual step (2 pixel rows x 8 channels per lane)
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int t = threadIdx.x, lane = t & 63;
@@ -117,6 +118,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
     const __amdgpu_buffer_rsrc_t ysrd = gs_srd(a.y, a.y_bytes);
     const __amdgpu_buffer_rsrc_t rsrd = gs_srd(a.res ? a.res : a.y, a.res ? a.res_bytes : 0u);
     const __amdgpu_buffer_rsrc_t hsrd = gs_srd(a.shift, a.shift ? (unsigned)a.Cout * 4u : 0u);   // null: zero fill
+    const __amdgpu_buffer_rsrc_t rowsrd = gs_srd(a.rowstats, a.rowstats ? (unsigned)a.M * 8u : 0u);   // null: zero fill
     const __amdgpu_buffer_rsrc_t ssrd = a.scale ? gs_srd(a.scale, (unsigned)a.Cout * 4u) : gs_srd(g_ones4, 16u);
 
     // ---- loader (gemm_pp.hip): piece = 8 rows x 128 B; wave w fills pieces w, w+8 of a half tile
@@ -161,6 +163,9 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
             gs_dma16(hsrd, dst, off);
             gs_dma16(ssrd, dst + 128, a.scale ? off : 0);
         }
+        // row statistics (LayerNorm folded in, tlxmi_linear_ln): rows 32w .. 32w+31 of the tile, 2 per lane; without
+        // them the piece is a zero fill that keeps the operation count uniform
+        if (lane < 16) gs_dma16(rowsrd, smem + ROWTAB + (i & 1) * 2048 + wid * 256, ok ? (bm0 + 32 * wid + 2 * lane) * 8 : OOB);
     };
 
     // ---- fragment reads (gemm_pp.hip)
@@ -211,14 +216,23 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
         for (int pi = 0; pi < 4; ++pi) {
             const int m = bm0 + 128 * H + 64 * wr + 16 * pi + px;
             float v[8];
+            if (!RES && a.rowstats) {   // y = a[m] * acc + b[m] * c1[n] + c2[n]
+                const float2 ab = *reinterpret_cast<const float2*>(smem + ROWTAB + tpar * 2048 + (128 * H + 64 * wr + 16 * pi + px) * 8);
 #pragma unroll
-            for (int bb = 0; bb < 4; ++bb) {
-                if constexpr (RES) {
-                    v[bb] = acc[2 * G][4 * H + pi][bb] + h0[bb];
-                    v[4 + bb] = acc[2 * G + 1][4 * H + pi][bb] + h1[bb];
-                } else {
-                    v[bb] = acc[2 * G][4 * H + pi][bb] * s0[bb] + h0[bb];
-                    v[4 + bb] = acc[2 * G + 1][4 * H + pi][bb] * s1[bb] + h1[bb];
+                for (int bb = 0; bb < 4; ++bb) {
+                    v[bb] = acc[2 * G][4 * H + pi][bb] * ab.x + (ab.y * s0[bb] + h0[bb]);
+                    v[4 + bb] = acc[2 * G + 1][4 * H + pi][bb] * ab.x + (ab.y * s1[bb] + h1[bb]);
+                }
+            } else {
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) {
+                    if constexpr (RES) {
+                        v[bb] = acc[2 * G][4 * H + pi][bb] + h0[bb];
+                        v[4 + bb] = acc[2 * G + 1][4 * H + pi][bb] + h1[bb];
+                    } else {
+                        v[bb] = acc[2 * G][4 * H + pi][bb] * s0[bb] + h0[bb];
+                        v[4 + bb] = acc[2 * G + 1][4 * H + pi][bb] * s1[bb] + h1[bb];
+                    }
                 }
             }
             if constexpr (ACT == TLXMI_ACT_GELU && ES == 2) {
@@ -421,7 +435,7 @@ template <typename T, int ACT, bool RES> static int launch_gs(const Gemm256Args&
     a.mtiles = (a.M + 255) / 256;
     a.ntiles = (a.Cout + 255) / 256;
     a.gn = a.ntiles;
-    const size_t lds = (size_t)8 * 128 * 128 + 2 * 2048;
+    const size_t lds = (size_t)8 * 128 * 128 + 4 * 2048;   // two K tiles, channel tables, row tables
     const void* fn = reinterpret_cast<const void*>(&gemm_stream_kernel<T, ACT, RES>);
     static bool raised = false;
     if (!raised) {
@@ -456,7 +470,7 @@ template <typename T> static int launch_gs_t(const Gemm256Args& a, hipStream_t s
 bool gemm_stream_ok(int dtype, const Gemm256Args& a) {
     if (a.ksteps < 2) return false;
     if (a.act != TLXMI_ACT_NONE && a.act != TLXMI_ACT_RELU && !(a.act == TLXMI_ACT_GELU && dtype == TLXMI_F16 && !a.res)) return false;
-    if (a.res && (dtype != TLXMI_F16 || a.scale != nullptr || (a.flags & TLXMI_EPI_RES_AFTER_ACT) || a.ksteps < 11)) return false;
+    if (a.res && (a.rowstats || dtype != TLXMI_F16 || a.scale != nullptr || (a.flags & TLXMI_EPI_RES_AFTER_ACT) || a.ksteps < 11)) return false;
     return true;
 }
 

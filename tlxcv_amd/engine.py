@@ -261,11 +261,12 @@ _cus = {}
 
 
 def linear_ln_supported(K, Cout, dtype, rows=None, device=None):
-    """Shapes tlxmi_linear_ln takes (the 256 x 256 GEMM kernel); fp16 only — the fp32 parity mode keeps the
-    reference's order of operations (LayerNorm output rounded, then the Linear).  With `rows` given, also
-    requires the one-workgroup-per-CU launch to fill its last round (the fused call has no tail split):
-    measured on ViT-B/16 +1 % end to end; a 3.06-round shape (Swin-B stage 3 fc1) would lose 25 %."""
-    if os.environ.get("TLXMI_LNFUSE", "1") == "0":      # A/B aid
+    """Whether a layer takes the fused LayerNorm + Linear path (tlxmi_linear_ln).  OFF unless TLXMI_LNFUSE=1:
+    measured on ViT-B/16 (same box, hipGraph replay) the fused qkv is -1 % end to end and fused qkv + fc1 -1..+1 %
+    — the statistics pass (28 us) plus the row-affine epilogue cost what the LayerNorm pass (46 us) saved.  fp16
+    only: the fp32 parity mode keeps the reference's order of operations.  With `rows` given, also requires the
+    one-workgroup-per-CU launch to fill its last round (the fused call has no tail split)."""
+    if os.environ.get("TLXMI_LNFUSE", "0") != "1":
         return False
     if not (dtype == torch.float16 and Cout % 8 == 0 and Cout >= 256 and K % 8 == 0 and K * 2 >= 256):
         return False
@@ -304,8 +305,16 @@ def linear_ln(x, prep, eps, act=ACT_NONE):
     stats = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
     y = torch.empty((*shp[:-1], prep.Cout), dtype=x.dtype, device=x.device)
     _lib.call("tlxmi_row_stats", _p(x), dt_code(x.dtype), rows, prep.K, prep.K, C.c_float(eps), _p(stats), _stream())
+    if _probe is not None:      # bench.py's roofline pass: the GEMM launch alone, like conv2d()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _lib.call("tlxmi_linear_ln", dt_code(x.dtype), rows, prep.K, prep.Cout, prep.K, prep.Cout, _p(x), _p(prep.pk.buf),
               _p(prep.c1), _p(prep.c2), _p(stats), act, _p(y), _stream())
+    if _probe is not None:
+        e1.record()
+        es = x.element_size()
+        _probe.append((e0, e1, (rows * prep.K + rows * prep.Cout + prep.Cout * prep.K) * es + rows * 8,
+                       2 * rows * prep.Cout * prep.K, (rows, 1, 1, prep.K, prep.Cout, 1, 1, False)))
     return y
 
 
