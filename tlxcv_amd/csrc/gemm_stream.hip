@@ -23,7 +23,7 @@
 // Layout of a K tile in LDS, wave->quadrant map, fragment reads, channel permutation: gemm_pp.hip.
 //
 // In-order VMEM sequence of one wave around a tile boundary (L = last K tile of a tile; D = 2 DMA pieces,
-// S = the stores of a quadrant (8 for fp16, 16 for fp32), T = 3 table pieces), and the counted waits:
+// S = the stores of a quadrant (8 for fp16, 16 for fp32), T = 2 table pieces, 3 with row statistics), and the counted waits:
 //     p0(L)   D W1(L+1)                        wait W1(L)          : 8
 //     p1(L)   D X1(L+1), S00                   wait X1(L)          : 8 + S
 //     p2(L)   D X0(L+2), T, S01
@@ -84,7 +84,8 @@ template <int N> __device__ __forceinline__ void gs_vmcnt() {
 
 // ACT: TLXMI_ACT_NONE / RELU / GELU (other activations, and exact-erf GELU in fp32, stay on gemm_pp.hip).
 // RES: a.res is added (before the activation; a.scale must be null) — needs >= 11 K tiles.
-template <typename T, int ACT, bool RES>
+// ROWAFF: per-row (a, b) of tlxmi_row_stats applied in the epilogue (LayerNorm folded in), one more table piece per tile
+template <typename T, int ACT, bool RES, bool ROWAFF>
 __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
     constexpr int ES = (int)sizeof(T);
     constexpr int HALF = 128 * 128;            // bytes of a half tile
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
     constexpr int TABLE = 8 * HALF;            // two tables of 8 x 256 B behind the two K tiles
     constexpr int OOB = (int)0x80000000;
     constexpr int ROWTAB = TABLE + 2 * 2048;   // two tables of 256 rows x (a, b) behind the channel tables
-    constexpr int S = ES == 2 ? 8 : 16, R = ES, TT = 3;   // R: loads of one residual step (2 pixel rows x 8 channels per lane)
+    constexpr int S = ES == 2 ? 8 : 16, R = ES, TT = ROWAFF ? 3 : 2;   // R: loads of one residual step (2 pixel rows x 8 channels per lane)
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int t = threadIdx.x, lane = t & 63;
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
         }
         // row statistics (LayerNorm folded in, tlxmi_linear_ln): rows 32w .. 32w+31 of the tile, 2 per lane; without
         // them the piece is a zero fill that keeps the operation count uniform
-        if (lane < 16) gs_dma16(rowsrd, smem + ROWTAB + (i & 1) * 2048 + wid * 256, ok ? (bm0 + 32 * wid + 2 * lane) * 8 : OOB);
+        if (ROWAFF && lane < 16) gs_dma16(rowsrd, smem + ROWTAB + (i & 1) * 2048 + wid * 256, ok ? (bm0 + 32 * wid + 2 * lane) * 8 : OOB);
     };
 
     // ---- fragment reads (gemm_pp.hip)
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
         for (int pi = 0; pi < 4; ++pi) {
             const int m = bm0 + 128 * H + 64 * wr + 16 * pi + px;
             float v[8];
-            if (!RES && a.rowstats) {   // y = a[m] * acc + b[m] * c1[n] + c2[n]
+            if constexpr (ROWAFF) {   // y = a[m] * acc + b[m] * c1[n] + c2[n]
                 const float2 ab = *reinterpret_cast<const float2*>(smem + ROWTAB + tpar * 2048 + (128 * H + 64 * wr + 16 * pi + px) * 8);
 #pragma unroll
                 for (int bb = 0; bb < 4; ++bb) {
@@ -429,14 +430,14 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
 
 // Preconditions as launch_gemm256 (conv_igemm.hip's dispatcher) plus: a.ksteps = packed pitch / 128 >= 2;
 // with a residual: fp16, a.scale == nullptr, residual added before the activation, a.ksteps >= 11.
-template <typename T, int ACT, bool RES> static int launch_gs(const Gemm256Args& a0, hipStream_t st, int cus) {
+template <typename T, int ACT, bool RES, bool ROWAFF = false> static int launch_gs(const Gemm256Args& a0, hipStream_t st, int cus) {
     Gemm256Args a = a0;
     { static const int dbg = [] { const char* e = getenv("TLXMI_DEBUG"); return e ? atoi(e) : 0; }(); a.debug = dbg; }
     a.mtiles = (a.M + 255) / 256;
     a.ntiles = (a.Cout + 255) / 256;
     a.gn = a.ntiles;
     const size_t lds = (size_t)8 * 128 * 128 + 4 * 2048;   // two K tiles, channel tables, row tables
-    const void* fn = reinterpret_cast<const void*>(&gemm_stream_kernel<T, ACT, RES>);
+    const void* fn = reinterpret_cast<const void*>(&gemm_stream_kernel<T, ACT, RES, ROWAFF>);
     static bool raised = false;
     if (!raised) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -455,6 +456,7 @@ template <typename T, int ACT, bool RES> static int launch_gs(const Gemm256Args&
 
 template <typename T> static int launch_gs_t(const Gemm256Args& a, hipStream_t st, int cus) {
     if constexpr (sizeof(T) == 2) {
+        if (a.rowstats) return launch_gs<T, TLXMI_ACT_NONE, false, true>(a, st, cus);   // gemm_stream_ok: fp16, no act, no residual
         if (a.res) {
             if (a.act == TLXMI_ACT_RELU) return launch_gs<T, TLXMI_ACT_RELU, true>(a, st, cus);
             return launch_gs<T, TLXMI_ACT_NONE, true>(a, st, cus);
@@ -470,7 +472,8 @@ template <typename T> static int launch_gs_t(const Gemm256Args& a, hipStream_t s
 bool gemm_stream_ok(int dtype, const Gemm256Args& a) {
     if (a.ksteps < 2) return false;
     if (a.act != TLXMI_ACT_NONE && a.act != TLXMI_ACT_RELU && !(a.act == TLXMI_ACT_GELU && dtype == TLXMI_F16 && !a.res)) return false;
-    if (a.res && (a.rowstats || dtype != TLXMI_F16 || a.scale != nullptr || (a.flags & TLXMI_EPI_RES_AFTER_ACT) || a.ksteps < 11)) return false;
+    if (a.rowstats && (dtype != TLXMI_F16 || a.act != TLXMI_ACT_NONE || a.res)) return false;
+    if (a.res && (dtype != TLXMI_F16 || a.scale != nullptr || (a.flags & TLXMI_EPI_RES_AFTER_ACT) || a.ksteps < 11)) return false;
     return true;
 }
 
