@@ -40,8 +40,9 @@ def build_model(workload, dev):
     return m.to(dev).set_eval(), params
 
 
-def cpu_baseline(workload, params, batch=16, warm=1, iters=3):
-    """Oracle restatement timed on the host cores (rank 0, N=1 only)."""
+def cpu_baseline(workload, params, batch=16, warm=1, min_seconds=12.0, max_iters=200):
+    """Oracle restatement timed on the host cores (rank 0, N=1 only): forwards of `batch` images of the same
+    workload until about `min_seconds` of CPU work have been timed (a bounded sample, 10-30 s)."""
     from oracle import functional as OF
     from tlxcv_amd import seeded
     try:
@@ -58,9 +59,13 @@ def cpu_baseline(workload, params, batch=16, warm=1, iters=3):
         for _ in range(warm):
             fn()
         t0 = time.perf_counter()
-        for _ in range(iters):
+        iters = 0
+        while iters < max_iters:
             fn()
-        dt = time.perf_counter() - t0
+            iters += 1
+            dt = time.perf_counter() - t0
+            if dt >= min_seconds:
+                break
     return {"value": round(batch * iters / dt, 2), "unit": "images/sec", "cores": torch.get_num_threads(),
             "kind": "port", "sample": f"{iters} forwards of batch {batch}, fp32, oracle/functional.py on torch-CPU "
             f"({dt:.1f} s)"}
