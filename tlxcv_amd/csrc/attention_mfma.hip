@@ -35,7 +35,8 @@ typedef __attribute__((address_space(3))) fp16x4 lds_fp16x4;
 // 0 none (ViT: no code at all in the score loop), 1 summed once into an LDS table (Swin-sized windows),
 // 2 read from global memory per score (generic fallback), 3 one 16-byte load per key tile from the caller's
 // pre-summed, padded table (a.comb): no LDS table, no extra barrier dependency, 4 loads per lane instead of 20.
-template <int HD, int NT, int ADD>
+// KF = key tiles known to lie wholly inside the sequence (NT - 2 when N > 16 * (NT - 2), else 0): no padding mask there
+template <int HD, int NT, int ADD, int KF>
 __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const AttnArgs a) {
     constexpr int SR = HD * 2 + 32;          // padded LDS row stride in bytes (160 / 96)
     constexpr int NP = 16 * NT;              // padded key count
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const AttnArgs a) {
                                                              __builtin_bit_cast(half8v, qcur[ks]), acc, 0, 0, 0);
             // ADD == 0 keeps the raw dot products (the scale is folded into the exponent below); key tiles that lie
             // wholly inside the sequence need no padding mask (wave-uniform test)
-            const bool full_tile = kt * 16 + 16 <= N;
+            const bool full_tile = kt < KF || kt * 16 + 16 <= N;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = kt * 16 + 4 * g + r;
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const AttnArgs a) {
                         if (mask) v += mask[(size_t)query * N + key];
                     }
                 }
-                if (!full_tile && key >= N) v = -INFINITY;
+                if (kt >= KF && !full_tile && key >= N) v = -INFINITY;
                 s[kt][r] = v;
                 mx = fmaxf(mx, v);
             }
@@ -266,20 +267,25 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const AttnArgs a) {
     }
 }
 
-template <int HD, int NT, int ADD> static int launch_add(const AttnArgs& a, hipStream_t st) {
+template <int HD, int NT, int ADD, int KF> static int launch_kf(const AttnArgs& a, hipStream_t st) {
     constexpr int SR = HD * 2 + 32;
     const size_t lds = (size_t)2 * 16 * NT * SR + (ADD == 1 ? (size_t)a.N * a.N * sizeof(float) : 0);
     if (lds > 64 * 1024) {
         static thread_local bool raised = false;
         if (!raised) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<HD, NT, ADD>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<HD, NT, ADD, KF>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return fail(TLXMI_ERR_LAUNCH, "attention: cannot raise LDS limit: %s", hipGetErrorString(e));
             raised = true;
         }
     }
-    hipLaunchKernelGGL((attn_mfma_kernel<HD, NT, ADD>), dim3(a.B * a.heads), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((attn_mfma_kernel<HD, NT, ADD, KF>), dim3(a.B * a.heads), dim3(256), lds, st, a);
     return check_launch("attention(mfma)");
+}
+
+template <int HD, int NT, int ADD> static int launch_add(const AttnArgs& a, hipStream_t st) {
+    if (a.N > 16 * (NT - 2)) return launch_kf<HD, NT, ADD, NT - 2>(a, st);
+    return launch_kf<HD, NT, ADD, 0>(a, st);
 }
 
 template <int HD, int NT> static int launch_one(const AttnArgs& a, hipStream_t st) {
