@@ -267,6 +267,193 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const AttnArgs a) {
     }
 }
 
+// Persistent variant for windows of at most 64 tokens (Swin: 49 tokens, thousands of (window, head) items per
+// launch).  With one workgroup per item the launch was latency-bound — time proportional to the item count,
+// 175 / 92 / 51 / 29 us for 32768 / 16384 / 8192 / 4096 items — every workgroup paying its own global-memory
+// latency before its first barrier.  Here a workgroup walks items blockIdx, blockIdx + grid, ...; the K / V rows,
+// the Q fragments and the bias-table values of the NEXT item are fetched into registers while the current
+// item computes, so only the first item of a workgroup waits for memory.  Each wave owns one 16-query tile.
+// Scores: scale * q.k + comb (a.comb, pre-summed bias + mask, or nothing).
+template <int HD, int NT, int KF>
+__global__ __launch_bounds__(256) void attn_win_kernel(const AttnArgs a, const int nitems) {
+    constexpr int SR = HD * 2 + 32;
+    constexpr int NP = 16 * NT;
+    constexpr int KS = HD / 32;
+    constexpr int DT = HD / 16;
+    constexpr int CPR = HD / 8;
+    constexpr int ITEMS = NP * CPR, PER = (ITEMS + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;
+    char* Vs = smem + NP * SR;
+
+    const int N = a.N, heads = a.heads;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const size_t tok_ld = (size_t)3 * heads * HD;
+    const int nqt = (N + 15) >> 4;
+    const int query = wv * 16 + li;
+    const bool qok = wv < nqt && query < N;
+    const int npc = (N + 31) & ~31;
+
+    u32x4 kreg[PER], vreg[PER], qreg[KS];
+    f32x4 treg[NT];
+    auto fetch = [&](int item) {
+        const bool live = item < nitems;
+        const int b = live ? item / heads : 0, h = live ? item - b * heads : 0;
+        const half_t* qbase = reinterpret_cast<const half_t*>(a.qkv) + (size_t)b * N * tok_ld + (size_t)h * HD;
+        const half_t* kbase = qbase + (size_t)heads * HD;
+        const half_t* vbase = qbase + (size_t)2 * heads * HD;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            qreg[ks] = u32x4{0u, 0u, 0u, 0u};
+            if (live && qok) qreg[ks] = *reinterpret_cast<const u32x4*>(qbase + (size_t)query * tok_ld + ks * 32 + g * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int i = t + u * 256;
+            const int key = i / CPR, c = i - key * CPR;
+            kreg[u] = u32x4{0u, 0u, 0u, 0u};
+            vreg[u] = u32x4{0u, 0u, 0u, 0u};
+            if (live && i < ITEMS && key < N) {
+                kreg[u] = *reinterpret_cast<const u32x4*>(kbase + (size_t)key * tok_ld + c * 8);
+                vreg[u] = *reinterpret_cast<const u32x4*>(vbase + (size_t)key * tok_ld + c * 8);
+            }
+        }
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) treg[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a.comb && live && wv < nqt) {      // rows / columns up to npc exist in the padded table
+            const float* crow = a.comb + (((size_t)(a.nW > 0 ? b % a.nW : 0) * heads + h) * npc + query) * npc + 4 * g;
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt)
+                if (16 * kt < npc) treg[kt] = *reinterpret_cast<const f32x4*>(crow + 16 * kt);
+        }
+    };
+
+    const int vlane = (4 * g + (li >> 2)) * SR + (li & 3) * 8;
+    const int klane = li * SR + g * 16;
+    fetch(blockIdx.x);
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+        // ---- this item's K / V rows from the prefetch registers to LDS (zero rows for padded keys)
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int i = t + u * 256;
+            const int key = i / CPR, c = i - key * CPR;
+            if (i < ITEMS) {
+                *reinterpret_cast<u32x4*>(Ks + key * SR + c * 16) = kreg[u];
+                *reinterpret_cast<u32x4*>(Vs + key * SR + c * 16) = vreg[u];
+            }
+        }
+        u32x4 qcur[KS];
+        f32x4 tb[NT];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qcur[ks] = qreg[ks];
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) tb[kt] = treg[kt];
+        __syncthreads();
+        fetch(item + gridDim.x);       // travels while this item computes
+
+        if (wv < nqt) {
+            const int b = item / heads, h = item - b * heads;
+            // ---- scores s[kt][r] = S[query][key = 16kt + 4g + r]
+            float s[NT][4];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const u32x4 kf = *reinterpret_cast<const u32x4*>(Ks + kt * 16 * SR + klane + ks * 64);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8v, kf), __builtin_bit_cast(half8v, qcur[ks]), acc, 0, 0, 0);
+                }
+                const bool full_tile = kt < KF || kt * 16 + 16 <= N;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kt * 16 + 4 * g + r;
+                    float v = acc[r] * a.scale + tb[kt][r];
+                    if (kt >= KF && !full_tile && key >= N) v = -INFINITY;
+                    s[kt][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            }
+            fp16x4 vlo[NT / 2][DT], vhi[NT / 2][DT];
+#pragma unroll
+            for (int pr = 0; pr < NT / 2; ++pr)
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const char* a0 = Vs + pr * 32 * SR + vlane + dt * 32;
+                    vlo[pr][dt] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16x4*)(a0));
+                    vhi[pr][dt] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16x4*)(a0 + 16 * SR));
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float sum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __expf(s[kt][r] - mx);
+                    s[kt][r] = p;
+                    sum += p;
+                }
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            const float inv = 1.f / sum;
+            f32x4 o[DT];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int pr = 0; pr < NT / 2; ++pr) {
+                half8v pf;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pf[r] = (half_t)s[2 * pr][r];
+                    pf[4 + r] = (half_t)s[2 * pr + 1][r];
+                }
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    half8v vf;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        vf[r] = (half_t)vlo[pr][dt][r];
+                        vf[4 + r] = (half_t)vhi[pr][dt][r];
+                    }
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, o[dt], 0, 0, 0);
+                }
+            }
+            if (query < N) {
+                half_t* obase = reinterpret_cast<half_t*>(a.out) + (size_t)b * N * heads * HD + (size_t)h * HD;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    half4v ov;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ov[r] = (half_t)(o[dt][r] * inv);
+                    *reinterpret_cast<half4v*>(obase + (size_t)query * heads * HD + dt * 16 + 4 * g) = ov;
+                }
+            }
+        }
+        __syncthreads();               // every wave is done with this item's K / V before the next overwrite
+    }
+}
+
+template <int HD, int NT, int KF> static int launch_win_kf(const AttnArgs& a, hipStream_t st) {
+    constexpr int SR = HD * 2 + 32;
+    const size_t lds = (size_t)2 * 16 * NT * SR;
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+    }
+    const long nitems = (long)a.B * a.heads;
+    const long grid = nitems < (long)cus * 6 ? nitems : (long)cus * 6;
+    hipLaunchKernelGGL((attn_win_kernel<HD, NT, KF>), dim3((unsigned)grid), dim3(256), lds, st, a, (int)nitems);
+    return check_launch("attention(windows)");
+}
+template <int HD, int NT> static int launch_win(const AttnArgs& a, hipStream_t st) {
+    if (a.N > 16 * (NT - 2)) return launch_win_kf<HD, NT, NT - 2>(a, st);
+    return launch_win_kf<HD, NT, 0>(a, st);
+}
+
 template <int HD, int NT, int ADD, int KF> static int launch_kf(const AttnArgs& a, hipStream_t st) {
     constexpr int SR = HD * 2 + 32;
     const size_t lds = (size_t)2 * 16 * NT * SR + (ADD == 1 ? (size_t)a.N * a.N * sizeof(float) : 0);
@@ -297,6 +484,11 @@ template <int HD, int NT> static int launch_one(const AttnArgs& a, hipStream_t s
 
 template <int HD> static int launch_hd(const AttnArgs& a, hipStream_t st) {
     const int nt = ((a.N + 31) / 32) * 2;
+    // windows of at most 64 tokens whose bias is absent or pre-summed: the persistent kernel (many tiny items)
+    if (nt <= 4 && (a.comb || (!a.bias && !(a.mask && a.nW > 0))) && (long)a.B * a.heads < (1l << 31)) {
+        if (nt <= 2) return launch_win<HD, 2>(a, st);
+        return launch_win<HD, 4>(a, st);
+    }
     if (nt <= 2) return launch_one<HD, 2>(a, st);
     if (nt <= 4) return launch_one<HD, 4>(a, st);
     if (nt <= 8) return launch_one<HD, 8>(a, st);
