@@ -90,6 +90,21 @@ def test_many_tiles_per_workgroup(dev, force_tile, tile):
     run_linear(dev, torch.float16, 50432, 768, 768, res=True, seed=5)
 
 
+def test_auto_dispatch_tail_on_half_height_tiles(dev, force_tile):
+    # 197 x 3 tiles = 2 rounds + 79: 170 row tiles go to the 256 x 256 kernel, the last 6912 rows to the same
+    # antiphase kernel on 128 x 256 tiles (gemm_pp128), with bias + residual
+    force_tile(None)
+    run_linear(dev, torch.float16, 50432, 768, 768, res=True, seed=9)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32], ids=["fp16", "fp32"])
+def test_half_height_kernel_directly(dev, force_tile, dtype):
+    # small enough that only the tail path's shape rules matter: 2 rounds + a tail needs > 512 tiles, so the
+    # kernel is also reached through TLXMI_TILE=7 on a problem whose row count is not a multiple of 128
+    force_tile(None)
+    run_linear(dev, dtype, 256 * 170 * 1 + 128 * 3 + 5, 256, 768, act=E.ACT_RELU, scale=True, seed=10)
+
+
 def test_auto_dispatch_tail_split(dev, force_tile):
     # 197 x 12 tiles = 9 rounds + 60: the dispatcher sends 192 row tiles to the 256 x 256 kernel and the last
     # 1280 rows to small tiles; the seam must be invisible

@@ -603,14 +603,17 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
     // the persistent kernel hides the plain epilogue but not the GELU arithmetic (measured: fc1 of ViT-B)
     if (a.act == TLXMI_ACT_GELU) cands[8].eff = 0.f;
     // One workgroup per CU: the last round of a 256x256 launch runs a whole tile time however few tiles it
-    // has.  When its rows fit ONE round of 128x128 tiles (a quarter of the work each, about half a tile time
-    // alone on a CU), the rows of the full rounds go to the 256x256 kernel and the remaining rows to a second
-    // launch with small tiles (tail split, below).  Measured on ViT-B (tools/ab_tiles.py): fc1 (60 tiles left
-    // of 2364) 293 -> 282 us; with 79 tiles left (proj, fc2) the second launch costs what it saves.
+    // has.  When it would be at most half full, the rows of the full rounds go to the 256x256 kernel and the
+    // remaining rows to a second launch of the same kernel on 128x256 tiles (gemm_pp128): twice the tiles, about
+    // 0.6 of the time, still one round (tail split, below).
     const long t256 = (long)((a.M + 255) / 256) * ((a.Cout + 255) / 256);
     const int cus = num_cus();
     const long full_rounds = t256 / cus;
-    const bool tail_split = gemm256_ok && full_rounds >= 1 && (t256 % cus) != 0 && 4 * (t256 % cus) <= cus;
+    // TLXMI_TAIL (A/B): 0 no split, 1 small tiles only (4 * left <= CUs), default: 128 x 256 tiles (2 * left <= CUs)
+    int tail_mode = 2;
+    { const char* e = getenv("TLXMI_TAIL"); if (e && *e) tail_mode = atoi(e); }
+    const bool tail_split = gemm256_ok && tail_mode != 0 && full_rounds >= 1 && (t256 % cus) != 0 &&
+                            (tail_mode == 1 ? 4 : 2) * (t256 % cus) <= cus;
     int best = 0;
     float best_score = -1.f;
     for (int i = 0; i < NC; ++i) {
@@ -628,7 +631,7 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
         const long slots = (long)cus * per_cu;
         const long rounds = (blocks + slots - 1) / slots;
         float quant = (float)blocks / (float)(rounds * slots);
-        if (i >= 7 && tail_split) quant = (float)blocks / ((float)full_rounds * slots + 2.f * (blocks % slots));   // tail at ~half efficiency
+        if (i >= 7 && tail_split) quant = (float)blocks / (((float)full_rounds + 0.6f) * slots);   // the tail round: ~0.6 of a tile time
         // wasted work inside partial tiles
         const float fill = ((float)a.M * a.Cout) / ((float)blocks * bm * bn);
         const float score = quant * fill * cands[i].eff;
@@ -657,7 +660,21 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
             lo.y_nstride = hi.y_nstride = 0; lo.res_nstride = hi.res_nstride = 0;
             const int rc = dispatch<T>(lo, st, true);     // t256 % cus == 0 there: no further split
             if (rc != TLXMI_OK) return rc;
-            return dispatch<T>(hi, st, false);
+            // a short tail (one round of 128x128 tiles) runs best on the small-tile kernels (measured: ViT fc1,
+            // Swin stage-3 fc1); a longer one on the 128 x 256 antiphase kernel (ViT proj / fc2: -3 %)
+            if (tail_mode == 1 || 4 * (t256 % cus) <= cus) return dispatch<T>(hi, st, false);
+            // the rows left over: the same antiphase kernel on 128 x 256 tiles — twice the tiles, half the time each,
+            // still one round (2 * left <= CUs)
+            Gemm256Args g;
+            g.debug = 0;
+            g.rowstats = nullptr;
+            g.x = hi.x; g.w = hi.w; g.y = hi.y; g.scale = hi.scale; g.shift = hi.shift; g.res = hi.res;
+            g.M = hi.M; g.Cout = hi.Cout; g.x_ld = hi.x_ld; g.y_ld = hi.y_ld; g.res_ld = hi.res_ld;
+            g.kchunks = hi.kchunks; g.ksteps = hi.Kp_bytes / 128; g.Kp_bytes = hi.Kp_bytes;
+            g.act = hi.act; g.act_param = hi.act_param; g.flags = hi.flags; g.mtiles = g.ntiles = 0; g.gn = 1;
+            g.x_bytes = hi.x_bytes; g.w_bytes = hi.w_bytes; g.y_bytes = hi.y_bytes;
+            g.res_bytes = hi.res ? (unsigned)((long long)hi.M * hi.res_ld * (long long)sizeof(T)) : 0u;
+            return launch_gemm_pp128(sizeof(T) == 2 ? TLXMI_F16 : TLXMI_F32, g, st);
         }
     }
     if (best >= 5) {

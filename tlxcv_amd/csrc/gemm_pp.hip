@@ -56,12 +56,19 @@ template <> struct MmaPP<float> {
     }
 };
 
-template <typename T>
+// HM = X half tiles per K tile: 2 -> the 256 x 256 tile described above; 1 -> a 128 x 256 tile (tails: a launch
+// whose last round would hold fewer than half the CUs runs those rows as twice as many half-height tiles).
+// With one X half a K tile is two phases ((0,0) and (0,1)) and 48 KiB, so THREE K tiles are resident and the
+// DMA runs two K tiles ahead:  p0(k): X0, W0 of k+2 (vmcnt(10) retires W1(k));  p1(k): W1 of k+2 (vmcnt(8)
+// retires X0, W0 of k+1) — again every half tile is refilled two phases after its last read.
+template <typename T, int HM>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
     constexpr int ES = (int)sizeof(T);
-    constexpr int BM = 256, BN = 256;
+    constexpr int BM = 128 * HM, BN = 256;
     constexpr int HALF = 128 * 128;            // bytes of a half tile
-    constexpr int RX0 = 0, RX1 = HALF, RW0 = 2 * HALF, RW1 = 3 * HALF;   // regions of a K tile
+    constexpr int RX0 = 0, RX1 = HALF, RW0 = HM * HALF, RW1 = (HM + 1) * HALF;   // regions of a K tile (RX1: HM == 2)
+    constexpr int KTB = (HM + 2) * HALF;       // bytes of a K tile
+    constexpr int NBUF = HM == 2 ? 2 : 3;      // resident K tiles
     constexpr int OOB = (int)0x80000000;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -91,22 +98,23 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int m = bm0 + 128 * h + 8 * (wid + 8 * j) + lrow;
-            xo[h][j] = m < a.M ? m * a.x_ld * ES : OOB;
+            xo[h][j] = (h < HM && m < a.M) ? m * a.x_ld * ES : OOB;
             const int rho = 128 * h + 8 * (wid + 8 * j) + lrow;    // LDS row; holds channel perm(rho) (conv_igemm.hip)
             const int n = (rho & ~31) | (((rho >> 2) & 3) << 3) | (((rho >> 4) & 1) << 2) | (rho & 3);
             wo[h][j] = (bn0 + n) * a.Kp_bytes;
         }
     char* const lbase = smem + wid * 1024;
-    auto stage_x = [&](int h, int kt) {
+    // `buf` = resident K-tile slot the tile goes to (kt & 1 for HM == 2, kt % 3 for HM == 1)
+    auto stage_x = [&](int h, int kt, int buf) {
         const int q = kt * 8 + lc;
-        char* b = lbase + ((kt & 1) << 16) + (h ? RX1 : RX0);
+        char* b = lbase + buf * KTB + (h ? RX1 : RX0);
         const bool in = q < a.kchunks;
 #pragma unroll
         for (int j = 0; j < 2; ++j) pp_dma16(xsrd, b + j * 8192, in ? xo[h][j] + q * 16 : OOB);
     };
-    auto stage_w = [&](int g, int kt) {
+    auto stage_w = [&](int g, int kt, int buf) {
         const int q = kt * 8 + lc;
-        char* b = lbase + ((kt & 1) << 16) + (g ? RW1 : RW0);
+        char* b = lbase + buf * KTB + (g ? RW1 : RW0);
         const bool in = q * 16 < a.Kp_bytes;
 #pragma unroll
         for (int j = 0; j < 2; ++j) pp_dma16(wsrd, b + j * 8192, in ? wo[g][j] + q * 16 : OOB);
@@ -117,11 +125,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
     const int foff = frow * 128 + ((fg ^ ((frow >> 1) & 7)) << 4);
     const int xf0 = wr * 64 * 128 + foff, wf0 = wc * 32 * 128 + foff;   // ksub 1 = same offset ^ 64
 
-    f32x4 acc[4][8];   // [2*g + ci][4*h + pi]
+    f32x4 acc[4][4 * HM];   // [2*g + ci][4*h + pi]
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 4 * HM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     u32x4 xf[4][2], w0f[2][2], w1f[2][2];
     auto read_x = [&](const char* kb, int region) {
@@ -144,7 +152,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                             \
         _Pragma("unroll") for (int pi = 0; pi < 4; ++pi)                                             \
         _Pragma("unroll") for (int ci = 0; ci < 2; ++ci)                                             \
-            acc[2 * G + ci][4 * H + pi] = MmaPP<T>::run(WF[ci][ks], xf[pi][ks], acc[2 * G + ci][4 * H + pi]); \
+            acc[2 * (G) + ci][4 * (H) + pi] = MmaPP<T>::run(WF[ci][ks], xf[pi][ks], acc[2 * (G) + ci][4 * (H) + pi]); \
         __builtin_amdgcn_s_setprio(0);                                                               \
     }
 #define TLXMI_PP_SYNC()                       \
@@ -160,22 +168,31 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
         if (a.shift) sh_t = a.shift[ch];
     }
     // row statistics of the wave's 8 pixel sub-tiles (LayerNorm folded in): loaded here, used in the epilogue
-    float2 rowab[2][4];
+    float2 rowab[HM][4];
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < HM; ++h)
 #pragma unroll
         for (int pi = 0; pi < 4; ++pi) {
             const int m = bm0 + 128 * h + 64 * wr + 16 * pi + (lane & 15);
             rowab[h][pi] = (a.rowstats && m < a.M) ? *reinterpret_cast<const float2*>(a.rowstats + 2 * (size_t)m) : make_float2(1.f, 0.f);
         }
     __builtin_amdgcn_sched_barrier(0);   // these loads are older than every DMA: their wait leaves the DMAs in flight
-    stage_x(0, 0);
-    stage_w(0, 0);
-    stage_w(1, 0);
-    stage_x(1, 0);
-    stage_x(0, 1);
-    stage_w(0, 1);
-    float* sbuf = reinterpret_cast<float*>(smem + 2 * 4 * HALF);
+    if constexpr (HM == 2) {
+        stage_x(0, 0, 0);
+        stage_w(0, 0, 0);
+        stage_w(1, 0, 0);
+        stage_x(1, 0, 0);
+        stage_x(0, 1, 1);
+        stage_w(0, 1, 1);
+    } else {
+        stage_x(0, 0, 0);
+        stage_w(0, 0, 0);
+        stage_w(1, 0, 0);
+        stage_x(0, 1, 1);
+        stage_w(0, 1, 1);
+        stage_w(1, 1, 1);
+    }
+    float* sbuf = reinterpret_cast<float*>(smem + NBUF * KTB);
     if (t < BN) {
         sbuf[t] = sc_t;
         sbuf[BN + t] = sh_t;
@@ -185,35 +202,60 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
     if (wr == 1) { TLXMI_PP_SYNC(); }   // group 1 runs one barrier behind
 
     const int ks = a.ksteps;
-    for (int kt = 0; kt < ks; ++kt) {
-        const char* kb = smem + ((kt & 1) << 16);
-        // p0
-        read_x(kb, RX0);
-        read_w(kb, RW0, w0f);
-        stage_w(1, kt + 1);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // W1(kt)
-        TLXMI_PP_SYNC();
-        TLXMI_PP_MMA(0, 0, w0f);
-        TLXMI_PP_SYNC();
-        // p1
-        read_w(kb, RW1, w1f);
-        stage_x(1, kt + 1);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // X1(kt)
-        TLXMI_PP_SYNC();
-        TLXMI_PP_MMA(0, 1, w1f);
-        TLXMI_PP_SYNC();
-        // p2
-        read_x(kb, RX1);
-        stage_x(0, kt + 2);
-        TLXMI_PP_SYNC();
-        TLXMI_PP_MMA(1, 1, w1f);
-        TLXMI_PP_SYNC();
-        // p3
-        stage_w(0, kt + 2);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // X0(kt+1), W0(kt+1)
-        TLXMI_PP_SYNC();
-        TLXMI_PP_MMA(1, 0, w0f);
-        TLXMI_PP_SYNC();
+    if constexpr (HM == 2) {
+        for (int kt = 0; kt < ks; ++kt) {
+            const char* kb = smem + (kt & 1) * KTB;
+            // p0
+            read_x(kb, RX0);
+            read_w(kb, RW0, w0f);
+            stage_w(1, kt + 1, (kt + 1) & 1);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // W1(kt)
+            TLXMI_PP_SYNC();
+            TLXMI_PP_MMA(0, 0, w0f);
+            TLXMI_PP_SYNC();
+            // p1
+            read_w(kb, RW1, w1f);
+            stage_x(1, kt + 1, (kt + 1) & 1);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // X1(kt)
+            TLXMI_PP_SYNC();
+            TLXMI_PP_MMA(0, 1, w1f);
+            TLXMI_PP_SYNC();
+            // p2
+            read_x(kb, RX1);
+            stage_x(0, kt + 2, kt & 1);
+            TLXMI_PP_SYNC();
+            TLXMI_PP_MMA(HM - 1, 1, w1f);
+            TLXMI_PP_SYNC();
+            // p3
+            stage_w(0, kt + 2, kt & 1);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // X0(kt+1), W0(kt+1)
+            TLXMI_PP_SYNC();
+            TLXMI_PP_MMA(HM - 1, 0, w0f);
+            TLXMI_PP_SYNC();
+        }
+    } else {
+        int bc = 0, b2 = 2;      // slots of K tiles kt and kt + 2 (mod 3)
+        for (int kt = 0; kt < ks; ++kt) {
+            const char* kb = smem + bc * KTB;
+            // p0
+            read_x(kb, RX0);
+            read_w(kb, RW0, w0f);
+            stage_x(0, kt + 2, b2);
+            stage_w(0, kt + 2, b2);
+            asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // W1(kt)
+            TLXMI_PP_SYNC();
+            TLXMI_PP_MMA(0, 0, w0f);
+            TLXMI_PP_SYNC();
+            // p1
+            read_w(kb, RW1, w1f);
+            stage_w(1, kt + 2, b2);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // X0(kt+1), W0(kt+1)
+            TLXMI_PP_SYNC();
+            TLXMI_PP_MMA(0, 1, w1f);
+            TLXMI_PP_SYNC();
+            bc = bc == 2 ? 0 : bc + 1;
+            b2 = b2 == 2 ? 0 : b2 + 1;
+        }
     }
     if (wr == 0) { TLXMI_PP_SYNC(); }   // barrier counts match again
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero-fill DMAs of the tail
@@ -224,7 +266,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(acc[i][j]));
+            for (int j = 0; j < 4 * HM; ++j) asm volatile("" ::"v"(acc[i][j]));
         return;
     }
     // ---- epilogue from registers: lane (fg, px) owns channels 128g + 32wc + 8fg .. +7 of pixel row
@@ -247,7 +289,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
                 for (int e = 0; e < 4; ++e) { sc[e] = s0[e]; sc[4 + e] = s1[e]; sf[e] = h0[e]; sf[4 + e] = h1[e]; }
             }
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int h = 0; h < HM; ++h) {
                 u32x4 rr[4][ES / 2];
                 if (a.res) {
 #pragma unroll
@@ -327,14 +369,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
 }
 
 // Preconditions as launch_gemm256 (checked by conv_igemm.hip's dispatcher); a.ksteps = packed pitch / 128.
-template <typename T> static int launch_pp_t(const Gemm256Args& a0, hipStream_t st, bool& raised) {
+template <typename T, int HM> static int launch_pp_t(const Gemm256Args& a0, hipStream_t st, bool& raised) {
     Gemm256Args a = a0;
     { static const int dbg = [] { const char* e = getenv("TLXMI_DEBUG"); return e ? atoi(e) : 0; }(); a.debug = dbg; }
-    a.mtiles = (a.M + 255) / 256;
+    a.mtiles = (a.M + 128 * HM - 1) / (128 * HM);
     a.ntiles = (a.Cout + 255) / 256;
     a.gn = a.ntiles;
-    const size_t lds = (size_t)8 * 128 * 128 + 2 * 256 * sizeof(float);
-    const void* fn = reinterpret_cast<const void*>(&gemm_pp_kernel<T>);
+    const size_t lds = (size_t)(HM == 2 ? 8 : 9) * 128 * 128 + 2 * 256 * sizeof(float);
+    const void* fn = reinterpret_cast<const void*>(&gemm_pp_kernel<T, HM>);
     if (!raised) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail(TLXMI_ERR_LAUNCH, "gemm_pp: cannot raise LDS limit: %s", hipGetErrorString(e));
@@ -348,8 +390,15 @@ template <typename T> static int launch_pp_t(const Gemm256Args& a0, hipStream_t 
 
 int launch_gemm_pp(int dtype, const Gemm256Args& a, hipStream_t st) {
     static bool raised[2] = {false, false};
-    if (dtype == TLXMI_F16) return launch_pp_t<half_t>(a, st, raised[0]);
-    return launch_pp_t<float>(a, st, raised[1]);
+    if (dtype == TLXMI_F16) return launch_pp_t<half_t, 2>(a, st, raised[0]);
+    return launch_pp_t<float, 2>(a, st, raised[1]);
+}
+
+// 128 x 256 tiles (same preconditions)
+int launch_gemm_pp128(int dtype, const Gemm256Args& a, hipStream_t st) {
+    static bool raised[2] = {false, false};
+    if (dtype == TLXMI_F16) return launch_pp_t<half_t, 1>(a, st, raised[0]);
+    return launch_pp_t<float, 1>(a, st, raised[1]);
 }
 
 }  // namespace tlxmi
