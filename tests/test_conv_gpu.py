@@ -177,3 +177,29 @@ def test_thin_input_stride1(dev, cfg, halo):
         run_case(dev, torch.float16, N, Cin, Cout, k, 1, pad, H, W, act=act, act_param=0.1, with_res=res, seed=11)
     finally:
         os.environ.pop("TLXMI_HALO", None)
+
+
+@pytest.mark.parametrize("cfg", [(128, 64, 64, 3, 1, 56, 56, True), (64, 16, 64, 4, 0, 115, 115, False)],
+                         ids=["3x3x64_batch128", "stem_batch64"])
+def test_thin_input_full_size_matches_the_implicit_gemm(dev, cfg):
+    """BASELINE-sized property check: at full image count (dozens of tiles per workgroup, every ring wrap and
+    image boundary of conv_halo.hip) the row-ring kernel and the implicit GEMM — each checked against the oracle
+    at small sizes above — agree to fp16 rounding of one accumulation order vs the other."""
+    import os
+    N, Cin, Cout, k, pad, H, W, res = cfg
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn((N, H, W, Cin), generator=g) * 0.5).half().to(dev)
+    w = torch.randn((Cout, Cin, k, k), generator=g) * (2.0 / (Cin * k * k)) ** 0.5
+    pk = E.PackedFilter(w.to(dev), torch.float16)
+    sc = (torch.rand(Cout, generator=g) + 0.5).to(dev)
+    sh = (torch.randn(Cout, generator=g) * 0.1).to(dev)
+    Ho, Wo = H + 2 * pad - k + 1, W + 2 * pad - k + 1
+    r = torch.randn((N, Ho, Wo, Cout), generator=g).half().to(dev) if res else None
+    outs = []
+    for halo in ("1", "0"):
+        os.environ["TLXMI_HALO"] = halo
+        try:
+            outs.append(E.conv2d(x, pk, 1, pad, 1, sc, sh, r, E.ACT_RELU).float().cpu())
+        finally:
+            os.environ.pop("TLXMI_HALO", None)
+    torch.testing.assert_close(outs[0], outs[1], atol=4e-3, rtol=4e-3)
