@@ -160,6 +160,10 @@ int tlxmi_maxpool2d(const void* x, void* y, int dtype, int N, int H, int W, int 
 /* y[n][c] = mean over H*W of x[n][.][.][c];  y pixel stride y_ld */
 int tlxmi_global_avgpool(const void* x, void* y, int dtype, int N, int HW, int C, int x_ld, int y_ld,
                          void* stream);
+/* nn.AdaptiveAvgPool2d((OH, OW)), vgg.py:36-39: y[n][oh][ow][c] = mean of x over rows [floor(oh*H/OH),
+ * ceil((oh+1)*H/OH)) and the matching columns.  x: [N][H][W][x_ld], y: [N][OH][OW][y_ld]. */
+int tlxmi_adaptive_avgpool2d(const void* x, void* y, int dtype, int N, int H, int W, int C, int OH, int OW,
+                             int x_ld, int y_ld, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Elementwise: y = act(x*scale[c] + shift[c]) (+ res).  Used when a BatchNorm / activation / add

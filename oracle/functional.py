@@ -89,6 +89,59 @@ def resnet(p, x, depth=50, num_classes=1000, with_pool=True):
     return x
 
 
+# ---------------------------------------------------------------------------------------------
+# VGG — models/classification/vgg.py;  AlexNet — models/classification/alexnet.py
+# ---------------------------------------------------------------------------------------------
+VGG_CFG = {  # vgg.py:93-98
+    "A": [64, "M", 128, "M", 256, 256, "M", 512, 512, "M", 512, 512, "M"],
+    "B": [64, 64, "M", 128, 128, "M", 256, 256, "M", 512, 512, "M", 512, 512, "M"],
+    "D": [64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512, "M"],
+    "E": [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512, 512, 512, 512, "M"],
+}
+VGG_ARCH = {"vgg11": "A", "vgg13": "B", "vgg16": "D", "vgg19": "E"}
+
+
+def vgg(p, x, arch="vgg16", batch_norm=False, num_classes=1000, with_pool=True):
+    """VGG.forward vgg.py:52-59 over make_layers :61-90: Sequential index i counts every layer
+    (conv, [bn], relu, pool), which is how the parameters are named (`features.<i>.filters`)."""
+    i = 0
+    for v in VGG_CFG[VGG_ARCH[arch]]:
+        if v == "M":
+            x = F.max_pool2d(x, 2, 2)                                         # :66-72 (padding 'SAME' of a 2x2/2 pool = 0)
+            i += 1
+        else:
+            x = conv(p, f"features.{i}", x, 1, 1)                             # :74-80 3x3, padding='SAME', bias
+            i += 1
+            if batch_norm:
+                x = bn(p, f"features.{i}", x)                                 # :82-86
+                i += 1
+            x = F.relu(x)
+            i += 1
+    if with_pool:
+        x = F.adaptive_avg_pool2d(x, (7, 7))                                  # :54-55
+    if num_classes > 0:
+        x = x.reshape(x.shape[0], -1)                                         # :56 FlattenReshape (C, H, W order)
+        x = F.relu(linear(p, "classifier.0", x))                              # :57, :42-50 (Dropout = identity in eval)
+        x = F.relu(linear(p, "classifier.3", x))
+        x = linear(p, "classifier.6", x)
+    return x
+
+
+def alexnet(p, x, num_classes=1000):
+    """AlexNet.forward alexnet.py:152-169; ConvPoolLayer.forward :44-49."""
+    x = F.max_pool2d(F.relu(conv(p, "_conv1._conv", x, 4, 2)), 3, 2)          # :153  11x11/4 pad 2, pool 3/2/0
+    x = F.max_pool2d(F.relu(conv(p, "_conv2._conv", x, 1, 2)), 3, 2)          # :154  5x5 pad 2
+    x = F.relu(conv(p, "_conv3", x, 1, 1))                                    # :155-156
+    x = F.relu(conv(p, "_conv4", x, 1, 1))                                    # :157-158
+    x = F.max_pool2d(F.relu(conv(p, "_conv5._conv", x, 1, 1)), 3, 2)          # :159
+    if num_classes > 0:
+        x = x.flatten(1)                                                      # :161
+        x = F.relu(linear(p, "_fc6", x))                                      # :162-164
+        x = F.relu(linear(p, "_fc7", x))                                      # :165-167
+        x = linear(p, "_fc8", x)                                              # :168
+    return x
+
+
 def predict(logits):
     """ImageClassification.predict, tasks/image_classification.py:20-23."""
     return torch.argmax(logits, dim=-1)

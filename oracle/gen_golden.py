@@ -115,6 +115,44 @@ def gen_mobilenetv1(batch, wseed, xseed, fname):
         param_names=np.array(list(shapes.keys())), torch_version=torch.__version__)
 
 
+def gen_vgg(arch, batch_norm, batch, wseed, xseed, fname):
+    ref = import_reference("tlxcv/models/classification/vgg.py", "ref_vgg")
+    model = getattr(ref, arch)(batch_norm=batch_norm)
+    shapes = seeded.shapes_of(model)
+    params = seeded.fill(shapes, wseed)
+    model.load_dict(params)
+    model.set_eval()
+    x = torch.from_numpy(seeded.image_batch(batch, xseed))
+    with torch.no_grad():
+        ref_out = model(x)
+        re_out = OF.vgg({k: torch.from_numpy(v) for k, v in params.items()}, x, arch, batch_norm)
+    d = _check(arch + ("_bn" if batch_norm else ""), ref_out, re_out)
+    np.savez_compressed(
+        os.path.join(OUT, fname), arch=arch, batch_norm=batch_norm, weight_seed=wseed, input_seed=xseed, batch=batch,
+        logits=ref_out.numpy().astype(np.float32), argmax=ref_out.argmax(-1).numpy().astype(np.int64),
+        restatement_max_abs_diff=np.float64(d), pinned_by="reference-file-on-tlx_cpu",
+        param_names=np.array(list(shapes.keys())), torch_version=torch.__version__)
+
+
+def gen_alexnet(batch, wseed, xseed, fname):
+    ref = import_reference("tlxcv/models/classification/alexnet.py", "ref_alexnet")
+    model = ref.alexnet()
+    shapes = seeded.shapes_of(model)
+    params = seeded.fill(shapes, wseed)
+    model.load_dict(params)
+    model.set_eval()
+    x = torch.from_numpy(seeded.image_batch(batch, xseed))
+    with torch.no_grad():
+        ref_out = model(x)
+        re_out = OF.alexnet({k: torch.from_numpy(v) for k, v in params.items()}, x)
+    d = _check("alexnet", ref_out, re_out)
+    np.savez_compressed(
+        os.path.join(OUT, fname), arch="alexnet", weight_seed=wseed, input_seed=xseed, batch=batch,
+        logits=ref_out.numpy().astype(np.float32), argmax=ref_out.argmax(-1).numpy().astype(np.int64),
+        restatement_max_abs_diff=np.float64(d), pinned_by="reference-file-on-tlx_cpu",
+        param_names=np.array(list(shapes.keys())), torch_version=torch.__version__)
+
+
 def gen_darknet(batch, hw, wseed, xseed, fname):
     ref = import_reference("tlxcv/models/detection/backbones/darknet.py", "ref_darknet")
     model = ref.DarkNet()
@@ -191,6 +229,9 @@ def main():
     gen_restatement_only("mobilenet_v3_large", "mobilenet_v3_large",
                          lambda p, x: OF.mobilenetv3(p, x, OF.MBV3_LARGE), 1, 9, 7, "mobilenetv3_large_b1.npz", note, hw=128)
     gen_mobilenetv1(2, 4, 1, "mobilenetv1_b2.npz")
+    gen_vgg("vgg16", False, 1, 10, 8, "vgg16_b1.npz")
+    gen_vgg("vgg11", True, 2, 11, 9, "vgg11_bn_b2.npz")
+    gen_alexnet(2, 12, 10, "alexnet_b2.npz")
     gen_darknet(1, 64, 5, 2, "darknet53_b1.npz")
     gen_yolov3(1, 64, 6, 3, "yolov3_b1.npz")
     for extra in EXTRA:

@@ -28,6 +28,14 @@ class xavier_uniform:
         return (torch.rand(tuple(shape), generator=_g) - 0.5) * 0.1
 
 
+class random_uniform:
+    def __init__(self, minval=-0.05, maxval=0.05, seed=None):
+        self.minval, self.maxval = minval, maxval
+
+    def __call__(self, shape, dtype=None):
+        return torch.rand(tuple(shape), generator=_g) * (self.maxval - self.minval) + self.minval
+
+
 def str_to_init(s):
     if callable(s):
         return s

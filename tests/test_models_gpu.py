@@ -54,6 +54,52 @@ def test_classifier_fp16_tracks_golden(dev, fp16_mode, fname, ctor):
     assert (y.argmax(1)[safe] == g["argmax"][safe]).all()
 
 
+# VGG / AlexNet: fixtures from the reference's own vgg.py / alexnet.py on the oracle's stand-in
+VGG_ALEX = [("vgg16_b1.npz", "vgg16", {}), ("vgg11_bn_b2.npz", "vgg11", {"batch_norm": True}), ("alexnet_b2.npz", "alexnet", {})]
+
+
+@pytest.mark.parametrize("fname,ctor,kw", VGG_ALEX, ids=[c[0][:-4] for c in VGG_ALEX])
+def test_vgg_alexnet_fp32_matches_golden_1e4_and_argmax_exact(dev, fp32_mode, fname, ctor, kw):
+    g = np.load(os.path.join(GOLDEN, fname))
+    m = build(ctor, int(g["weight_seed"]), dev, **kw)
+    x = torch.from_numpy(seeded.image_batch(int(g["batch"]), int(g["input_seed"]))).to(dev)
+    y = m(x)
+    ref = g["logits"]
+    err = np.abs(y.cpu().numpy() - ref).max()
+    assert err <= 1e-4 * max(1.0, np.abs(ref).max()), err       # logits reach +-40 here: 1e-4 relative to their scale
+    from tlxcv_amd.tasks import ImageClassification
+    assert (ImageClassification(m).predict(x).cpu().numpy() == g["argmax"]).all()
+
+
+@pytest.mark.parametrize("fname,ctor,kw", VGG_ALEX, ids=[c[0][:-4] for c in VGG_ALEX])
+def test_vgg_alexnet_fp16_tracks_golden(dev, fp16_mode, fname, ctor, kw):
+    g = np.load(os.path.join(GOLDEN, fname))
+    m = build(ctor, int(g["weight_seed"]), dev, **kw)
+    x = torch.from_numpy(seeded.image_batch(int(g["batch"]), int(g["input_seed"]))).to(dev)
+    y = m(x).float().cpu().numpy()
+    ref = g["logits"]
+    err = np.abs(y - ref).max()
+    assert err <= 0.02 * (ref.max() - ref.min()), err
+    s = np.sort(ref, axis=1)
+    safe = (s[:, -1] - s[:, -2]) > 2 * err
+    assert (y.argmax(1)[safe] == g["argmax"][safe]).all()
+
+
+def test_vgg_adaptive_pool_off_the_identity_size(dev, fp32_mode):
+    """160 x 160 input: the feature map is 5 x 5 and AdaptiveAvgPool2d((7,7)) really pools (vgg.py:36-39, 54-55)."""
+    from oracle import functional as OF
+    from tlxcv_amd import models
+    m = models.vgg11()
+    params = seeded.fill(seeded.shapes_of(m), 13)
+    m.load_dict(params)
+    m = m.to(dev).set_eval()
+    x = torch.from_numpy(seeded.image_batch(1, 3, hw=160))
+    with torch.no_grad():
+        ref = OF.vgg({k: torch.from_numpy(v) for k, v in params.items()}, x, "vgg11", False).numpy()
+    y = m(x.to(dev)).cpu().numpy()
+    assert np.abs(y - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+
+
 def _close(got, ref, dtype):
     got = got.float().cpu().numpy()
     scale = np.abs(ref).max()

@@ -46,6 +46,7 @@ PROTOTYPES = {
     "tlxmi_dwconv2d": [C.POINTER(DwConvDesc), _vp, _vp, _vp, _vp, _vp, _vp],
     "tlxmi_maxpool2d": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "tlxmi_global_avgpool": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "tlxmi_adaptive_avgpool2d": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "tlxmi_affine_act": [_vp, _vp, _vp, _vp, _vp, _i, _l, _i, _i, _i, _i, _i, _f, _u, _vp],
     "tlxmi_scale_channels": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "tlxmi_layernorm": [_vp, _vp, _vp, _vp, _i, _l, _i, _i, _i, _f, _vp],

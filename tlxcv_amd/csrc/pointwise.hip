@@ -183,6 +183,40 @@ __global__ void global_avgpool_kernel(const T* __restrict__ x, T* __restrict__ y
     }
 }
 
+// nn.AdaptiveAvgPool2d((OH, OW)) (vgg.py:36-39): output (oh, ow) averages rows [floor(oh*H/OH), ceil((oh+1)*H/OH))
+// and the same for columns — the definition torch / paddle / TLX share
+template <typename T>
+__global__ void adaptive_avgpool_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C, int OH,
+                                        int OW, int x_ld, int y_ld) {
+    constexpr int V = Chunk<T>::N;
+    const int nch = C / V;
+    const long total = (long)N * OH * OW * nch;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % nch);
+        long p = i / nch;
+        const int ow = (int)(p % OW);
+        p /= OW;
+        const int oh = (int)(p % OH);
+        const long n = p / OH;
+        const int h0 = (oh * H) / OH, h1 = ((oh + 1) * H + OH - 1) / OH;
+        const int w0 = (ow * W) / OW, w1 = ((ow + 1) * W + OW - 1) / OW;
+        float acc[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] = 0.f;
+        for (int h = h0; h < h1; ++h)
+            for (int w = w0; w < w1; ++w) {
+                float v[V];
+                Chunk<T>::load(x + ((n * H + h) * W + w) * x_ld + cg * V, v);
+#pragma unroll
+                for (int e = 0; e < V; ++e) acc[e] += v[e];
+            }
+        const float inv = 1.f / (float)((h1 - h0) * (w1 - w0));
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] *= inv;
+        Chunk<T>::store(y + ((n * OH + oh) * OW + ow) * y_ld + cg * V, acc);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // y = act(x*scale + shift (+res)) (+res)
 // ------------------------------------------------------------------------------------------
@@ -458,6 +492,20 @@ extern "C" int tlxmi_global_avgpool(const void* x, void* y, int dt, int N, int H
     else
         hipLaunchKernelGGL((global_avgpool_kernel<float>), g, b, 0, as_stream(stream), (const float*)x, (float*)y, N, HW, C, x_ld, y_ld);
     return check_launch("global_avgpool");
+}
+
+extern "C" int tlxmi_adaptive_avgpool2d(const void* x, void* y, int dt, int N, int H, int W, int C, int OH, int OW,
+                                        int x_ld, int y_ld, void* stream) {
+    TLXMI_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && OH > 0 && OW > 0, TLXMI_ERR_BAD_ARG, "adaptive_avgpool2d: bad argument");
+    REQUIRE_CHUNKED("adaptive_avgpool2d", dt, C, x_ld, y_ld);
+    TLXMI_REQUIRE(aligned16(x) && aligned16(y), TLXMI_ERR_ALIGNMENT, "adaptive_avgpool2d: buffers must be 16-byte aligned");
+    const long work = (long)N * OH * OW * (C / VECN(dt));
+    dim3 g(grid_for(work)), b(256);
+    if (dt == TLXMI_F16)
+        hipLaunchKernelGGL((adaptive_avgpool_kernel<half_t>), g, b, 0, as_stream(stream), (const half_t*)x, (half_t*)y, N, H, W, C, OH, OW, x_ld, y_ld);
+    else
+        hipLaunchKernelGGL((adaptive_avgpool_kernel<float>), g, b, 0, as_stream(stream), (const float*)x, (float*)y, N, H, W, C, OH, OW, x_ld, y_ld);
+    return check_launch("adaptive_avgpool2d");
 }
 
 extern "C" int tlxmi_affine_act(const void* x, const float* scale, const float* shift, const void* res, void* y,

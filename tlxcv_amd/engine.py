@@ -388,6 +388,18 @@ def scale_channels(x, s):
     return y
 
 
+def adaptive_avgpool2d(x, out_hw):
+    """(N,H,W,C) -> (N,OH,OW,C), windows as nn.AdaptiveAvgPool2d (vgg.py:36-39)."""
+    need_gpu(x, "input")
+    N, H, W, Cc = x.shape
+    OH, OW = out_hw
+    if (OH, OW) == (H, W):
+        return x
+    y = torch.empty((N, OH, OW, Cc), dtype=x.dtype, device=x.device)
+    _lib.call("tlxmi_adaptive_avgpool2d", _p(x), _p(y), dt_code(x.dtype), N, H, W, Cc, OH, OW, x.stride(2), Cc, _stream())
+    return y
+
+
 def layernorm(x, gamma, beta, eps):
     need_gpu(x, "input")
     if not x.is_contiguous():

@@ -9,3 +9,5 @@ from .swin_transformer import (SwinTransformer, swintransformer_tiny_patch4_wind
 from .mobilenetv1 import MobileNetV1  # noqa: F401
 from .mobilenetv2 import (MobileNetV2, mobilenet_v2, MobileNetV3Small, MobileNetV3Large, mobilenet_v3_small,  # noqa: F401
                           mobilenet_v3_large)
+from .vgg import VGG, vgg11, vgg13, vgg16, vgg19  # noqa: F401
+from .alexnet import AlexNet, alexnet  # noqa: F401

@@ -554,20 +554,22 @@ class MaxPool2d(Module):
 
 
 class AdaptiveAvgPool2d(Module):
-    """Only output_size (1,1) occurs on the hot path (resnet.py:228-231, mobilenetv1.py:246)."""
+    """nn.AdaptiveAvgPool2d(output_size, data_format): (1,1) on the hot path (resnet.py:228-231, mobilenetv1.py:246),
+    (7,7) in VGG (vgg.py:36-39; the identity at 224 x 224)."""
 
     def __init__(self, output_size, data_format="channels_last", name=None):
         super().__init__(name=name)
         self.output_size = _tup2(output_size)
-        if self.output_size != (1, 1):
-            raise NotImplementedError("AdaptiveAvgPool2d: only output_size (1,1)")
         self.data_format = data_format
 
+    def run_nhwc(self, v):
+        if self.output_size == (1, 1):
+            N = v.shape[0]
+            return E.global_avgpool(v).view(N, 1, 1, -1)
+        return E.adaptive_avgpool2d(v, self.output_size)
+
     def forward(self, x):
-        v = as_nhwc(x, self.data_format)
-        y = E.global_avgpool(v)
-        N, Cc = y.shape
-        return y.view(N, 1, 1, Cc) if self.data_format == "channels_last" else y.view(N, Cc, 1, 1)
+        return from_nhwc(self.run_nhwc(as_nhwc(x, self.data_format)), self.data_format)
 
 
 class AdaptiveAvgPool1d(Module):

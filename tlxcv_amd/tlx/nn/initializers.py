@@ -6,7 +6,7 @@ import math
 
 import torch
 
-__all__ = ["Constant", "Zeros", "Ones", "TruncatedNormal", "RandomNormal", "xavier_uniform", "XavierUniform",
+__all__ = ["Constant", "Zeros", "Ones", "TruncatedNormal", "RandomNormal", "RandomUniform", "random_uniform", "xavier_uniform", "XavierUniform",
            "he_normal", "HeNormal", "str_to_init"]
 
 _gen = torch.Generator().manual_seed(0)
@@ -36,6 +36,19 @@ class RandomNormal:
 
     def __call__(self, shape, dtype=torch.float32):
         return torch.randn(tuple(shape), generator=_gen) * self.stddev + self.mean
+
+
+class RandomUniform:
+    """random_uniform(minval, maxval) — alexnet.py:6,32-33,134."""
+
+    def __init__(self, minval=-0.05, maxval=0.05, seed=None):
+        self.minval, self.maxval = minval, maxval
+
+    def __call__(self, shape, dtype=torch.float32):
+        return torch.rand(tuple(shape), generator=_gen) * (self.maxval - self.minval) + self.minval
+
+
+random_uniform = RandomUniform
 
 
 class TruncatedNormal:
@@ -85,6 +98,7 @@ _BY_NAME = {
     "ones": Ones,
     "truncated_normal": lambda: TruncatedNormal(stddev=0.02),
     "random_normal": RandomNormal,
+    "random_uniform": RandomUniform,
     "xavier_uniform": XavierUniform,
     "he_normal": HeNormal,
 }
