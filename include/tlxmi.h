@@ -133,6 +133,23 @@ int tlxmi_conv2d(const tlxmi_conv2d_desc* d, const void* x, const void* w_packed
                  const void* res /* or NULL */, void* y, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Grouped convolution, 1 < groups < C: nn.GroupConv2d(n_group=cardinality) of the ResNeXt bottleneck,
+ * resnext.py:30-40 (constructed at :83-91 with groups = 32 / 64), + BatchNorm(act='relu') :46-52.
+ * d->C / d->Cout are the TOTAL input / output channels (both divisible by groups), x_ld / y_ld the pixel
+ * strides; everything else as tlxmi_conv2d.  m consecutive groups are merged into one launch chunk with a
+ * block-diagonal filter (tlxmi_group_conv_chunks() chunks of C/chunks -> Cout/chunks channels; 0 = the
+ * channel counts cannot be merged into 16-byte aligned chunks -> TLXMI_ERR_UNSUPPORTED).
+ *   src: OIHW fp32 [Cout][Cin/groups][R][S]; dst: `chunks` packed filters of tlxmi_pack_filter's layout.
+ * groups == 1 forwards to tlxmi_conv2d / tlxmi_pack_filter; groups == C is tlxmi_dwconv2d's job.
+ * ---------------------------------------------------------------------------------------- */
+int tlxmi_group_conv_chunks(int Cin, int Cout, int groups, int dtype);
+size_t tlxmi_packed_group_filter_bytes(int Cout, int Cin, int R, int S, int groups, int dtype);
+int tlxmi_pack_group_filter(const float* src_oihw, void* dst, int Cout, int Cin, int R, int S, int groups,
+                            int dtype, void* stream);
+int tlxmi_group_conv2d(const tlxmi_conv2d_desc* d, int groups, const void* x, const void* w_packed,
+                       const float* scale, const float* shift, const void* res, void* y, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Depthwise conv (groups == C == Cout), HBM-bound, no MFMA.
  * Replaces nn.GroupConv2d(n_group=C)+BN+act: mobilenetv1.py:79-88, mobilenetv2.py:30,
  * mobilenetv3.py (k3/k5).   w: [R][S][C] dtype.

@@ -142,6 +142,36 @@ def alexnet(p, x, num_classes=1000):
     return x
 
 
+# ---------------------------------------------------------------------------------------------
+# ResNeXt — models/classification/resnext.py
+# ---------------------------------------------------------------------------------------------
+RESNEXT_DEPTH = {50: [3, 4, 6, 3], 101: [3, 4, 23, 3], 152: [3, 8, 36, 3]}   # resnext.py:141-146
+
+
+def _convbn(p, pre, x, stride=1, groups=1, relu=False):
+    """ConvBNLayer.forward resnext.py:54-57: GroupConv2d (no bias, padding (k-1)//2 :35) + BatchNorm(act) :46-52."""
+    k = _t(p, pre + "._conv.filters").shape[-1]
+    y = bn(p, pre + ".batch_norm", conv(p, pre + "._conv", x, stride, (k - 1) // 2, 1, groups))
+    return F.relu(y) if relu else y
+
+
+def resnext(p, x, layers=50, cardinality=32):
+    """ResNeXt.forward resnext.py:205-213; BottleneckBlock.forward :109-119."""
+    x = _convbn(p, "conv", x, 2, 1, True)                                     # :206  7x7/2 pad 3 + bn + relu
+    x = F.max_pool2d(x, 3, 2, 1)                                              # :207
+    for block, n in enumerate(RESNEXT_DEPTH[layers]):
+        for i in range(n):
+            pre = f"bb_{block}_{i}"
+            stride = 2 if i == 0 and block != 0 else 1                        # :181
+            y = _convbn(p, pre + ".conv0", x, 1, 1, True)                     # :110  1x1
+            y = _convbn(p, pre + ".conv1", y, stride, cardinality, True)      # :111  3x3, groups = cardinality
+            y = _convbn(p, pre + ".conv2", y)                                 # :112  1x1, no activation
+            short = x if i > 0 else _convbn(p, pre + ".short", x, stride)     # :113-116 (first block of a stage projects)
+            x = F.relu(short + y)                                             # :117-118
+    x = F.adaptive_avg_pool2d(x, 1).reshape(x.shape[0], -1)                   # :210-211
+    return linear(p, "out", x)                                                # :212
+
+
 def predict(logits):
     """ImageClassification.predict, tasks/image_classification.py:20-23."""
     return torch.argmax(logits, dim=-1)

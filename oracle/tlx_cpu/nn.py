@@ -14,6 +14,14 @@ def _falsy_bias(b_init):
     return b_init is None or b_init is False or (isinstance(b_init, (tuple, list)) and len(b_init) == 0)
 
 
+def str_to_act(act):
+    """`act` given by name (resnext.py:46-52 BatchNorm(act='relu'))."""
+    if act is None or not isinstance(act, str):
+        return act
+    return {"relu": F.relu, "relu6": F.relu6, "sigmoid": torch.sigmoid, "gelu": F.gelu, "hardswish": F.hardswish,
+            "hard_sigmoid": F.hardsigmoid, "leaky_relu": F.leaky_relu, "tanh": torch.tanh}[act.lower()]
+
+
 def _tup2(v):
     return (v, v) if isinstance(v, int) else tuple(int(a) for a in v)
 
@@ -34,7 +42,7 @@ class Module(torch.nn.Module):
             for k, v in list(vars(m).items()):
                 if isinstance(v, (list, tuple)) and v and all(isinstance(e, torch.nn.Module) for e in v):
                     for i, e in enumerate(v):
-                        if f"{k}_{i}" not in m._modules:
+                        if f"{k}_{i}" not in m._modules and not any(e is r for r in m._modules.values()):
                             m.add_module(f"{k}_{i}", e)
             stack.extend(m._modules.values())
 
@@ -125,7 +133,7 @@ class GroupConv2d(Module):
                  in_channels=None, name=None):
         super().__init__(name=name)
         self.kernel_size, self.stride, self.dilation = _tup2(kernel_size), _tup2(stride), _tup2(dilation)
-        self.n_group, self.data_format, self.act = n_group, data_format, act
+        self.n_group, self.data_format, self.act = n_group, data_format, str_to_act(act)
         if isinstance(padding, str):
             self.padding = (0, 0) if padding.upper() == "VALID" else tuple(
                 d * (k - 1) // 2 for k, d in zip(self.kernel_size, self.dilation))
@@ -154,7 +162,7 @@ class BatchNorm2d(Module):
                  moving_mean_init="zeros", moving_var_init="ones", num_features=None, data_format="channels_last",
                  name=None):
         super().__init__(name=name)
-        self.epsilon, self.data_format, self.act = epsilon, data_format, act
+        self.epsilon, self.data_format, self.act = epsilon, data_format, str_to_act(act)
         n = (num_features,)
         self.gamma = Parameter(str_to_init(gamma_init)(shape=n))
         self.beta = Parameter(str_to_init(beta_init)(shape=n))

@@ -203,3 +203,55 @@ def test_thin_input_full_size_matches_the_implicit_gemm(dev, cfg):
         finally:
             os.environ.pop("TLXMI_HALO", None)
     torch.testing.assert_close(outs[0], outs[1], atol=4e-3, rtol=4e-3)
+
+
+# ---- grouped convolution (tlxmi_group_conv2d; resnext.py:83-91 cardinality 32 / 64): every ResNeXt-50 stage
+# shape, odd group sizes that still merge into 16-byte chunks, residual + every chunk count, and the error path
+GROUP_CASES = [
+    # (N, Cin, Cout, groups, k, stride, pad, H, W, res, act)
+    (2, 128, 128, 32, 3, 1, 1, 24, 24, False, 1),    # 32x4d stage 1: 4 channels per group, 2 launch chunks (fp16)
+    (2, 256, 256, 32, 3, 2, 1, 23, 23, False, 1),    # stage 2 entry, stride 2, odd extent
+    (1, 512, 512, 32, 3, 1, 1, 14, 14, False, 1),    # stage 3: 16 per group
+    (1, 1024, 1024, 32, 3, 1, 1, 7, 7, False, 1),    # stage 4: 32 per group, 16 chunks
+    (1, 256, 256, 64, 3, 1, 1, 12, 20, False, 1),    # 64x4d stage 1
+    (1, 2048, 2048, 64, 3, 2, 1, 9, 9, False, 1),    # 64x4d stage 4 entry
+    (1, 64, 128, 4, 3, 1, 1, 10, 10, True, 3),       # Cin != Cout per group (16 -> 32), residual, leaky
+    (1, 96, 48, 3, 1, 1, 0, 6, 6, False, 0),         # 1x1, 3 groups of 32 -> 16 merged into one chunk
+    (1, 48, 96, 2, 5, 1, 2, 11, 11, True, 2),        # 5x5, 2 groups of 24 -> 48
+    (1, 40, 40, 5, 3, 1, 1, 8, 8, False, 1),         # 8 per group: groups merge until all 5 are one chunk
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["fp32", "fp16"])
+@pytest.mark.parametrize("cfg", GROUP_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_group_conv(dev, dtype, cfg):
+    N, Cin, Cout, groups, k, stride, pad, H, W, with_res, act = cfg
+    rng = np.random.default_rng(17)
+    cg = Cin // groups
+    x = rnd(rng, (N, Cin, H, W))
+    w = rnd(rng, (Cout, cg, k, k), (2.0 / (cg * k * k)) ** 0.5)
+    scale = torch.from_numpy(rng.uniform(0.5, 1.5, Cout).astype(np.float32))
+    shift = rnd(rng, (Cout,), 0.1)
+    if dtype == torch.float16:
+        x, w = q16(x), q16(w)
+    Ho = (H + 2 * pad - k) // stride + 1
+    Wo = (W + 2 * pad - k) // stride + 1
+    res = rnd(rng, (N, Cout, Ho, Wo)) if with_res else None
+    if res is not None and dtype == torch.float16:
+        res = q16(res)
+    want = OF.conv_bn_act(x, w, scale, shift, res, act, 0.1, (stride, stride), (pad, pad), 1, groups, False)
+    pk = E.PackedGroupFilter(w.to(dev), groups, dtype)
+    assert pk.chunks >= 1 and groups % pk.chunks == 0
+    xe = x.permute(0, 2, 3, 1).contiguous().to(dtype).to(dev)
+    re_ = res.permute(0, 2, 3, 1).contiguous().to(dtype).to(dev) if res is not None else None
+    got = E.group_conv2d(xe, pk, stride, pad, 1, scale.to(dev), shift.to(dev), re_, act, 0.1)
+    torch.cuda.synchronize()
+    assert got.shape == (N, Ho, Wo, Cout)
+    torch.testing.assert_close(engine_to_nchw(got), want, **tol(dtype))
+
+
+def test_group_conv_rejects_unmergeable_channel_counts(dev):
+    """3 channels per group, 5 groups: no merge of whole groups makes 16-byte pixel chunks (fp16) — the packer says so."""
+    w = torch.randn(15, 3, 3, 3)
+    with pytest.raises(NotImplementedError):
+        E.PackedGroupFilter(w.to(dev), 5, torch.float16)

@@ -100,6 +100,43 @@ def test_vgg_adaptive_pool_off_the_identity_size(dev, fp32_mode):
     assert np.abs(y - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
 
 
+# ResNeXt: fixtures from the reference's own resnext.py; grouped 3x3 through tlxmi_group_conv2d
+RESNEXT = ["resnext50_32x4d_b2.npz", "resnext50_64x4d_b1.npz"]
+
+
+def _resnext(g, dev):
+    from tlxcv_amd import models
+    m = models.ResNeXt(layers=int(g["layers"]), cardinality=int(g["cardinality"]))
+    m.load_dict(seeded.fill(seeded.shapes_of(m), int(g["weight_seed"])))
+    x = torch.from_numpy(seeded.image_batch(int(g["batch"]), int(g["input_seed"]), int(g["hw"]))).to(dev)
+    return m.to(dev).set_eval(), x
+
+
+@pytest.mark.parametrize("fname", RESNEXT, ids=[f[:-4] for f in RESNEXT])
+def test_resnext_fp32_matches_golden_1e4_and_argmax_exact(dev, fp32_mode, fname):
+    g = np.load(os.path.join(GOLDEN, fname))
+    m, x = _resnext(g, dev)
+    y = m(x)
+    ref = g["logits"]
+    err = np.abs(y.cpu().numpy() - ref).max()
+    assert err <= 1e-4 * max(1.0, np.abs(ref).max()), err
+    from tlxcv_amd.tasks import ImageClassification
+    assert (ImageClassification(m).predict(x).cpu().numpy() == g["argmax"]).all()
+
+
+@pytest.mark.parametrize("fname", RESNEXT, ids=[f[:-4] for f in RESNEXT])
+def test_resnext_fp16_tracks_golden(dev, fp16_mode, fname):
+    g = np.load(os.path.join(GOLDEN, fname))
+    m, x = _resnext(g, dev)
+    y = m(x).float().cpu().numpy()
+    ref = g["logits"]
+    err = np.abs(y - ref).max()
+    assert err <= 0.02 * (ref.max() - ref.min()), err
+    s = np.sort(ref, axis=1)
+    safe = (s[:, -1] - s[:, -2]) > 2 * err
+    assert (y.argmax(1)[safe] == g["argmax"][safe]).all()
+
+
 def _close(got, ref, dtype):
     got = got.float().cpu().numpy()
     scale = np.abs(ref).max()

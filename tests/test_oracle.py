@@ -86,6 +86,23 @@ def test_vgg_and_alexnet_restatements_reproduce_golden():
         assert np.abs(y.numpy() - g["logits"]).max() <= 1e-3 and (y.argmax(-1).numpy() == g["argmax"]).all()
 
 
+def test_resnext_restatement_reproduces_golden_and_parameter_tree_matches_the_reference():
+    """Fixtures written by the reference's own resnext.py (oracle/gen_golden.py); the engine-side constructor must
+    expose the parameter names the reference file produced (resnext.py:18-203)."""
+    from tlxcv_amd import models
+    for fname in ("resnext50_32x4d_b2.npz", "resnext50_64x4d_b1.npz"):
+        g = np.load(os.path.join(GOLDEN, fname))
+        m = models.ResNeXt(layers=int(g["layers"]), cardinality=int(g["cardinality"]))
+        shapes = seeded.shapes_of(m)
+        assert list(shapes.keys()) == [str(n) for n in g["param_names"]]
+        p = {k: torch.from_numpy(v) for k, v in seeded.fill(shapes, int(g["weight_seed"])).items()}
+        x = torch.from_numpy(seeded.image_batch(int(g["batch"]), int(g["input_seed"]), int(g["hw"])))
+        with torch.no_grad():
+            y = OF.resnext(p, x, int(g["layers"]), int(g["cardinality"]))
+        assert str(g["pinned_by"]) == "reference-file-on-tlx_cpu"
+        assert np.abs(y.numpy() - g["logits"]).max() <= 1e-3 and (y.argmax(-1).numpy() == g["argmax"]).all()
+
+
 def test_swin_helpers_against_their_definitions():
     """The restated index / mask helpers checked against independent brute-force definitions."""
     ws = 7

@@ -43,6 +43,8 @@ PROTOTYPES = {
     "tlxmi_pack_filter": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     "tlxmi_fold_bn": [_vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp],
     "tlxmi_conv2d": [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "tlxmi_group_conv2d": [C.POINTER(ConvDesc), _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "tlxmi_pack_group_filter": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "tlxmi_dwconv2d": [C.POINTER(DwConvDesc), _vp, _vp, _vp, _vp, _vp, _vp],
     "tlxmi_maxpool2d": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "tlxmi_global_avgpool": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
@@ -68,6 +70,8 @@ _SPECIAL = {
     "tlxmi_last_error": ([], C.c_char_p),
     "tlxmi_device_count": ([], C.c_int),
     "tlxmi_packed_filter_bytes": ([_i, _i, _i, _i, _i], C.c_size_t),
+    "tlxmi_packed_group_filter_bytes": ([_i, _i, _i, _i, _i, _i], C.c_size_t),
+    "tlxmi_group_conv_chunks": ([_i, _i, _i, _i], C.c_int),
 }
 ALL_SYMBOLS = sorted(list(PROTOTYPES) + list(_SPECIAL))
 

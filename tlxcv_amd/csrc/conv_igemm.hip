@@ -60,6 +60,11 @@ struct ConvArgs {
     unsigned y_bytes;           // extent of y when it may be written through a descriptor (0: plain stores)
     int store_policy;           // 0 plain, 16 sc1 (write-through, line dropped from L2), 2 nt
     int sb_off;                 // LDS byte offset of the block's scale/shift table (2 x BN floats)
+    // grouped convolution: blockIdx.y = launch chunk (a few merged groups, block-diagonal filter); every chunk is
+    // this same problem at a byte / channel offset.  nchunk == 1 and all strides 0 for the dense convolution.
+    int nchunk;
+    int gx, gy, gres, gc;       // per-chunk byte offsets into x / y / res pixels, channel offset of scale / shift
+    unsigned gw;                // bytes between the packed filters of consecutive chunks
 };
 
 __device__ __attribute__((aligned(16))) unsigned g_zero_page[4];  // source of padding / tail chunks
@@ -129,8 +134,18 @@ static __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const char* p,
 // RESP = the residual tile is prefetched into registers at kernel entry (dense, 16-byte-aligned residual):
 // its HBM latency then overlaps the first DMA stage instead of starting after the last MFMA.
 template <typename T, int BM, int BN, bool IS_1X1, int WGM, int STAGES, bool RESP>
-__global__ __launch_bounds__(WGM * 128) void conv_igemm_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(WGM * 128) void conv_igemm_kernel(const ConvArgs a0) {
     constexpr int ES = (int)sizeof(T);
+    ConvArgs a = a0;
+    if (a.nchunk > 1) {
+        const int g = blockIdx.y;
+        a.x += (size_t)g * a.gx; a.x_bytes -= (unsigned)(g * a.gx);
+        a.w += (size_t)g * a.gw;
+        a.y += (size_t)g * a.gy; if (a.y_bytes) a.y_bytes -= (unsigned)(g * a.gy);
+        if (a.res) a.res += (size_t)g * a.gres;
+        if (a.scale) a.scale += g * a.gc;
+        if (a.shift) a.shift += g * a.gc;
+    }
     constexpr int NW = WGM * 2, NT = NW * 64;     // waves, threads
     constexpr int WM = BM / WGM, WN = BN / 2;     // wave tile (pixels x channels)
     constexpr int PI = WM / 16, CI = WN / 16;
@@ -531,7 +546,7 @@ template <typename T, int BM, int BN, int WGM, int STAGES> static int launch(con
         }
     }
     void* args[] = {&b};
-    hipError_t e = hipLaunchKernel(fns[which], dim3((unsigned)grid), dim3(WGM * 128), args, lds, st);
+    hipError_t e = hipLaunchKernel(fns[which], dim3((unsigned)grid, (unsigned)a.nchunk), dim3(WGM * 128), args, lds, st);
     if (e != hipSuccess) return fail(TLXMI_ERR_LAUNCH, "conv2d: HIP launch failed: %s", hipGetErrorString(e));
     return TLXMI_OK;
 }
@@ -549,7 +564,7 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
         const int PB = a.C * 2;
         int forced_h = -1;
         { const char* e = getenv("TLXMI_HALO"); if (e && *e) forced_h = atoi(e); }   // 0: off (A/B runs)
-        if (forced_h != 0 && a.sh == 1 && a.sw == 1 && a.dh == 1 && a.dw == 1 && (a.R > 1 || a.S > 1) && conv_halo_tile_pixels(a.R, a.S, PB) > 0 &&
+        if (forced_h != 0 && a.nchunk == 1 && a.sh == 1 && a.sw == 1 && a.dh == 1 && a.dw == 1 && (a.R > 1 || a.S > 1) && conv_halo_tile_pixels(a.R, a.S, PB) > 0 &&
             conv_halo_act_ok(a.act) && !a.strided_n && a.vec_io && a.Cout % 8 == 0 && a.Cout <= 128 && a.y_bytes != 0 &&
             a.HoWo >= 1024 && (!a.res || (long long)a.M * a.res_ld * 2 < (1ll << 31))) {
             HaloArgs h;
@@ -585,7 +600,7 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
     constexpr int NC = 9;
     Cand cands[NC] = {{128, 128, 1.00f}, {64, 128, 0.85f}, {128, 64, 0.85f}, {64, 64, 0.70f}, {256, 128, 0.90f},
                       {256, 256, 1.12f}, {256, 128, 1.20f}, {256, 256, 1.40f}, {256, 256, 1.50f}};
-    const bool gemm256_ok = a.R == 1 && a.S == 1 && a.ph == 0 && a.pw == 0 && a.sh == 1 && a.sw == 1 && !a.strided_n &&
+    const bool gemm256_ok = a.nchunk == 1 && a.R == 1 && a.S == 1 && a.ph == 0 && a.pw == 0 && a.sh == 1 && a.sw == 1 && !a.strided_n &&
                             a.vec_io && a.Cout % 8 == 0 && a.y_bytes != 0 && a.Cout >= 256 && a.ktiles >= 2 &&
                             (!a.res || (long long)a.M * a.res_ld * (long long)sizeof(T) < (1ll << 31));
     if (!gemm256_ok) cands[5].eff = cands[6].eff = cands[7].eff = cands[8].eff = 0.f;
@@ -627,13 +642,13 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
         if (per_cu < 1) continue;
         const int reg_cap = i == 6 ? 2 : i >= 4 ? 1 : (bm == 128 && bn == 128) ? 3 : ((bm == 64 && bn == 64) ? 8 : 5);
         if (per_cu > reg_cap) per_cu = reg_cap;
-        const long blocks = (long)((a.M + bm - 1) / bm) * ((a.Cout + bn - 1) / bn);
+        const long blocks = (long)((a.M + bm - 1) / bm) * ((a.Cout + bn - 1) / bn) * a.nchunk;
         const long slots = (long)cus * per_cu;
         const long rounds = (blocks + slots - 1) / slots;
         float quant = (float)blocks / (float)(rounds * slots);
         if (i >= 7 && tail_split) quant = (float)blocks / (((float)full_rounds + 0.6f) * slots);   // the tail round: ~0.6 of a tile time
         // wasted work inside partial tiles
-        const float fill = ((float)a.M * a.Cout) / ((float)blocks * bm * bn);
+        const float fill = ((float)a.M * a.Cout * a.nchunk) / ((float)blocks * bm * bn);
         const float score = quant * fill * cands[i].eff;
         if (score > best_score) { best_score = score; best = i; }
     }
@@ -712,9 +727,9 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
 
 using namespace tlxmi;
 
-extern "C" int tlxmi_conv2d(const tlxmi_conv2d_desc* d, const void* x, const void* w_packed,
-                            const float* scale, const float* shift, const void* res, void* y,
-                            void* stream) {
+// nchunk launch chunks of (C / nchunk) -> (Cout / nchunk) channels each; nchunk == 1: the dense convolution
+static int conv2d_impl(const tlxmi_conv2d_desc* d, int nchunk, const void* x, const void* w_packed,
+                       const float* scale, const float* shift, const void* res, void* y, void* stream) {
     TLXMI_REQUIRE(d && x && w_packed && y, TLXMI_ERR_BAD_ARG, "conv2d: null descriptor or buffer");
     TLXMI_REQUIRE(d->dtype == TLXMI_F16 || d->dtype == TLXMI_F32, TLXMI_ERR_BAD_ARG, "conv2d: bad dtype %d", d->dtype);
     TLXMI_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->C > 0 && d->Cout > 0 && d->R > 0 && d->S > 0,
@@ -741,12 +756,13 @@ extern "C" int tlxmi_conv2d(const tlxmi_conv2d_desc* d, const void* x, const voi
     ConvArgs a;
     a.x = (const char*)x; a.w = (const char*)w_packed; a.y = (char*)y;
     a.scale = scale; a.shift = shift; a.res = (const char*)res;
-    a.N = d->N; a.H = d->H; a.W = d->W; a.C = d->C; a.Cout = d->Cout; a.R = d->R; a.S = d->S;
+    const int cw_in = d->C / nchunk, cw_out = d->Cout / nchunk;   // channels of one launch chunk
+    a.N = d->N; a.H = d->H; a.W = d->W; a.C = cw_in; a.Cout = cw_out; a.R = d->R; a.S = d->S;
     a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_h; a.pw = d->pad_w; a.dh = d->dil_h; a.dw = d->dil_w;
     a.Ho = d->Ho; a.Wo = d->Wo; a.x_ld = d->x_ld; a.y_ld = d->y_ld; a.res_ld = res ? d->res_ld : 0;
     a.act = d->act; a.act_param = d->act_param; a.flags = d->flags;
     a.M = (int)M; a.HoWo = d->Ho * d->Wo;
-    a.cpt = d->C * es / 16;
+    a.cpt = cw_in * es / 16;
     a.kchunks = d->R * d->S * a.cpt;
     a.ktiles = (a.kchunks + 7) / 8;
     a.Kp_bytes = a.ktiles * 128;
@@ -761,7 +777,12 @@ extern "C" int tlxmi_conv2d(const tlxmi_conv2d_desc* d, const void* x, const voi
         a.y_bytes = yb < (1ll << 31) ? (unsigned)yb : 0u;
         a.store_policy = (a.y_bytes && !d->y_nstride) ? pol : 0;
     }
-    a.w_bytes = (unsigned)(((size_t)(d->Cout + 127) / 128 * 128) * (size_t)a.Kp_bytes);
+    a.w_bytes = (unsigned)(((size_t)(cw_out + 127) / 128 * 128) * (size_t)a.Kp_bytes);
+    a.nchunk = nchunk;
+    a.gx = nchunk > 1 ? cw_in * es : 0;
+    a.gy = a.gres = nchunk > 1 ? cw_out * es : 0;
+    a.gc = nchunk > 1 ? cw_out : 0;
+    a.gw = nchunk > 1 ? a.w_bytes : 0u;
     const int vecn = 16 / es;  // elements per 16 bytes
     const bool bcast = res && (d->flags & TLXMI_EPI_RES_BCAST_N);
     TLXMI_REQUIRE(d->y_nstride >= 0 && d->res_nstride >= 0, TLXMI_ERR_BAD_ARG, "conv2d: negative batch stride");
@@ -773,6 +794,74 @@ extern "C" int tlxmi_conv2d(const tlxmi_conv2d_desc* d, const void* x, const voi
     const int rc = d->dtype == TLXMI_F16 ? dispatch<half_t>(a, as_stream(stream)) : dispatch<float>(a, as_stream(stream));
     if (rc != TLXMI_OK) return rc;
     return check_launch("conv2d");
+}
+
+extern "C" int tlxmi_conv2d(const tlxmi_conv2d_desc* d, const void* x, const void* w_packed,
+                            const float* scale, const float* shift, const void* res, void* y,
+                            void* stream) {
+    return conv2d_impl(d, 1, x, w_packed, scale, shift, res, y, stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// Grouped convolution, 1 < groups < C (resnext.py:30-40 via :83-91, n_group = cardinality 32 / 64).
+// m consecutive groups are merged into one launch chunk whose filter is block-diagonal ([m*cg_out][taps][m*cg_in],
+// zeros off the diagonal blocks), wide enough that a filter tap is at least one 128-byte K tile and the chunk
+// fills a 64-channel MFMA tile; every chunk is then the dense implicit GEMM at a channel offset (blockIdx.y).
+// The zero blocks cost MFMA work (x m), not HBM bytes: the layer stays bound by its activation traffic.
+// ------------------------------------------------------------------------------------------
+namespace tlxmi {
+static int group_chunks(int Cin, int Cout, int groups, int dtype) {
+    if (groups <= 1 || Cin <= 0 || Cout <= 0 || Cin % groups || Cout % groups) return 0;
+    const int es = (int)elt_size(dtype);
+    const int cgi = Cin / groups, cgo = Cout / groups;
+    int m_ok = 0;
+    for (int m = 1; m <= groups; ++m) {
+        if (groups % m) continue;
+        if ((m * cgi * es) % 16 || (m * cgo * es) % 16) continue;
+        m_ok = m;
+        if (m * cgi * es >= 128 && m * cgo >= 64) break;
+    }
+    return m_ok ? groups / m_ok : 0;
+}
+template <typename T>
+__global__ void pack_group_filter_kernel(const float* __restrict__ src, T* __restrict__ dst, int cgi, int cgo, int R, int S,
+                                         int cwi, int cwo, int cop, int Kp, long total) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % Kp);
+        const long row = i / Kp;
+        const int ol = (int)(row % cop), chunk = (int)(row / cop);
+        const int cl = k % cwi, tap = k / cwi;
+        float v = 0.f;
+        if (ol < cwo && tap < R * S && ol / cgo == cl / cgi) {      // same group inside the chunk: a diagonal block
+            const int o = chunk * cwo + ol, c = cl % cgi;
+            const int r = tap / S, s = tap - r * S;
+            v = src[(((long)o * cgi + c) * R + r) * S + s];
+        }
+        dst[i] = (T)v;
+    }
+}
+}  // namespace tlxmi
+
+extern "C" int tlxmi_group_conv_chunks(int Cin, int Cout, int groups, int dtype) {
+    if (dtype != TLXMI_F16 && dtype != TLXMI_F32) return 0;
+    return group_chunks(Cin, Cout, groups, dtype);
+}
+
+extern "C" int tlxmi_group_conv2d(const tlxmi_conv2d_desc* d, int groups, const void* x, const void* w_packed,
+                                  const float* scale, const float* shift, const void* res, void* y, void* stream) {
+    TLXMI_REQUIRE(d, TLXMI_ERR_BAD_ARG, "group_conv2d: null descriptor");
+    TLXMI_REQUIRE(d->dtype == TLXMI_F16 || d->dtype == TLXMI_F32, TLXMI_ERR_BAD_ARG, "group_conv2d: bad dtype %d", d->dtype);
+    TLXMI_REQUIRE(groups >= 1 && d->C > 0 && d->Cout > 0 && d->C % groups == 0 && d->Cout % groups == 0, TLXMI_ERR_BAD_ARG,
+                  "group_conv2d: channels %d -> %d are not divisible by groups=%d", d->C, d->Cout, groups);
+    if (groups == 1) return conv2d_impl(d, 1, x, w_packed, scale, shift, res, y, stream);
+    const int nchunk = group_chunks(d->C, d->Cout, groups, d->dtype);
+    if (nchunk == 0)
+        return fail(TLXMI_ERR_UNSUPPORTED, "group_conv2d: %d -> %d channels in %d groups cannot be merged into 16-byte aligned chunks",
+                    d->C, d->Cout, groups);
+    TLXMI_REQUIRE(nchunk <= 65535, TLXMI_ERR_UNSUPPORTED, "group_conv2d: %d launch chunks", nchunk);
+    TLXMI_REQUIRE(!res || (d->res_ld * (int)elt_size(d->dtype)) % 16 == 0, TLXMI_ERR_ALIGNMENT, "group_conv2d: res_ld=%d", d->res_ld);
+    TLXMI_REQUIRE((d->y_ld * (int)elt_size(d->dtype)) % 16 == 0, TLXMI_ERR_ALIGNMENT, "group_conv2d: y_ld=%d", d->y_ld);
+    return conv2d_impl(d, nchunk, x, w_packed, scale, shift, res, y, stream);
 }
 
 // LayerNorm + Linear in one launch (vision_transformer.py:144-159 norm1 -> attn.qkv, norm2 -> mlp.fc1;
@@ -862,4 +951,37 @@ extern "C" int tlxmi_pack_filter(const float* src, void* dst, int Cout, int Cin,
         hipLaunchKernelGGL((pack_filter_kernel<float>), dim3(grid), dim3(256), 0, as_stream(stream), src,
                            (float*)dst, Cout, Cin, R, S, Cinp, Kp, total);
     return check_launch("pack_filter");
+}
+
+extern "C" size_t tlxmi_packed_group_filter_bytes(int Cout, int Cin, int R, int S, int groups, int dtype) {
+    if (dtype != TLXMI_F16 && dtype != TLXMI_F32) return 0;
+    if (groups == 1) return tlxmi_packed_filter_bytes(Cout, Cin, R, S, dtype);
+    const int nchunk = group_chunks(Cin, Cout, groups, dtype);
+    if (nchunk == 0 || R <= 0 || S <= 0) return 0;
+    return (size_t)nchunk * tlxmi_packed_filter_bytes(Cout / nchunk, Cin / nchunk, R, S, dtype);
+}
+
+extern "C" int tlxmi_pack_group_filter(const float* src, void* dst, int Cout, int Cin, int R, int S, int groups, int dtype,
+                                       void* stream) {
+    if (groups == 1) return tlxmi_pack_filter(src, dst, Cout, Cin, R, S, dtype, stream);
+    TLXMI_REQUIRE(src && dst, TLXMI_ERR_BAD_ARG, "pack_group_filter: null buffer");
+    TLXMI_REQUIRE(dtype == TLXMI_F16 || dtype == TLXMI_F32, TLXMI_ERR_BAD_ARG, "pack_group_filter: bad dtype");
+    TLXMI_REQUIRE(Cout > 0 && Cin > 0 && R > 0 && S > 0 && groups > 0, TLXMI_ERR_BAD_ARG, "pack_group_filter: non-positive extent");
+    TLXMI_REQUIRE(aligned16(dst), TLXMI_ERR_ALIGNMENT, "pack_group_filter: dst must be 16-byte aligned");
+    const int nchunk = group_chunks(Cin, Cout, groups, dtype);
+    if (nchunk == 0)
+        return fail(TLXMI_ERR_UNSUPPORTED, "pack_group_filter: %d -> %d channels in %d groups cannot be merged into 16-byte aligned chunks",
+                    Cin, Cout, groups);
+    const int cwi = Cin / nchunk, cwo = Cout / nchunk;
+    const int Kp = kpad_elems(cwi, R, S, dtype);
+    const int cop = (cwo + 127) / 128 * 128;
+    const long total = (long)nchunk * cop * Kp;
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    if (dtype == TLXMI_F16)
+        hipLaunchKernelGGL((pack_group_filter_kernel<half_t>), dim3(grid), dim3(256), 0, as_stream(stream), src, (half_t*)dst,
+                           Cin / groups, Cout / groups, R, S, cwi, cwo, cop, Kp, total);
+    else
+        hipLaunchKernelGGL((pack_group_filter_kernel<float>), dim3(grid), dim3(256), 0, as_stream(stream), src, (float*)dst,
+                           Cin / groups, Cout / groups, R, S, cwi, cwo, cop, Kp, total);
+    return check_launch("pack_group_filter");
 }

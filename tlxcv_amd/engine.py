@@ -172,6 +172,28 @@ class PackedFilter:
                   _stream())
 
 
+class PackedGroupFilter:
+    """Filter of a grouped convolution (1 < groups < C, resnext.py:30-40): `chunks` block-diagonal packed filters,
+    one per launch chunk of tlxmi_group_conv2d."""
+
+    def __init__(self, w_oihw, groups, dtype):
+        w = _f32(w_oihw)
+        self.Cout, cg, self.R, self.S = w.shape
+        self.groups = int(groups)
+        self.Cin = cg * self.groups
+        self.Cin_pad = self.Cin
+        self.dtype = dtype
+        lib = _lib.load()
+        self.chunks = lib.tlxmi_group_conv_chunks(self.Cin, self.Cout, self.groups, dt_code(dtype))
+        if self.chunks <= 0:
+            raise NotImplementedError(f"grouped conv {self.Cin}->{self.Cout} in {self.groups} groups: channel counts "
+                                      "cannot be merged into 16-byte aligned launch chunks")
+        nbytes = lib.tlxmi_packed_group_filter_bytes(self.Cout, self.Cin, self.R, self.S, self.groups, dt_code(dtype))
+        self.buf = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+        _lib.call("tlxmi_pack_group_filter", _p(w), _p(self.buf), self.Cout, self.Cin, self.R, self.S, self.groups,
+                  dt_code(dtype), _stream())
+
+
 def fold_bn(gamma, beta, mean, var, eps, conv_bias=None):
     """Eval-mode BatchNorm (+ optional conv bias) -> per-channel fp32 (scale, shift)."""
     ref = next(t for t in (gamma, beta, mean, var, conv_bias) if t is not None)
@@ -234,6 +256,48 @@ def conv2d(x, pk, stride=1, padding=0, dilation=1, scale=None, shift=None, res=N
     _lib.call("tlxmi_conv2d", C.byref(d), _p(x), _p(pk.buf), _p(scale), _p(shift), _p(res), _p(out), _stream())
     e1.record()
     _probe.append((e0, e1, alg_bytes, flops, (N, H, W, pk.Cin, pk.Cout, pk.R, sh, res is not None)))
+    return out
+
+
+def group_conv2d(x, pk, stride=1, padding=0, dilation=1, scale=None, shift=None, res=None, act=ACT_NONE,
+                 act_param=0.0, res_after_act=False):
+    """Grouped convolution (+ folded BatchNorm / bias, activation, residual): x (N,H,W,Cin) NHWC with exactly the
+    filter's input channels -> (N,Ho,Wo,Cout).  pk: PackedGroupFilter."""
+    need_gpu(x, "input")
+    N, H, W, ld = x.shape
+    if x.dtype != pk.dtype:
+        raise RuntimeError(f"group_conv2d: input dtype {x.dtype} != packed filter dtype {pk.dtype}")
+    if ld != pk.Cin:
+        raise RuntimeError(f"group_conv2d: input has {ld} channels, filter expects {pk.Cin}")
+    sh, sw = _pair(stride)
+    ph, pw = _pair(padding)
+    dh, dw = _pair(dilation)
+    Ho = (H + 2 * ph - dh * (pk.R - 1) - 1) // sh + 1
+    Wo = (W + 2 * pw - dw * (pk.S - 1) - 1) // sw + 1
+    if Ho <= 0 or Wo <= 0:
+        raise RuntimeError(f"group_conv2d: empty output {Ho}x{Wo} for input {H}x{W}")
+    out = torch.empty((N, Ho, Wo, pk.Cout), dtype=x.dtype, device=x.device)
+    if res is not None and res.dtype != x.dtype:
+        raise RuntimeError("group_conv2d: residual dtype mismatch")
+    d = _lib.ConvDesc(dtype=dt_code(x.dtype), N=N, H=H, W=W, C=pk.Cin, Cout=pk.Cout, R=pk.R, S=pk.S,
+                      stride_h=sh, stride_w=sw, pad_h=ph, pad_w=pw, dil_h=dh, dil_w=dw, Ho=Ho, Wo=Wo,
+                      x_ld=ld, y_ld=pk.Cout, res_ld=(res.shape[-1] if res is not None else 0),
+                      y_nstride=0, res_nstride=0, act=act, act_param=float(act_param),
+                      flags=(EPI_RES_AFTER_ACT if res_after_act else 0))
+    args = (C.byref(d), pk.groups, _p(x), _p(pk.buf), _p(scale), _p(shift), _p(res), _p(out), _stream())
+    if _probe is None:
+        _lib.call("tlxmi_group_conv2d", *args)
+        return out
+    es = x.element_size()
+    M = N * Ho * Wo
+    cg = pk.Cin // pk.groups
+    alg_bytes = (N * H * W * pk.Cin + M * pk.Cout * (2 if res is not None else 1) + pk.Cout * cg * pk.R * pk.S) * es
+    flops = 2 * M * pk.Cout * cg * pk.R * pk.S
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    _lib.call("tlxmi_group_conv2d", *args)
+    e1.record()
+    _probe.append((e0, e1, alg_bytes, flops, (N, H, W, pk.Cin, pk.Cout, pk.R, sh, f"g{pk.groups}")))
     return out
 
 

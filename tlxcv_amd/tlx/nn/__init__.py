@@ -55,7 +55,9 @@ class Module(torch.nn.Module):
                 if isinstance(v, (list, tuple)) and v and all(isinstance(e, torch.nn.Module) for e in v):
                     for i, e in enumerate(v):
                         key = f"{k}_{i}"
-                        if key not in m._modules:
+                        # (a list whose members are also attributes — resnext.py:176-189 `bb_i_j` + `block_list` —
+                        # keeps the attribute names only)
+                        if key not in m._modules and not any(e is r for r in m._modules.values()):
                             m.add_module(key, e)
 
     def modules_shallow(self):
@@ -302,6 +304,17 @@ class LeakyReLU(_Act):  # darknet.py:50
         self.PARAM = float(negative_slope)
 
 
+def str_to_act(act):
+    """TensorLayerX layers take `act` as a callable or a name (resnext.py:46-52 BatchNorm(act='relu'))."""
+    if act is None or not isinstance(act, str):
+        return act
+    table = {"relu": ReLU, "relu6": ReLU6, "sigmoid": Sigmoid, "gelu": GELU, "hardswish": Hardswish,
+             "hard_sigmoid": HardSigmoid, "leaky_relu": LeakyReLU}
+    if act.lower() not in table:
+        raise NotImplementedError(f"activation {act!r}")
+    return table[act.lower()]()
+
+
 class Softmax(Module):
     def __init__(self, axis=-1, name=None):
         super().__init__(name=name)
@@ -378,8 +391,8 @@ class GroupConv2d(Module):
             pk = self._cached("pk", lambda: E.PackedFilter(self.filters, dt))
         elif self.n_group == self.in_channels == self.out_channels:
             pk = self._cached("dw", lambda: self.filters.detach()[:, 0].permute(1, 2, 0).contiguous().to(dt))
-        else:
-            raise NotImplementedError(f"GroupConv2d: n_group={self.n_group} (only 1 or depthwise) — SURVEY §8f")
+        else:   # 1 < n_group < C: ResNeXt cardinality, resnext.py:83-91
+            pk = self._cached("gpk", lambda: E.PackedGroupFilter(self.filters, self.n_group, dt))
         if bn is not None:
             scale, shift = self._cached(("bn", id(bn)), lambda: bn.folded(self.biases))
         else:
@@ -387,6 +400,9 @@ class GroupConv2d(Module):
         if self.n_group == 1:
             return E.conv2d(x, pk, self.stride, self.padding, self.dilation, scale, shift, res, act, act_param,
                             res_after_act, **kw)
+        if isinstance(pk, E.PackedGroupFilter):
+            return E.group_conv2d(x, pk, self.stride, self.padding, self.dilation, scale, shift, res, act, act_param,
+                                  res_after_act)
         if res is not None:
             raise NotImplementedError("depthwise conv with fused residual")
         return E.dwconv2d(x, pk, self.stride, self.padding, self.dilation, scale, shift, act, act_param)
@@ -448,7 +464,7 @@ class BatchNorm2d(Module):
         if num_features is None:
             raise ValueError("BatchNorm2d: num_features must be given")
         self.num_features, self.epsilon, self.momentum = int(num_features), float(epsilon), momentum
-        self.data_format, self.act = data_format, act
+        self.data_format, self.act = data_format, str_to_act(act)
         n = (self.num_features,)
         self.gamma = Parameter(data=str_to_init(gamma_init)(shape=n))
         self.beta = Parameter(data=str_to_init(beta_init)(shape=n))

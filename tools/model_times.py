@@ -11,7 +11,8 @@ from tlxcv_amd import seeded, models  # noqa: E402
 
 dev = torch.device("cuda:0")
 CASES = [("resnet18", 256, 224, False), ("resnet34", 256, 224, False), ("resnet50", 256, 224, False), ("resnet101", 128, 224, False),
-         ("vgg16", 64, 224, False), ("alexnet", 256, 224, False),
+         ("vgg16", 64, 224, False), ("alexnet", 256, 224, False), ("resnext50_32x4d", 256, 224, False),
+         ("resnext101_64x4d", 64, 224, False),
          ("MobileNetV1", 256, 224, False), ("mobilenet_v2", 256, 224, False), ("mobilenet_v3_small", 256, 224, False),
          ("mobilenet_v3_large", 256, 224, False), ("DarkNet", 64, 256, True), ("YOLOv3", 32, 416, True),
          ("vit_small_patch16_224", 256, 224, False), ("vit_base_patch16_224", 256, 224, False),
@@ -35,5 +36,19 @@ for ctor, bs, hw, dict_in in CASES:
     torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0) / n
     print(f"{ctor:44s} bs{bs:4d} {hw}px  {ms:8.2f} ms  {bs / ms * 1e3:9.0f} img/s", flush=True)
+    if os.environ.get("LAYERS"):      # per conv / linear launch: shape, us, GB/s, TFLOP/s (the bench's probe)
+        from tlxcv_amd import engine as E
+        probe = []
+        E.set_probe(probe)
+        m(inp)
+        torch.cuda.synchronize()
+        E.set_probe(None)
+        agg = {}
+        for e0, e1, b, f, shape in probe:
+            a = agg.setdefault(shape, [0, 0.0, b, f])
+            a[0] += 1
+            a[1] += e0.elapsed_time(e1) * 1e3
+        for shape, (cnt, us, b, f) in agg.items():
+            print(f"    {str(shape):52s} x{cnt:3d} {us / cnt:8.1f} us {b / (us / cnt) / 1e3:7.0f} GB/s {f / (us / cnt) / 1e6:7.1f} TF/s")
     del m
     torch.cuda.empty_cache()
