@@ -551,7 +551,7 @@ template <typename T, int BM, int BN, int WGM, int STAGES> static int launch(con
     return TLXMI_OK;
 }
 
-template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, bool allow_stream = true) {
+template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, bool allow_stream = true, bool allow_split = true) {
     // Tile choice = max over the four shapes of (grid quantisation efficiency) x (shape efficiency):
     // a launch of B blocks on S = CUs x resident-blocks-per-CU slots runs ceil(B/S) rounds, so B/(rounds*S)
     // of the machine does useful work; bigger tiles re-use operands better (fewer LDS bytes per MFMA).
@@ -627,7 +627,7 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
     // TLXMI_TAIL (A/B): 0 no split, 1 small tiles only (4 * left <= CUs), default: 128 x 256 tiles (2 * left <= CUs)
     int tail_mode = 2;
     { const char* e = getenv("TLXMI_TAIL"); if (e && *e) tail_mode = atoi(e); }
-    const bool tail_split = gemm256_ok && tail_mode != 0 && full_rounds >= 1 && (t256 % cus) != 0 &&
+    const bool tail_split = gemm256_ok && allow_split && tail_mode != 0 && full_rounds >= 1 && (t256 % cus) != 0 &&
                             (tail_mode == 1 ? 4 : 2) * (t256 % cus) <= cus;
     int best = 0;
     float best_score = -1.f;
