@@ -255,3 +255,33 @@ def test_group_conv_rejects_unmergeable_channel_counts(dev):
     w = torch.randn(15, 3, 3, 3)
     with pytest.raises(NotImplementedError):
         E.PackedGroupFilter(w.to(dev), 5, torch.float16)
+
+
+# ---- 3x3 convolutions on the antiphase GEMM kernel (gemm_pp.hip CONV mode: candidate 7 = 256 x 256 tiles,
+# candidate 9 = 128 x 256), forced through TLXMI_TILE and checked against the oracle: every tap-mask edge (image
+# borders, image-to-image boundaries inside a tile, stride 2, odd extents), 1 / 2 / 4 / 8 K tiles per tap, channel
+# tails, row tails, residual + activation epilogues.
+PPCONV_CASES = [
+    # (N, Cin, Cout, k, stride, pad, H, W, res, act)
+    (2, 256, 256, 3, 1, 1, 14, 14, False, 1),      # resnet.py:111-121 conv2 of layer3
+    (3, 512, 512, 3, 1, 1, 7, 7, False, 1),        # layer4: several images inside one 256-row tile
+    (1, 256, 256, 3, 2, 1, 28, 28, False, 1),      # stride-2 entry of layer3
+    (1, 512, 512, 3, 2, 1, 15, 13, True, 1),       # odd extents, stride 2, residual
+    (2, 64, 256, 3, 1, 1, 12, 20, False, 3),       # one K tile per tap (fp16), leaky
+    (1, 128, 264, 3, 1, 0, 19, 19, True, 0),       # no padding, channel tail (264 = 256 + 8)
+    (1, 128, 512, (1, 3), 1, (0, 1), 9, 33, False, 2),   # 1 x 3 filter
+    (5, 128, 256, 3, 1, 1, 10, 10, False, 1),      # 500 rows: 2 tiles of 256, the second ragged
+]
+
+
+@pytest.mark.parametrize("tile", ["7", "9"], ids=["pp256", "pp128"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["fp32", "fp16"])
+@pytest.mark.parametrize("cfg", PPCONV_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv3x3_on_the_antiphase_gemm(dev, dtype, cfg, tile):
+    import os
+    N, Cin, Cout, k, stride, pad, H, W, res, act = cfg
+    os.environ["TLXMI_TILE"] = tile
+    try:
+        run_case(dev, dtype, N, Cin, Cout, k, stride, pad, H, W, act=act, act_param=0.1, with_res=res, seed=23)
+    finally:
+        os.environ.pop("TLXMI_TILE", None)

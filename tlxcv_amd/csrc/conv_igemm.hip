@@ -597,13 +597,21 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
     // candidate 6 = gemm256.hip's 256x128 variant: 4 waves, 3-deep ring, two workgroups per CU
     // candidate 7 = gemm_pp.hip: 256x256, 8 waves in two antiphase groups, 128-byte K tiles
     // candidate 8 = gemm_stream.hip: candidate 7 as a persistent kernel (one K-tile stream per CU)
-    constexpr int NC = 9;
+    // candidate 9 = gemm_pp.hip on 128 x 256 tiles (3x3 convs whose 256 x 256 tiles would fill under half the CUs)
+    constexpr int NC = 10;
     Cand cands[NC] = {{128, 128, 1.00f}, {64, 128, 0.85f}, {128, 64, 0.85f}, {64, 64, 0.70f}, {256, 128, 0.90f},
-                      {256, 256, 1.12f}, {256, 128, 1.20f}, {256, 256, 1.40f}, {256, 256, 1.50f}};
+                      {256, 256, 1.12f}, {256, 128, 1.20f}, {256, 256, 1.40f}, {256, 256, 1.50f}, {128, 256, 1.25f}};
     const bool gemm256_ok = a.nchunk == 1 && a.R == 1 && a.S == 1 && a.ph == 0 && a.pw == 0 && a.sh == 1 && a.sw == 1 && !a.strided_n &&
                             a.vec_io && a.Cout % 8 == 0 && a.y_bytes != 0 && a.Cout >= 256 && a.ktiles >= 2 &&
                             (!a.res || (long long)a.M * a.res_ld * (long long)sizeof(T) < (1ll << 31));
-    if (!gemm256_ok) cands[5].eff = cands[6].eff = cands[7].eff = cands[8].eff = 0.f;
+    // 3x3 (R x 3) convs on the antiphase GEMM kernel: a 128-byte K tile must lie inside one filter tap
+    const int tpk = a.cpt / 8;     // K tiles per tap
+    const bool pp_conv_ok = a.nchunk == 1 && !(a.R == 1 && a.S == 1) && a.S == 3 && a.R <= 3 && a.dh == 1 && a.dw == 1 && !a.strided_n &&
+                            a.vec_io && a.Cout % 8 == 0 && a.Cout >= 256 && a.y_bytes != 0 && a.cpt % 8 == 0 && (tpk & (tpk - 1)) == 0 &&
+                            (!a.res || (long long)a.M * a.res_ld * (long long)sizeof(T) < (1ll << 31));
+    if (!gemm256_ok) cands[5].eff = cands[6].eff = cands[8].eff = 0.f;
+    if (!gemm256_ok && !pp_conv_ok) cands[7].eff = 0.f;
+    if (!pp_conv_ok) cands[9].eff = 0.f;
     cands[5].eff = 0.f;   // superseded by candidate 7 (same tile, antiphase wave groups); kept for A/B runs (TLXMI_TILE=5)
     if (obi >= 0.0015 || a.ktiles < 4) cands[4].eff = 0.f;
     // regimes by output bytes per FLOP (tools/ab_tiles.py sweep over the ResNet-50 / ViT-B / Swin-B layer shapes):
@@ -635,7 +643,7 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
         const int bm = cands[i].bm, bn = cands[i].bn;
         if (cands[i].eff <= 0.f) continue;
         if (bn == 128 && a.Cout <= 64) continue;
-        size_t lds = (i == 5 || i >= 7) ? (size_t)128 * 1024 : i == 6 ? (size_t)72 * 1024 : (size_t)(a.ktiles > 1 ? (i == 4 ? 3 : 2) : 1) * (bm + bn) * 128;
+        size_t lds = (i == 5 || i >= 7) ? (size_t)(i == 9 ? 144 : 128) * 1024 : i == 6 ? (size_t)72 * 1024 : (size_t)(a.ktiles > 1 ? (i == 4 ? 3 : 2) : 1) * (bm + bn) * 128;
         if (i < 5 && lds < (size_t)bm * bn * 4) lds = (size_t)bm * bn * 4;   // fp32 epilogue tile (gemm256 stores from registers)
         lds += 2 * bn * sizeof(float);                                        // scale / shift table
         int per_cu = (int)((160 * 1024) / lds);
@@ -656,7 +664,8 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
     // compare candidates: tools/ab_tiles.py, tests/test_gemm_gpu.py)
     int forced = -1;
     { const char* e = getenv("TLXMI_TILE"); if (e && *e) forced = atoi(e); }
-    if (forced >= 0 && forced < NC && !(cands[forced].bn == 128 && a.Cout <= 64) && (forced < 5 || gemm256_ok)) best = forced;
+    if (forced >= 0 && forced < NC && !(cands[forced].bn == 128 && a.Cout <= 64) &&
+        (forced < 5 || (forced != 9 && gemm256_ok) || ((forced == 7 || forced == 9) && pp_conv_ok))) best = forced;
     if (best >= 7 && tail_split) {
         // rows of the full rounds (whole M tiles) -> this candidate; the rest -> best small-tile candidate
         const int nt = (a.Cout + 255) / 256;
@@ -682,6 +691,7 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
             // still one round (2 * left <= CUs)
             Gemm256Args g;
             g.debug = 0;
+            g.conv = 0;
             g.rowstats = nullptr;
             g.x = hi.x; g.w = hi.w; g.y = hi.y; g.scale = hi.scale; g.shift = hi.shift; g.res = hi.res;
             g.M = hi.M; g.Cout = hi.Cout; g.x_ld = hi.x_ld; g.y_ld = hi.y_ld; g.res_ld = hi.res_ld;
@@ -695,6 +705,14 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
     if (best >= 5) {
         Gemm256Args g;
         g.debug = 0;
+        g.conv = 0;
+        if (!gemm256_ok) {      // candidates 7 / 9 as a convolution
+            g.conv = 1;
+            g.cH = a.H; g.cW = a.W; g.cWo = a.Wo; g.cHoWo = a.HoWo; g.csh = a.sh; g.csw = a.sw; g.cph = a.ph; g.cpw = a.pw;
+            g.ctaps = a.R * a.S;
+            g.ctshift = 0;
+            while ((1 << g.ctshift) < tpk) ++g.ctshift;
+        }
         g.rowstats = nullptr;
         g.x = a.x; g.w = a.w; g.y = a.y; g.scale = a.scale; g.shift = a.shift; g.res = a.res;
         g.M = a.M; g.Cout = a.Cout; g.x_ld = a.x_ld; g.y_ld = a.y_ld; g.res_ld = a.res_ld;
@@ -708,9 +726,10 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
                 return launch_gemm_stream(sizeof(T) == 2 ? TLXMI_F16 : TLXMI_F32, g, st, cus);
             best = 7;
         }
-        if (best == 7) {
+        if (best == 7 || best == 9) {
             g.ksteps = a.Kp_bytes / 128;
-            return launch_gemm_pp(sizeof(T) == 2 ? TLXMI_F16 : TLXMI_F32, g, st);
+            return best == 7 ? launch_gemm_pp(sizeof(T) == 2 ? TLXMI_F16 : TLXMI_F32, g, st)
+                             : launch_gemm_pp128(sizeof(T) == 2 ? TLXMI_F16 : TLXMI_F32, g, st);
         }
         return launch_gemm256(sizeof(T) == 2 ? TLXMI_F16 : TLXMI_F32, best - 5, g, st);
     }
@@ -887,6 +906,7 @@ extern "C" int tlxmi_linear_ln(int dtype, int64_t rows, int K, int Cout, int x_l
         return fail(TLXMI_ERR_UNSUPPORTED, "linear_ln: shape %lld x %d -> %d is outside the 256 x 256 GEMM kernel", (long long)rows, K, Cout);
     Gemm256Args g;
     g.debug = 0;
+    g.conv = 0;
     g.x = (const char*)x; g.w = (const char*)w_packed; g.y = (char*)y; g.scale = c1; g.shift = c2; g.res = nullptr;
     g.rowstats = rowstats;
     g.M = (int)rows; g.Cout = Cout; g.x_ld = x_ld; g.y_ld = y_ld; g.res_ld = 0;

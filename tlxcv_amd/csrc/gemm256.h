@@ -23,6 +23,11 @@ struct Gemm256Args {
     int gn;        // N-tiles per column panel of the tile walk
     unsigned x_bytes, w_bytes, y_bytes, res_bytes;
     int debug;     // tuning builds only
+    // gemm_pp.hip only — 3-wide-filter convolution as implicit GEMM (conv != 0): X rows are gathered per filter tap.
+    // One K tile (128 bytes) never straddles taps: C * sizeof(T) is 128 << ctshift bytes.
+    int conv;
+    int cH, cW, cWo, cHoWo, csh, csw, cph, cpw;   // input extent, output extent, stride, padding (dilation 1)
+    int ctshift, ctaps;                           // log2(K tiles per tap), R * 3 taps
 };
 
 int launch_gemm256(int dtype, int variant, const Gemm256Args& a, hipStream_t st);

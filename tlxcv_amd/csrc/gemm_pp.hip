@@ -61,7 +61,12 @@ template <> struct MmaPP<float> {
 // With one X half a K tile is two phases ((0,0) and (0,1)) and 48 KiB, so THREE K tiles are resident and the
 // DMA runs two K tiles ahead:  p0(k): X0, W0 of k+2 (vmcnt(10) retires W1(k));  p1(k): W1 of k+2 (vmcnt(8)
 // retires X0, W0 of k+1) — again every half tile is refilled two phases after its last read.
-template <typename T, int HM>
+// CONV: the X operand is the im2col view of an NHWC map under an R x 3 filter, stride / zero padding as given
+// (3x3 convs with >= 256 output channels: resnet.py:111-121 conv2 of the 14x14 / 7x7 stages, vgg.py:74-80,
+// darknet.py:54-58).  A K tile of 128 bytes lies inside one filter tap (C * sizeof(T) = 128 << ctshift), so the tap
+// of a K tile is wave-uniform: its byte offset is scalar arithmetic, and each of a lane's four rows carries a bit
+// mask of the taps that fall inside the image (bit clear -> out-of-range descriptor offset -> zero fill).
+template <typename T, int HM, bool CONV>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
     constexpr int ES = (int)sizeof(T);
     constexpr int BM = 128 * HM, BN = 256;
@@ -93,12 +98,30 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
     const int lrow = lane >> 3;
     const int lc = (lane & 7) ^ ((4 * (wid & 1) + (lane >> 4)) & 7);   // logical K chunk behind this lane's slot
     int xo[2][2], wo[2][2];
+    unsigned tapmask[2][2];   // CONV: taps of this row that lie inside the image
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int m = bm0 + 128 * h + 8 * (wid + 8 * j) + lrow;
-            xo[h][j] = (h < HM && m < a.M) ? m * a.x_ld * ES : OOB;
+            if constexpr (CONV) {
+                const bool live = h < HM && m < a.M;
+                const int mm = live ? m : 0;
+                const int n = mm / a.cHoWo, rem = mm - n * a.cHoWo;
+                const int ho = rem / a.cWo, wo_ = rem - ho * a.cWo;
+                const int hi0 = ho * a.csh - a.cph, wi0 = wo_ * a.csw - a.cpw;
+                xo[h][j] = ((n * a.cH + hi0) * a.cW + wi0) * a.x_ld * ES;     // tap (0,0); may wrap below zero under padding
+                unsigned mk = 0;
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp) {
+                    const int r = tp / 3, s_ = tp - 3 * r;
+                    if (live && tp < a.ctaps && (unsigned)(hi0 + r) < (unsigned)a.cH && (unsigned)(wi0 + s_) < (unsigned)a.cW) mk |= 1u << tp;
+                }
+                tapmask[h][j] = mk;
+            } else {
+                xo[h][j] = (h < HM && m < a.M) ? m * a.x_ld * ES : OOB;
+                tapmask[h][j] = 0;
+            }
             const int rho = 128 * h + 8 * (wid + 8 * j) + lrow;    // LDS row; holds channel perm(rho) (conv_igemm.hip)
             const int n = (rho & ~31) | (((rho >> 2) & 3) << 3) | (((rho >> 4) & 1) << 2) | (rho & 3);
             wo[h][j] = (bn0 + n) * a.Kp_bytes;
@@ -106,11 +129,19 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
     char* const lbase = smem + wid * 1024;
     // `buf` = resident K-tile slot the tile goes to (kt & 1 for HM == 2, kt % 3 for HM == 1)
     auto stage_x = [&](int h, int kt, int buf) {
-        const int q = kt * 8 + lc;
         char* b = lbase + buf * KTB + (h ? RX1 : RX0);
-        const bool in = q < a.kchunks;
+        if constexpr (CONV) {
+            const int tap = kt >> a.ctshift;                       // wave-uniform; >= ctaps past the end (mask bit clear)
+            const int r = (tap * 11) >> 5, s_ = tap - 3 * r;       // tap / 3 for tap <= 8
+            const int d = (r * a.cW + s_) * a.x_ld * ES + (((kt - (tap << a.ctshift)) * 8 + lc) << 4);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) pp_dma16(xsrd, b + j * 8192, in ? xo[h][j] + q * 16 : OOB);
+            for (int j = 0; j < 2; ++j) pp_dma16(xsrd, b + j * 8192, ((tapmask[h][j] >> tap) & 1u) ? xo[h][j] + d : OOB);
+        } else {
+            const int q = kt * 8 + lc;
+            const bool in = q < a.kchunks;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) pp_dma16(xsrd, b + j * 8192, in ? xo[h][j] + q * 16 : OOB);
+        }
     };
     auto stage_w = [&](int g, int kt, int buf) {
         const int q = kt * 8 + lc;
@@ -174,7 +205,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
 #pragma unroll
         for (int pi = 0; pi < 4; ++pi) {
             const int m = bm0 + 128 * h + 64 * wr + 16 * pi + (lane & 15);
-            rowab[h][pi] = (a.rowstats && m < a.M) ? *reinterpret_cast<const float2*>(a.rowstats + 2 * (size_t)m) : make_float2(1.f, 0.f);
+            if constexpr (CONV) rowab[h][pi] = make_float2(1.f, 0.f);
+            else rowab[h][pi] = (a.rowstats && m < a.M) ? *reinterpret_cast<const float2*>(a.rowstats + 2 * (size_t)m) : make_float2(1.f, 0.f);
         }
     __builtin_amdgcn_sched_barrier(0);   // these loads are older than every DMA: their wait leaves the DMAs in flight
     if constexpr (HM == 2) {
@@ -304,7 +336,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
                 for (int pi = 0; pi < 4; ++pi) {
                     const int m = bm0 + 128 * h + 64 * wr + pi * 16 + px;
                     float v[8], rv[8];
-                    if (a.rowstats) {   // LayerNorm folded in: row scale, row offset times the filter-row sums, shift
+                    if (!CONV && a.rowstats) {   // LayerNorm folded in: row scale, row offset times the filter-row sums, shift
                         const float2 ab = rowab[h][pi];
 #pragma unroll
                         for (int bb = 0; bb < 4; ++bb) {
@@ -369,14 +401,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
 }
 
 // Preconditions as launch_gemm256 (checked by conv_igemm.hip's dispatcher); a.ksteps = packed pitch / 128.
-template <typename T, int HM> static int launch_pp_t(const Gemm256Args& a0, hipStream_t st, bool& raised) {
+template <typename T, int HM, bool CONV> static int launch_pp_t(const Gemm256Args& a0, hipStream_t st, bool& raised) {
     Gemm256Args a = a0;
     { static const int dbg = [] { const char* e = getenv("TLXMI_DEBUG"); return e ? atoi(e) : 0; }(); a.debug = dbg; }
     a.mtiles = (a.M + 128 * HM - 1) / (128 * HM);
     a.ntiles = (a.Cout + 255) / 256;
     a.gn = a.ntiles;
     const size_t lds = (size_t)(HM == 2 ? 8 : 9) * 128 * 128 + 2 * 256 * sizeof(float);
-    const void* fn = reinterpret_cast<const void*>(&gemm_pp_kernel<T, HM>);
+    const void* fn = reinterpret_cast<const void*>(&gemm_pp_kernel<T, HM, CONV>);
     if (!raised) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail(TLXMI_ERR_LAUNCH, "gemm_pp: cannot raise LDS limit: %s", hipGetErrorString(e));
@@ -389,16 +421,24 @@ template <typename T, int HM> static int launch_pp_t(const Gemm256Args& a0, hipS
 }
 
 int launch_gemm_pp(int dtype, const Gemm256Args& a, hipStream_t st) {
-    static bool raised[2] = {false, false};
-    if (dtype == TLXMI_F16) return launch_pp_t<half_t, 2>(a, st, raised[0]);
-    return launch_pp_t<float, 2>(a, st, raised[1]);
+    static bool raised[4] = {false, false, false, false};
+    if (a.conv) {
+        if (dtype == TLXMI_F16) return launch_pp_t<half_t, 2, true>(a, st, raised[2]);
+        return launch_pp_t<float, 2, true>(a, st, raised[3]);
+    }
+    if (dtype == TLXMI_F16) return launch_pp_t<half_t, 2, false>(a, st, raised[0]);
+    return launch_pp_t<float, 2, false>(a, st, raised[1]);
 }
 
 // 128 x 256 tiles (same preconditions)
 int launch_gemm_pp128(int dtype, const Gemm256Args& a, hipStream_t st) {
-    static bool raised[2] = {false, false};
-    if (dtype == TLXMI_F16) return launch_pp_t<half_t, 1>(a, st, raised[0]);
-    return launch_pp_t<float, 1>(a, st, raised[1]);
+    static bool raised[4] = {false, false, false, false};
+    if (a.conv) {
+        if (dtype == TLXMI_F16) return launch_pp_t<half_t, 1, true>(a, st, raised[2]);
+        return launch_pp_t<float, 1, true>(a, st, raised[3]);
+    }
+    if (dtype == TLXMI_F16) return launch_pp_t<half_t, 1, false>(a, st, raised[0]);
+    return launch_pp_t<float, 1, false>(a, st, raised[1]);
 }
 
 }  // namespace tlxmi
