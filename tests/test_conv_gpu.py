@@ -274,7 +274,7 @@ PPCONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("tile", ["7", "9"], ids=["pp256", "pp128"])
+@pytest.mark.parametrize("tile", ["7", "9", "10"], ids=["pp256", "pp128x256", "pp256x128"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["fp32", "fp16"])
 @pytest.mark.parametrize("cfg", PPCONV_CASES, ids=lambda c: "x".join(map(str, c)))
 def test_conv3x3_on_the_antiphase_gemm(dev, dtype, cfg, tile):
@@ -285,3 +285,35 @@ def test_conv3x3_on_the_antiphase_gemm(dev, dtype, cfg, tile):
         run_case(dev, dtype, N, Cin, Cout, k, stride, pad, H, W, act=act, act_param=0.1, with_res=res, seed=23)
     finally:
         os.environ.pop("TLXMI_TILE", None)
+
+
+# 128 output channels: only the 256 x 128 tile (candidate 10) takes these (resnet.py:111-121, 28 x 28 stage)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["fp32", "fp16"])
+@pytest.mark.parametrize("cfg", [(2, 128, 128, 3, 1, 1, 28, 28, False, 1), (1, 128, 128, 3, 2, 1, 56, 56, False, 1),
+                                 (3, 64, 136, 3, 1, 1, 11, 17, True, 3), (1, 256, 128, 3, 1, 1, 16, 16, True, 0)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_conv3x3_with_128_output_channels_on_the_antiphase_gemm(dev, dtype, cfg):
+    import os
+    N, Cin, Cout, k, stride, pad, H, W, res, act = cfg
+    os.environ["TLXMI_TILE"] = "10"
+    try:
+        run_case(dev, dtype, N, Cin, Cout, k, stride, pad, H, W, act=act, act_param=0.1, with_res=res, seed=29)
+    finally:
+        os.environ.pop("TLXMI_TILE", None)
+
+
+def test_linear_on_the_256x128_antiphase_tile(dev):
+    """The 1x1 / Linear path of the same tile shape (reachable through TLXMI_TILE=10 only)."""
+    import os
+    os.environ["TLXMI_TILE"] = "10"
+    try:
+        run_case(dev, torch.float16, 2, 512, 128, 1, 1, 0, 28, 28, act=1, with_res=False, seed=31)
+        run_case(dev, torch.float32, 1, 256, 392, 1, 1, 0, 19, 19, act=0, with_res=True, seed=32)
+    finally:
+        os.environ.pop("TLXMI_TILE", None)
+
+
+def test_conv3x3_image_axis_tail_split(dev):
+    """270 tiles of 256 x 128 on 256 CUs: the dispatcher keeps 83 images on the antiphase kernel and runs the last 5 as
+    a convolution of their own on small tiles; the seam (an image boundary) must be invisible.  Residual + ReLU."""
+    run_case(dev, torch.float16, 88, 128, 128, 3, 1, 1, 28, 28, act=1, with_res=True, seed=37)

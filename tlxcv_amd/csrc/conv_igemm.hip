@@ -598,20 +598,25 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
     // candidate 7 = gemm_pp.hip: 256x256, 8 waves in two antiphase groups, 128-byte K tiles
     // candidate 8 = gemm_stream.hip: candidate 7 as a persistent kernel (one K-tile stream per CU)
     // candidate 9 = gemm_pp.hip on 128 x 256 tiles (3x3 convs whose 256 x 256 tiles would fill under half the CUs)
-    constexpr int NC = 10;
+    // candidate 10 = gemm_pp.hip on 256 x 128 tiles (3x3 convs with 128 output channels)
+    constexpr int NC = 11;
     Cand cands[NC] = {{128, 128, 1.00f}, {64, 128, 0.85f}, {128, 64, 0.85f}, {64, 64, 0.70f}, {256, 128, 0.90f},
-                      {256, 256, 1.12f}, {256, 128, 1.20f}, {256, 256, 1.40f}, {256, 256, 1.50f}, {128, 256, 1.25f}};
-    const bool gemm256_ok = a.nchunk == 1 && a.R == 1 && a.S == 1 && a.ph == 0 && a.pw == 0 && a.sh == 1 && a.sw == 1 && !a.strided_n &&
-                            a.vec_io && a.Cout % 8 == 0 && a.y_bytes != 0 && a.Cout >= 256 && a.ktiles >= 2 &&
+                      {256, 256, 1.12f}, {256, 128, 1.20f}, {256, 256, 1.40f}, {256, 256, 1.50f}, {128, 256, 1.25f},
+                      {256, 128, 1.25f}};
+    const bool gemm128_ok = a.nchunk == 1 && a.R == 1 && a.S == 1 && a.ph == 0 && a.pw == 0 && a.sh == 1 && a.sw == 1 && !a.strided_n &&
+                            a.vec_io && a.Cout % 8 == 0 && a.y_bytes != 0 && a.Cout >= 128 && a.ktiles >= 2 &&
                             (!a.res || (long long)a.M * a.res_ld * (long long)sizeof(T) < (1ll << 31));
+    const bool gemm256_ok = gemm128_ok && a.Cout >= 256;
     // 3x3 (R x 3) convs on the antiphase GEMM kernel: a 128-byte K tile must lie inside one filter tap
     const int tpk = a.cpt / 8;     // K tiles per tap
-    const bool pp_conv_ok = a.nchunk == 1 && !(a.R == 1 && a.S == 1) && a.S == 3 && a.R <= 3 && a.dh == 1 && a.dw == 1 && !a.strided_n &&
-                            a.vec_io && a.Cout % 8 == 0 && a.Cout >= 256 && a.y_bytes != 0 && a.cpt % 8 == 0 && (tpk & (tpk - 1)) == 0 &&
-                            (!a.res || (long long)a.M * a.res_ld * (long long)sizeof(T) < (1ll << 31));
+    const bool pp_conv128_ok = a.nchunk == 1 && !(a.R == 1 && a.S == 1) && a.S == 3 && a.R <= 3 && a.dh == 1 && a.dw == 1 && !a.strided_n &&
+                               a.vec_io && a.Cout % 8 == 0 && a.Cout >= 128 && a.y_bytes != 0 && a.cpt % 8 == 0 && (tpk & (tpk - 1)) == 0 &&
+                               (!a.res || (long long)a.M * a.res_ld * (long long)sizeof(T) < (1ll << 31));
+    const bool pp_conv_ok = pp_conv128_ok && a.Cout >= 256;
     if (!gemm256_ok) cands[5].eff = cands[6].eff = cands[8].eff = 0.f;
     if (!gemm256_ok && !pp_conv_ok) cands[7].eff = 0.f;
     if (!pp_conv_ok) cands[9].eff = 0.f;
+    if (!pp_conv128_ok) cands[10].eff = 0.f;      // (1x1 layers: reachable through TLXMI_TILE=10 only)
     cands[5].eff = 0.f;   // superseded by candidate 7 (same tile, antiphase wave groups); kept for A/B runs (TLXMI_TILE=5)
     if (obi >= 0.0015 || a.ktiles < 4) cands[4].eff = 0.f;
     // regimes by output bytes per FLOP (tools/ab_tiles.py sweep over the ResNet-50 / ViT-B / Swin-B layer shapes):
@@ -643,7 +648,7 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
         const int bm = cands[i].bm, bn = cands[i].bn;
         if (cands[i].eff <= 0.f) continue;
         if (bn == 128 && a.Cout <= 64) continue;
-        size_t lds = (i == 5 || i >= 7) ? (size_t)(i == 9 ? 144 : 128) * 1024 : i == 6 ? (size_t)72 * 1024 : (size_t)(a.ktiles > 1 ? (i == 4 ? 3 : 2) : 1) * (bm + bn) * 128;
+        size_t lds = (i == 5 || i >= 7) ? (size_t)(i >= 9 ? 144 : 128) * 1024 : i == 6 ? (size_t)72 * 1024 : (size_t)(a.ktiles > 1 ? (i == 4 ? 3 : 2) : 1) * (bm + bn) * 128;
         if (i < 5 && lds < (size_t)bm * bn * 4) lds = (size_t)bm * bn * 4;   // fp32 epilogue tile (gemm256 stores from registers)
         lds += 2 * bn * sizeof(float);                                        // scale / shift table
         int per_cu = (int)((160 * 1024) / lds);
@@ -655,6 +660,10 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
         const long rounds = (blocks + slots - 1) / slots;
         float quant = (float)blocks / (float)(rounds * slots);
         if (i >= 7 && tail_split) quant = (float)blocks / (((float)full_rounds + 0.6f) * slots);   // the tail round: ~0.6 of a tile time
+        // 3x3 convs on the antiphase kernel: a short last round is cut off along the image axis (below)
+        if ((i == 7 || i >= 9) && !(a.R == 1 && a.S == 1) && allow_split && tail_mode != 0 && blocks / slots >= 1 &&
+            blocks % slots != 0 && 4 * (blocks % slots) <= slots)
+            quant = (float)blocks / (((float)(blocks / slots) + 0.4f) * slots);
         // wasted work inside partial tiles
         const float fill = ((float)a.M * a.Cout * a.nchunk) / ((float)blocks * bm * bn);
         const float score = quant * fill * cands[i].eff;
@@ -665,7 +674,34 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
     int forced = -1;
     { const char* e = getenv("TLXMI_TILE"); if (e && *e) forced = atoi(e); }
     if (forced >= 0 && forced < NC && !(cands[forced].bn == 128 && a.Cout <= 64) &&
-        (forced < 5 || (forced != 9 && gemm256_ok) || ((forced == 7 || forced == 9) && pp_conv_ok))) best = forced;
+        (forced < 5 || (forced < 9 && gemm256_ok) || ((forced == 7 || forced == 9) && pp_conv_ok) ||
+         (forced == 10 && (pp_conv128_ok || gemm128_ok)))) best = forced;
+    if ((best == 7 || best >= 9) && !(a.R == 1 && a.S == 1) && allow_split && tail_mode != 0) {
+        // Image-axis tail split: one workgroup per CU, so a last round with few tiles costs a whole tile time.  The
+        // images whose rows fill the whole rounds stay on this kernel; the last few images are a convolution of their
+        // own on the small tiles (28 x 28 stage of ResNet-50 at batch 256: 784 tiles = 3.06 rounds -> 250 + 6 images).
+        const int bm = cands[best].bm, bn = cands[best].bn;
+        const long ntn = (a.Cout + bn - 1) / bn;
+        const long tiles = (long)((a.M + bm - 1) / bm) * ntn;
+        const long full = tiles / cus, left = tiles % cus;
+        if (full >= 1 && left != 0 && 4 * left <= cus) {
+            const int n1 = (int)(((full * cus) / ntn) * bm / a.HoWo);
+            if (n1 >= 1 && n1 < a.N) {
+                ConvArgs lo = a, hi = a;
+                lo.N = n1; lo.M = n1 * a.HoWo;
+                hi.N = a.N - n1; hi.M = hi.N * a.HoWo;
+                const size_t xoff = (size_t)n1 * a.H * a.W * a.x_ld * sizeof(T), yoff = (size_t)n1 * a.HoWo * a.y_ld * sizeof(T);
+                hi.x = a.x + xoff;
+                hi.y = a.y + yoff;
+                if (a.res) hi.res = a.res + (size_t)n1 * a.HoWo * a.res_ld * sizeof(T);
+                lo.x_bytes = (unsigned)xoff; hi.x_bytes = a.x_bytes - lo.x_bytes;
+                lo.y_bytes = (unsigned)yoff; hi.y_bytes = a.y_bytes - lo.y_bytes;
+                const int rc = dispatch<T>(lo, st, allow_stream, false);
+                if (rc != TLXMI_OK) return rc;
+                return dispatch<T>(hi, st, false, false);
+            }
+        }
+    }
     if (best >= 7 && tail_split) {
         // rows of the full rounds (whole M tiles) -> this candidate; the rest -> best small-tile candidate
         const int nt = (a.Cout + 255) / 256;
@@ -706,7 +742,7 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
         Gemm256Args g;
         g.debug = 0;
         g.conv = 0;
-        if (!gemm256_ok) {      // candidates 7 / 9 as a convolution
+        if (!(a.R == 1 && a.S == 1)) {      // candidates 7 / 9 / 10 as a convolution
             g.conv = 1;
             g.cH = a.H; g.cW = a.W; g.cWo = a.Wo; g.cHoWo = a.HoWo; g.csh = a.sh; g.csw = a.sw; g.cph = a.ph; g.cpw = a.pw;
             g.ctaps = a.R * a.S;
@@ -726,10 +762,10 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
                 return launch_gemm_stream(sizeof(T) == 2 ? TLXMI_F16 : TLXMI_F32, g, st, cus);
             best = 7;
         }
-        if (best == 7 || best == 9) {
+        if (best == 7 || best >= 9) {
             g.ksteps = a.Kp_bytes / 128;
-            return best == 7 ? launch_gemm_pp(sizeof(T) == 2 ? TLXMI_F16 : TLXMI_F32, g, st)
-                             : launch_gemm_pp128(sizeof(T) == 2 ? TLXMI_F16 : TLXMI_F32, g, st);
+            const int dt = sizeof(T) == 2 ? TLXMI_F16 : TLXMI_F32;
+            return best == 7 ? launch_gemm_pp(dt, g, st) : best == 9 ? launch_gemm_pp128(dt, g, st) : launch_gemm_pp_n128(dt, g, st);
         }
         return launch_gemm256(sizeof(T) == 2 ? TLXMI_F16 : TLXMI_F32, best - 5, g, st);
     }

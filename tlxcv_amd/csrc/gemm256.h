@@ -34,6 +34,7 @@ int launch_gemm256(int dtype, int variant, const Gemm256Args& a, hipStream_t st)
 // gemm_pp.hip: 256 x 256 tile, two wave groups in antiphase; a.ksteps = packed pitch / 128
 int launch_gemm_pp(int dtype, const Gemm256Args& a, hipStream_t st);
 int launch_gemm_pp128(int dtype, const Gemm256Args& a, hipStream_t st);   // 128 x 256 tiles (tails)
+int launch_gemm_pp_n128(int dtype, const Gemm256Args& a, hipStream_t st); // 256 x 128 tiles (128 output channels)
 // gemm_stream.hip: persistent version (one workgroup per CU walks its tiles as one K-tile stream)
 bool gemm_stream_ok(int dtype, const Gemm256Args& a);
 int launch_gemm_stream(int dtype, const Gemm256Args& a, hipStream_t st, int cus);

@@ -66,14 +66,17 @@ template <> struct MmaPP<float> {
 // darknet.py:54-58).  A K tile of 128 bytes lies inside one filter tap (C * sizeof(T) = 128 << ctshift), so the tap
 // of a K tile is wave-uniform: its byte offset is scalar arithmetic, and each of a lane's four rows carries a bit
 // mask of the taps that fall inside the image (bit clear -> out-of-range descriptor offset -> zero fill).
-template <typename T, int HM, bool CONV>
+// HN = W half tiles per K tile: (HM, HN) = (2, 1) is the mirror image of (1, 2) — a 256 x 128 tile for layers with 128
+// output channels (3x3 convs of ResNet's 28 x 28 stage): phases (0,0) and (1,0), X1 taking W1's place in the DMA order.
+template <typename T, int HM, int HN, bool CONV>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
+    static_assert(HM + HN >= 3 && HM <= 2 && HN <= 2, "tile is 256x256, 128x256 or 256x128");
     constexpr int ES = (int)sizeof(T);
-    constexpr int BM = 128 * HM, BN = 256;
+    constexpr int BM = 128 * HM, BN = 128 * HN;
     constexpr int HALF = 128 * 128;            // bytes of a half tile
-    constexpr int RX0 = 0, RX1 = HALF, RW0 = HM * HALF, RW1 = (HM + 1) * HALF;   // regions of a K tile (RX1: HM == 2)
-    constexpr int KTB = (HM + 2) * HALF;       // bytes of a K tile
-    constexpr int NBUF = HM == 2 ? 2 : 3;      // resident K tiles
+    constexpr int RX0 = 0, RX1 = HALF, RW0 = HM * HALF, RW1 = (HM + 1) * HALF;   // regions of a K tile (RX1: HM == 2, RW1: HN == 2)
+    constexpr int KTB = (HM + HN) * HALF;      // bytes of a K tile
+    constexpr int NBUF = (HM + HN == 4) ? 2 : 3;   // resident K tiles
     constexpr int OOB = (int)0x80000000;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -156,9 +159,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
     const int foff = frow * 128 + ((fg ^ ((frow >> 1) & 7)) << 4);
     const int xf0 = wr * 64 * 128 + foff, wf0 = wc * 32 * 128 + foff;   // ksub 1 = same offset ^ 64
 
-    f32x4 acc[4][4 * HM];   // [2*g + ci][4*h + pi]
+    f32x4 acc[2 * HN][4 * HM];   // [2*g + ci][4*h + pi]
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 2 * HN; ++i)
 #pragma unroll
         for (int j = 0; j < 4 * HM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -209,13 +212,20 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
             else rowab[h][pi] = (a.rowstats && m < a.M) ? *reinterpret_cast<const float2*>(a.rowstats + 2 * (size_t)m) : make_float2(1.f, 0.f);
         }
     __builtin_amdgcn_sched_barrier(0);   // these loads are older than every DMA: their wait leaves the DMAs in flight
-    if constexpr (HM == 2) {
+    if constexpr (HM == 2 && HN == 2) {
         stage_x(0, 0, 0);
         stage_w(0, 0, 0);
         stage_w(1, 0, 0);
         stage_x(1, 0, 0);
         stage_x(0, 1, 1);
         stage_w(0, 1, 1);
+    } else if constexpr (HN == 1) {
+        stage_x(0, 0, 0);
+        stage_w(0, 0, 0);
+        stage_x(1, 0, 0);
+        stage_x(0, 1, 1);
+        stage_w(0, 1, 1);
+        stage_x(1, 1, 1);
     } else {
         stage_x(0, 0, 0);
         stage_w(0, 0, 0);
@@ -234,7 +244,30 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
     if (wr == 1) { TLXMI_PP_SYNC(); }   // group 1 runs one barrier behind
 
     const int ks = a.ksteps;
-    if constexpr (HM == 2) {
+    if constexpr (HN == 1) {
+        int bc = 0, b2 = 2;      // slots of K tiles kt and kt + 2 (mod 3)
+        for (int kt = 0; kt < ks; ++kt) {
+            const char* kb = smem + bc * KTB;
+            // p0
+            read_x(kb, RX0);
+            read_w(kb, RW0, w0f);
+            stage_x(0, kt + 2, b2);
+            stage_w(0, kt + 2, b2);
+            asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // X1(kt)
+            TLXMI_PP_SYNC();
+            TLXMI_PP_MMA(0, 0, w0f);
+            TLXMI_PP_SYNC();
+            // p1
+            read_x(kb, RX1);
+            stage_x(1, kt + 2, b2);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // X0(kt+1), W0(kt+1)
+            TLXMI_PP_SYNC();
+            TLXMI_PP_MMA(HM - 1, 0, w0f);
+            TLXMI_PP_SYNC();
+            bc = bc == 2 ? 0 : bc + 1;
+            b2 = b2 == 2 ? 0 : b2 + 1;
+        }
+    } else if constexpr (HM == 2) {
         for (int kt = 0; kt < ks; ++kt) {
             const char* kb = smem + (kt & 1) * KTB;
             // p0
@@ -296,7 +329,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
 
     if (a.debug & 1) {   // ablation: no epilogue
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 2 * HN; ++i)
 #pragma unroll
             for (int j = 0; j < 4 * HM; ++j) asm volatile("" ::"v"(acc[i][j]));
         return;
@@ -309,7 +342,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
     auto epi = [&](auto act_tag) {
         constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
+        for (int g = 0; g < HN; ++g) {
             const int col = 128 * g + 32 * wc + 8 * fg;
             const int ch0 = bn0 + col;
             if (ch0 >= a.Cout) continue;      // Cout is a multiple of 8 on this path
@@ -401,14 +434,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
 }
 
 // Preconditions as launch_gemm256 (checked by conv_igemm.hip's dispatcher); a.ksteps = packed pitch / 128.
-template <typename T, int HM, bool CONV> static int launch_pp_t(const Gemm256Args& a0, hipStream_t st, bool& raised) {
+template <typename T, int HM, int HN, bool CONV> static int launch_pp_t(const Gemm256Args& a0, hipStream_t st, bool& raised) {
     Gemm256Args a = a0;
     { static const int dbg = [] { const char* e = getenv("TLXMI_DEBUG"); return e ? atoi(e) : 0; }(); a.debug = dbg; }
     a.mtiles = (a.M + 128 * HM - 1) / (128 * HM);
-    a.ntiles = (a.Cout + 255) / 256;
+    a.ntiles = (a.Cout + 128 * HN - 1) / (128 * HN);
     a.gn = a.ntiles;
-    const size_t lds = (size_t)(HM == 2 ? 8 : 9) * 128 * 128 + 2 * 256 * sizeof(float);
-    const void* fn = reinterpret_cast<const void*>(&gemm_pp_kernel<T, HM, CONV>);
+    const size_t lds = (size_t)(HM + HN == 4 ? 8 : 9) * 128 * 128 + 2 * 256 * sizeof(float);
+    const void* fn = reinterpret_cast<const void*>(&gemm_pp_kernel<T, HM, HN, CONV>);
     if (!raised) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail(TLXMI_ERR_LAUNCH, "gemm_pp: cannot raise LDS limit: %s", hipGetErrorString(e));
@@ -423,22 +456,33 @@ template <typename T, int HM, bool CONV> static int launch_pp_t(const Gemm256Arg
 int launch_gemm_pp(int dtype, const Gemm256Args& a, hipStream_t st) {
     static bool raised[4] = {false, false, false, false};
     if (a.conv) {
-        if (dtype == TLXMI_F16) return launch_pp_t<half_t, 2, true>(a, st, raised[2]);
-        return launch_pp_t<float, 2, true>(a, st, raised[3]);
+        if (dtype == TLXMI_F16) return launch_pp_t<half_t, 2, 2, true>(a, st, raised[2]);
+        return launch_pp_t<float, 2, 2, true>(a, st, raised[3]);
     }
-    if (dtype == TLXMI_F16) return launch_pp_t<half_t, 2, false>(a, st, raised[0]);
-    return launch_pp_t<float, 2, false>(a, st, raised[1]);
+    if (dtype == TLXMI_F16) return launch_pp_t<half_t, 2, 2, false>(a, st, raised[0]);
+    return launch_pp_t<float, 2, 2, false>(a, st, raised[1]);
 }
 
 // 128 x 256 tiles (same preconditions)
 int launch_gemm_pp128(int dtype, const Gemm256Args& a, hipStream_t st) {
     static bool raised[4] = {false, false, false, false};
     if (a.conv) {
-        if (dtype == TLXMI_F16) return launch_pp_t<half_t, 1, true>(a, st, raised[2]);
-        return launch_pp_t<float, 1, true>(a, st, raised[3]);
+        if (dtype == TLXMI_F16) return launch_pp_t<half_t, 1, 2, true>(a, st, raised[2]);
+        return launch_pp_t<float, 1, 2, true>(a, st, raised[3]);
     }
-    if (dtype == TLXMI_F16) return launch_pp_t<half_t, 1, false>(a, st, raised[0]);
-    return launch_pp_t<float, 1, false>(a, st, raised[1]);
+    if (dtype == TLXMI_F16) return launch_pp_t<half_t, 1, 2, false>(a, st, raised[0]);
+    return launch_pp_t<float, 1, 2, false>(a, st, raised[1]);
+}
+
+// 256 x 128 tiles (layers with 128 output channels)
+int launch_gemm_pp_n128(int dtype, const Gemm256Args& a, hipStream_t st) {
+    static bool raised[4] = {false, false, false, false};
+    if (a.conv) {
+        if (dtype == TLXMI_F16) return launch_pp_t<half_t, 2, 1, true>(a, st, raised[2]);
+        return launch_pp_t<float, 2, 1, true>(a, st, raised[3]);
+    }
+    if (dtype == TLXMI_F16) return launch_pp_t<half_t, 2, 1, false>(a, st, raised[0]);
+    return launch_pp_t<float, 2, 1, false>(a, st, raised[1]);
 }
 
 }  // namespace tlxmi
