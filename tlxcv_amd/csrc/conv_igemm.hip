@@ -65,6 +65,8 @@ struct ConvArgs {
     int nchunk;
     int gx, gy, gres, gc;       // per-chunk byte offsets into x / y / res pixels, channel offset of scale / shift
     unsigned gw;                // bytes between the packed filters of consecutive chunks
+    int diag;                   // 1: 64 -> 64 channel chunks whose filter is block-diagonal at 32 channels (fp16): the wave
+                                // that owns output channels 32c..32c+31 needs only the K half 32c..32c+31 of every tap
 };
 
 __device__ __attribute__((aligned(16))) unsigned g_zero_page[4];  // source of padding / tail chunks
@@ -133,8 +135,9 @@ static __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const char* p,
 // WGM = waves along the pixel axis (2 or 4; always 2 along channels), STAGES = LDS-DMA ring depth.
 // RESP = the residual tile is prefetched into registers at kernel entry (dense, 16-byte-aligned residual):
 // its HBM latency then overlaps the first DMA stage instead of starting after the last MFMA.
-template <typename T, int BM, int BN, bool IS_1X1, int WGM, int STAGES, bool RESP>
+template <typename T, int BM, int BN, bool IS_1X1, int WGM, int STAGES, bool RESP, bool DIAG = false>
 __global__ __launch_bounds__(WGM * 128) void conv_igemm_kernel(const ConvArgs a0) {
+    static_assert(!DIAG || (BN == 64 && sizeof(T) == 2 && !IS_1X1), "DIAG: 64-channel fp16 chunks of a grouped conv");
     constexpr int ES = (int)sizeof(T);
     ConvArgs a = a0;
     if (a.nchunk > 1) {
@@ -344,6 +347,9 @@ __global__ __launch_bounds__(WGM * 128) void conv_igemm_kernel(const ConvArgs a0
         const char* b = smem + buf * BUF;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
+            if constexpr (DIAG) {
+                if (ks != wid / WGM) continue;     // the other 32 input channels meet only zeros of this wave's filter rows
+            }
             u32x4 wf[CI], xf[PI];
 #pragma unroll
             for (int ci = 0; ci < CI; ++ci)
@@ -536,17 +542,25 @@ template <typename T, int BM, int BN, int WGM, int STAGES> static int launch(con
                           reinterpret_cast<const void*>(&conv_igemm_kernel<T, BM, BN, false, WGM, STAGES, true>),
                           reinterpret_cast<const void*>(&conv_igemm_kernel<T, BM, BN, true, WGM, STAGES, false>),
                           reinterpret_cast<const void*>(&conv_igemm_kernel<T, BM, BN, true, WGM, STAGES, true>)};
-    const int which = (is1x1 ? 2 : 0) + (resp ? 1 : 0);
+    int which = (is1x1 ? 2 : 0) + (resp ? 1 : 0);
+    const void* fns_diag[2] = {nullptr, nullptr};
+    if constexpr (BN == 64 && sizeof(T) == 2) {
+        fns_diag[0] = reinterpret_cast<const void*>(&conv_igemm_kernel<T, BM, BN, false, WGM, STAGES, false, true>);
+        fns_diag[1] = reinterpret_cast<const void*>(&conv_igemm_kernel<T, BM, BN, false, WGM, STAGES, true, true>);
+    }
+    const bool diag = a.diag && !is1x1 && fns_diag[0] != nullptr;
+    const void* fn = diag ? fns_diag[resp ? 1 : 0] : fns[which];
+    if (diag) which = 4 + (resp ? 1 : 0);
     if (lds > 64 * 1024) {
-        static bool raised[4] = {false, false, false, false};
+        static bool raised[6] = {false, false, false, false, false, false};
         if (!raised[which]) {
-            hipError_t e = hipFuncSetAttribute(fns[which], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return fail(TLXMI_ERR_LAUNCH, "conv2d: cannot raise LDS limit: %s", hipGetErrorString(e));
             raised[which] = true;
         }
     }
     void* args[] = {&b};
-    hipError_t e = hipLaunchKernel(fns[which], dim3((unsigned)grid, (unsigned)a.nchunk), dim3(WGM * 128), args, lds, st);
+    hipError_t e = hipLaunchKernel(fn, dim3((unsigned)grid, (unsigned)a.nchunk), dim3(WGM * 128), args, lds, st);
     if (e != hipSuccess) return fail(TLXMI_ERR_LAUNCH, "conv2d: HIP launch failed: %s", hipGetErrorString(e));
     return TLXMI_OK;
 }
@@ -783,8 +797,9 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
 using namespace tlxmi;
 
 // nchunk launch chunks of (C / nchunk) -> (Cout / nchunk) channels each; nchunk == 1: the dense convolution
+// diag32: the filter of every chunk is block-diagonal at a granularity that divides 32 channels (in == out per group)
 static int conv2d_impl(const tlxmi_conv2d_desc* d, int nchunk, const void* x, const void* w_packed,
-                       const float* scale, const float* shift, const void* res, void* y, void* stream) {
+                       const float* scale, const float* shift, const void* res, void* y, void* stream, bool diag32 = false) {
     TLXMI_REQUIRE(d && x && w_packed && y, TLXMI_ERR_BAD_ARG, "conv2d: null descriptor or buffer");
     TLXMI_REQUIRE(d->dtype == TLXMI_F16 || d->dtype == TLXMI_F32, TLXMI_ERR_BAD_ARG, "conv2d: bad dtype %d", d->dtype);
     TLXMI_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->C > 0 && d->Cout > 0 && d->R > 0 && d->S > 0,
@@ -838,6 +853,7 @@ static int conv2d_impl(const tlxmi_conv2d_desc* d, int nchunk, const void* x, co
     a.gy = a.gres = nchunk > 1 ? cw_out * es : 0;
     a.gc = nchunk > 1 ? cw_out : 0;
     a.gw = nchunk > 1 ? a.w_bytes : 0u;
+    a.diag = diag32 && es == 2 && cw_in == 64 && cw_out == 64 ? 1 : 0;
     const int vecn = 16 / es;  // elements per 16 bytes
     const bool bcast = res && (d->flags & TLXMI_EPI_RES_BCAST_N);
     TLXMI_REQUIRE(d->y_nstride >= 0 && d->res_nstride >= 0, TLXMI_ERR_BAD_ARG, "conv2d: negative batch stride");
@@ -916,7 +932,8 @@ extern "C" int tlxmi_group_conv2d(const tlxmi_conv2d_desc* d, int groups, const 
     TLXMI_REQUIRE(nchunk <= 65535, TLXMI_ERR_UNSUPPORTED, "group_conv2d: %d launch chunks", nchunk);
     TLXMI_REQUIRE(!res || (d->res_ld * (int)elt_size(d->dtype)) % 16 == 0, TLXMI_ERR_ALIGNMENT, "group_conv2d: res_ld=%d", d->res_ld);
     TLXMI_REQUIRE((d->y_ld * (int)elt_size(d->dtype)) % 16 == 0, TLXMI_ERR_ALIGNMENT, "group_conv2d: y_ld=%d", d->y_ld);
-    return conv2d_impl(d, nchunk, x, w_packed, scale, shift, res, y, stream);
+    const int cgi = d->C / groups, cgo = d->Cout / groups;
+    return conv2d_impl(d, nchunk, x, w_packed, scale, shift, res, y, stream, cgi == cgo && 32 % cgi == 0);
 }
 
 // LayerNorm + Linear in one launch (vision_transformer.py:144-159 norm1 -> attn.qkv, norm2 -> mlp.fc1;
