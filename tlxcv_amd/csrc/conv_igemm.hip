@@ -629,14 +629,17 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
     const bool pp_conv_ok = pp_conv128_ok && a.Cout >= 256;
     if (!gemm256_ok) cands[5].eff = cands[6].eff = cands[8].eff = 0.f;
     if (!gemm256_ok && !pp_conv_ok) cands[7].eff = 0.f;
-    if (!pp_conv_ok) cands[9].eff = 0.f;
+    // 128 x 256 tiles for plain GEMM rows too (few row tiles: 7 x 7 stage, 2048 -> 512); TLXMI_PP128=0: convs only (A/B)
+    int pp128_gemm = 1;
+    { const char* e = getenv("TLXMI_PP128"); if (e && *e) pp128_gemm = atoi(e); }
+    if (!pp_conv_ok && !(gemm256_ok && pp128_gemm)) cands[9].eff = 0.f;
     if (!pp_conv128_ok) cands[10].eff = 0.f;      // (1x1 layers: reachable through TLXMI_TILE=10 only)
     cands[5].eff = 0.f;   // superseded by candidate 7 (same tile, antiphase wave groups); kept for A/B runs (TLXMI_TILE=5)
     if (obi >= 0.0015 || a.ktiles < 4) cands[4].eff = 0.f;
     // regimes by output bytes per FLOP (tools/ab_tiles.py sweep over the ResNet-50 / ViT-B / Swin-B layer shapes):
     // the 256-row GEMM kernels win up to ~0.005 (256x256) / ~0.02 (256x128, two workgroups per CU); beyond that
     // the layer is HBM / latency-bound and wants many small resident blocks
-    if (obi >= 0.005) cands[7].eff = cands[8].eff = 0.f;
+    if (obi >= 0.005) cands[7].eff = cands[8].eff = cands[9].eff = 0.f;
     if (obi >= 0.020) cands[6].eff = 0.f;
     if (obi >= 0.020 || (obi >= 0.010 && a.ktiles == 1)) { cands[0].eff = 0.65f; cands[1].eff = 0.80f; cands[2].eff = 0.85f; cands[3].eff = 1.00f; }   // 64 -> 256 (+ skip) at 56x56: one K step
     else if (obi >= 0.010) { cands[0].eff = 1.00f; cands[1].eff = 0.95f; cands[2].eff = 0.95f; cands[3].eff = 0.85f; }   // 128 -> 512 + skip at 28x28
@@ -673,7 +676,7 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
         const long slots = (long)cus * per_cu;
         const long rounds = (blocks + slots - 1) / slots;
         float quant = (float)blocks / (float)(rounds * slots);
-        if (i >= 7 && tail_split) quant = (float)blocks / (((float)full_rounds + 0.6f) * slots);   // the tail round: ~0.6 of a tile time
+        if ((i == 7 || i == 8) && tail_split) quant = (float)blocks / (((float)full_rounds + 0.6f) * slots);   // the tail round: ~0.6 of a tile time
         // 3x3 convs on the antiphase kernel: a short last round is cut off along the image axis (below)
         if ((i == 7 || i >= 9) && !(a.R == 1 && a.S == 1) && allow_split && tail_mode != 0 && blocks / slots >= 1 &&
             blocks % slots != 0 && 4 * (blocks % slots) <= slots)
@@ -688,7 +691,7 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
     int forced = -1;
     { const char* e = getenv("TLXMI_TILE"); if (e && *e) forced = atoi(e); }
     if (forced >= 0 && forced < NC && !(cands[forced].bn == 128 && a.Cout <= 64) &&
-        (forced < 5 || (forced < 9 && gemm256_ok) || ((forced == 7 || forced == 9) && pp_conv_ok) ||
+        (forced < 5 || (forced <= 9 && gemm256_ok) || ((forced == 7 || forced == 9) && pp_conv_ok) ||
          (forced == 10 && (pp_conv128_ok || gemm128_ok)))) best = forced;
     if ((best == 7 || best >= 9) && !(a.R == 1 && a.S == 1) && allow_split && tail_mode != 0) {
         // Image-axis tail split: one workgroup per CU, so a last round with few tiles costs a whole tile time.  The
@@ -716,7 +719,7 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
             }
         }
     }
-    if (best >= 7 && tail_split) {
+    if ((best == 7 || best == 8) && tail_split) {
         // rows of the full rounds (whole M tiles) -> this candidate; the rest -> best small-tile candidate
         const int nt = (a.Cout + 255) / 256;
         const int m_split = (int)((full_rounds * cus) / nt) * 256;
