@@ -1,0 +1,21 @@
+#!/bin/bash
+# Host side, after `gpurun -- bash tools/refresh_profiles.sh` (and `tools/gpu_ci.sh bench benchvit benchswin`): copy the
+# summaries to be judged from the scratch gpurun_out/ into profiles/<round>/.  gpurun MERGES into gpurun_out/, so older
+# rocprof run directories may still be there: always take the newest file.
+set -u
+R=${1:-r01}
+cd "$(dirname "$0")/.."
+mkdir -p profiles/$R
+: > profiles/$R/bench_lines_under_rocprof.jsonl
+for wl in resnet50 vit_b16 swin_b; do
+  f=$(find gpurun_out/prof_$wl -name "*kernel_stats.csv" -printf "%T@ %p\n" | sort -n | tail -1 | cut -d" " -f2)
+  cp "$f" profiles/$R/${wl}_kernel_stats.csv
+  cp gpurun_out/layers_$wl.txt profiles/$R/${wl}_layer_times.txt
+  cp gpurun_out/traffic_$wl/traffic.json profiles/$R/traffic_$wl.json
+  grep '^{"metric"' gpurun_out/prof_$wl/bench.log >> profiles/$R/bench_lines_under_rocprof.jsonl
+done
+if [ -f gpurun_out/bench.log ]; then
+  : > profiles/$R/bench_lines.jsonl
+  for f in bench benchvit benchswin; do grep '^{"metric"' gpurun_out/$f.log >> profiles/$R/bench_lines.jsonl; done
+fi
+ls -la profiles/$R
