@@ -97,6 +97,37 @@ __global__ __launch_bounds__(128) void nchw_to_nhwc_s2d_kernel(const TS* __restr
     }
 }
 
+// The RGB stem case (b = 2, C = 3, fp32 image, W even): per (channel, row parity) one 8-byte load brings the two
+// horizontal neighbours, six loads per output pixel instead of twelve, consecutive lanes read consecutive 8 bytes.
+template <typename TD>
+__global__ __launch_bounds__(256) void nchw3_to_nhwc_s2d2_kernel(const float* __restrict__ src, TD* __restrict__ dst, int H, int W,
+                                                               int Cpad, long total) {
+    constexpr int V = Chunk<TD>::N;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;    // output pixel
+    if (i >= total) return;
+    const int H2 = H >> 1, W2 = W >> 1;
+    const long row = i / W2;                                  // n*H2 + h2
+    const int w2 = (int)(i - row * W2);
+    const long n = row / H2;
+    const int h2 = (int)(row - n * H2);
+    const long HW = (long)H * W;
+    const float* sp = src + n * 3 * HW + (long)(2 * h2) * W + 2 * w2;
+    float v16[16];
+#pragma unroll
+    for (int e = 12; e < 16; ++e) v16[e] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+            const float2 t = *reinterpret_cast<const float2*>(sp + c * HW + (long)ph * W);
+            v16[(ph * 2 + 0) * 3 + c] = t.x;
+            v16[(ph * 2 + 1) * 3 + c] = t.y;
+        }
+    TD* dp = dst + i * Cpad;
+#pragma unroll
+    for (int cg = 0; cg < 16 / V; ++cg) Chunk<TD>::store(dp + cg * V, v16 + cg * V);
+}
+
 template <typename TS, typename TD>
 __global__ void nhwc_to_nchw_kernel(const TS* __restrict__ src, int ld, TD* __restrict__ dst, int N, int C, int H,
                                     int W) {
@@ -413,6 +444,13 @@ extern "C" int tlxmi_nchw_to_nhwc_s2d(const void* src, int sdt, void* dst, int d
     TLXMI_REQUIRE(blocks < (1l << 31), TLXMI_ERR_UNSUPPORTED, "nchw_to_nhwc_s2d: too many rows");
     dim3 g((unsigned)blocks), blk(128);
     hipStream_t st = as_stream(stream);
+    if (sdt == TLXMI_F32 && b == 2 && C == 3 && Cpad == 16 && W % 2 == 0 && ((uintptr_t)src % 8) == 0) {
+        const long total = (long)N * (H / 2) * (W / 2);
+        const dim3 g2((unsigned)((total + 255) / 256));
+        if (ddt == TLXMI_F16) hipLaunchKernelGGL((nchw3_to_nhwc_s2d2_kernel<half_t>), g2, dim3(256), 0, st, (const float*)src, (half_t*)dst, H, W, Cpad, total);
+        else hipLaunchKernelGGL((nchw3_to_nhwc_s2d2_kernel<float>), g2, dim3(256), 0, st, (const float*)src, (float*)dst, H, W, Cpad, total);
+        return check_launch("nchw_to_nhwc_s2d");
+    }
     if (sdt == TLXMI_F32 && ddt == TLXMI_F16)
         hipLaunchKernelGGL((nchw_to_nhwc_s2d_kernel<float, half_t>), g, blk, 0, st, (const float*)src, (half_t*)dst, N, C, H, W, b, Cpad, cb);
     else if (sdt == TLXMI_F32 && ddt == TLXMI_F32)
