@@ -28,6 +28,9 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 MFMA_F16_PEAK_TF = 2500.0  # dense fp16 MFMA
+# measured on a box of this pool (tools/roofline_denominators.py -> profiles/r01/roofline_denominators.txt):
+MEASURED_HBM_COPY_GBS = 4750.0    # torch copy of 1-4 GiB, read + write bytes
+MEASURED_GEMM_F16_TF = 1333.0     # hipBLASLt (torch.matmul) 16384 x 4096 x 4096
 
 
 def build_model(workload, dev):
@@ -177,6 +180,8 @@ def main():
             "peak": HBM_PEAK_GBS if hbm_bound else MFMA_F16_PEAK_TF,
             "unit": "GB/s" if hbm_bound else "TFLOP/s",
             "frac": round(gbs / HBM_PEAK_GBS if hbm_bound else tfs / MFMA_F16_PEAK_TF, 4), "traffic": traffic,
+            "peak_measured": MEASURED_HBM_COPY_GBS if hbm_bound else MEASURED_GEMM_F16_TF,
+            "frac_of_measured": round(gbs / MEASURED_HBM_COPY_GBS if hbm_bound else tfs / MEASURED_GEMM_F16_TF, 4),
             "kernel": "tlxmi_conv2d kernel family: conv_igemm_kernel, gemm_pp_kernel, gemm_stream_kernel, gemm256_kernel (all instantiations; every conv / linear launch of one forward)",
             "launches_per_step": nl // nprobe, "avg_launch_us": round(per_launch_us, 2),
             "alg_bytes_per_launch": int(alg_bytes / nl), "alg_flops_per_launch": int(flops / nl),
