@@ -124,23 +124,6 @@ __global__ __launch_bounds__(WGN * 128, 2) void gemm256_kernel(const Gemm256Args
 #pragma unroll
         for (int pi = 0; pi < PI; ++pi) acc[ci][pi] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // fp16: the residual of the wave's first channel pair is fetched before anything else, so its HBM latency runs
-    // under the whole K loop instead of starting after the last MFMA (the loads are older than every DMA: the
-    // counted waits of the K loop cover them); the second pair is fetched while the first is being stored.
-    constexpr bool RESP = ES == 2;
-    const int g = lane >> 4, px = lane & 15;
-    const __amdgpu_buffer_rsrc_t rsrd = srd(a.res ? a.res : a.y, a.res ? a.res_bytes : 0u);
-    u32x4 rpre[RESP ? PI : 1];
-    if constexpr (RESP) {
-        if (a.res) {
-            const int ch0 = bn0 + wave_n0 + 8 * g;
-#pragma unroll
-            for (int pi = 0; pi < PI; ++pi) {
-                const int m = bm0 + wave_m0 + pi * 16 + px;
-                rpre[pi] = buf_load16(rsrd, (m < a.M && ch0 < a.Cout) ? (m * a.res_ld + ch0) * ES : OOB);
-            }
-        }
-    }
     const int ks = a.ksteps;
     stage(0);
     if (ks > 1) stage(1);
@@ -175,8 +158,9 @@ __global__ __launch_bounds__(WGN * 128, 2) void gemm256_kernel(const Gemm256Args
     }
 
     // ---- epilogue from registers: lane (g, px) owns channels 32cp + 8g .. +7 of pixel 16pi + px
+    const int g = lane >> 4, px = lane & 15;
     const bool res_after = (a.flags & TLXMI_EPI_RES_AFTER_ACT) != 0;
-    const __amdgpu_buffer_rsrc_t ysrd = srd(a.y, a.y_bytes);
+    const __amdgpu_buffer_rsrc_t ysrd = srd(a.y, a.y_bytes), rsrd = srd(a.res ? a.res : a.y, a.res ? a.res_bytes : 0u);
     auto epi = [&](auto act_tag) {
     constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
@@ -193,17 +177,12 @@ __global__ __launch_bounds__(WGN * 128, 2) void gemm256_kernel(const Gemm256Args
         }
         u32x4 rr[PI][ES / 2];
         if (a.res) {
-            if (RESP && cp == 0) {
 #pragma unroll
-                for (int pi = 0; pi < PI; ++pi) rr[pi][0] = rpre[pi];
-            } else {
+            for (int pi = 0; pi < PI; ++pi) {
+                const int m = bm0 + wave_m0 + pi * 16 + px;
+                const int ro = m < a.M ? (m * a.res_ld + ch0) * ES : OOB;
 #pragma unroll
-                for (int pi = 0; pi < PI; ++pi) {
-                    const int m = bm0 + wave_m0 + pi * 16 + px;
-                    const int ro = m < a.M ? (m * a.res_ld + ch0) * ES : OOB;
-#pragma unroll
-                    for (int hh = 0; hh < ES / 2; ++hh) rr[pi][hh] = buf_load16(rsrd, ro + 16 * hh);
-                }
+                for (int hh = 0; hh < ES / 2; ++hh) rr[pi][hh] = buf_load16(rsrd, ro + 16 * hh);
             }
         }
 #pragma unroll
