@@ -91,7 +91,9 @@ def main():
     from tlxcv_amd import dist as D, engine as E, seeded
     import torch.distributed as dist
 
-    rank, world, local = D.init()
+    # rank / world from the launcher's environment; the process group (RCCL) is created only AFTER the model is built
+    # and its forward captured into a hipGraph, so no communicator thread exists while the capture is open
+    rank, world, local = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")))
     if a.gpus != world:
         if world == 1 and a.gpus > 1:
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
@@ -109,6 +111,10 @@ def main():
     if not a.no_graph:
         from tlxcv_amd.graph import GraphedForward
         fwd = GraphedForward(model, x)       # the whole forward as one hipGraph; x is its static input
+
+    if world > 1:
+        r2, w2, _ = D.init()
+        assert (r2, w2) == (rank, world)
 
     def step():
         y = fwd(x) if fwd is model else fwd()
@@ -139,9 +145,9 @@ def main():
         "metric": "images/sec fwd", "value": round(value, 1), "unit": "images/sec", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-        "config": {"workload": {"resnet50": "ResNet-50 fp16 forward, 224x224, batch 256 per GPU (BASELINE configs[1])",
-                                "vit_b16": "ViT-B/16 fp16 forward, 224x224, batch 256 per GPU (BASELINE configs[2])",
-                                "swin_b": "Swin-B (window 7) fp16 forward, 224x224, batch 128 per GPU (BASELINE configs[3])"}[a.workload],
+        "config": {"workload": {"resnet50": f"ResNet-50 fp16 forward, 224x224, batch {a.batch} per GPU (BASELINE configs[1])",
+                                "vit_b16": f"ViT-B/16 fp16 forward, 224x224, batch {a.batch} per GPU (BASELINE configs[2])",
+                                "swin_b": f"Swin-B (window 7) fp16 forward, 224x224, batch {a.batch} per GPU (BASELINE configs[3])"}[a.workload],
                    "global_batch": a.batch * world, "per_gpu_batch": a.batch, "weights": "seeded random (tlxcv_amd.seeded, seed 1)",
                    "parallelism": f"batch-sharded x{world}, all-gather logits" if world > 1 else "single GPU",
                    "launch": "per-kernel" if a.no_graph else "hipGraph replay of the forward"},
