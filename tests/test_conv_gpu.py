@@ -271,6 +271,9 @@ PPCONV_CASES = [
     (1, 128, 264, 3, 1, 0, 19, 19, True, 0),       # no padding, channel tail (264 = 256 + 8)
     (1, 128, 512, (1, 3), 1, (0, 1), 9, 33, False, 2),   # 1 x 3 filter
     (5, 128, 256, 3, 1, 1, 10, 10, False, 1),      # 500 rows: 2 tiles of 256, the second ragged
+    (2, 256, 512, 1, 2, 0, 28, 28, False, 0),      # strided 1x1 projection shortcut (resnet.py:246-261): one tap, rows at stride 2
+    (1, 512, 1024, 1, 2, 0, 15, 13, False, 1),     # odd extents
+    (3, 128, 256, 1, 2, 0, 10, 10, True, 0),
 ]
 
 

@@ -623,7 +623,10 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
     const bool gemm256_ok = gemm128_ok && a.Cout >= 256;
     // 3x3 (R x 3) convs on the antiphase GEMM kernel: a 128-byte K tile must lie inside one filter tap
     const int tpk = a.cpt / 8;     // K tiles per tap
-    const bool pp_conv128_ok = a.nchunk == 1 && !(a.R == 1 && a.S == 1) && a.S == 3 && a.R <= 3 && a.dh == 1 && a.dw == 1 && !a.strided_n &&
+    // (also the strided 1x1 projection shortcuts, resnet.py:246-261: one "tap", rows gathered at stride 2)
+    const bool strided1x1 = a.R == 1 && a.S == 1 && a.ph == 0 && a.pw == 0 && (a.sh > 1 || a.sw > 1);
+    const bool as_conv = !(a.R == 1 && a.S == 1 && a.ph == 0 && a.pw == 0 && a.sh == 1 && a.sw == 1);   // needs the gather of CONV mode
+    const bool pp_conv128_ok = a.nchunk == 1 && ((a.S == 3 && a.R <= 3) || strided1x1) && a.dh == 1 && a.dw == 1 && !a.strided_n &&
                                a.vec_io && a.Cout % 8 == 0 && a.Cout >= 128 && a.y_bytes != 0 && a.cpt % 8 == 0 && (tpk & (tpk - 1)) == 0 &&
                                (!a.res || (long long)a.M * a.res_ld * (long long)sizeof(T) < (1ll << 31));
     const bool pp_conv_ok = pp_conv128_ok && a.Cout >= 256;
@@ -678,7 +681,7 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
         float quant = (float)blocks / (float)(rounds * slots);
         if ((i == 7 || i == 8) && tail_split) quant = (float)blocks / (((float)full_rounds + 0.6f) * slots);   // the tail round: ~0.6 of a tile time
         // 3x3 convs on the antiphase kernel: a short last round is cut off along the image axis (below)
-        if ((i == 7 || i >= 9) && !(a.R == 1 && a.S == 1) && allow_split && tail_mode != 0 && blocks / slots >= 1 &&
+        if ((i == 7 || i >= 9) && as_conv && allow_split && tail_mode != 0 && blocks / slots >= 1 &&
             blocks % slots != 0 && 4 * (blocks % slots) <= slots)
             quant = (float)blocks / (((float)(blocks / slots) + 0.4f) * slots);
         // wasted work inside partial tiles
@@ -693,7 +696,7 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
     if (forced >= 0 && forced < NC && !(cands[forced].bn == 128 && a.Cout <= 64) &&
         (forced < 5 || (forced <= 9 && gemm256_ok) || ((forced == 7 || forced == 9) && pp_conv_ok) ||
          (forced == 10 && (pp_conv128_ok || gemm128_ok)))) best = forced;
-    if ((best == 7 || best >= 9) && !(a.R == 1 && a.S == 1) && allow_split && tail_mode != 0) {
+    if ((best == 7 || best >= 9) && as_conv && allow_split && tail_mode != 0) {
         // Image-axis tail split: one workgroup per CU, so a last round with few tiles costs a whole tile time.  The
         // images whose rows fill the whole rounds stay on this kernel; the last few images are a convolution of their
         // own on the small tiles (28 x 28 stage of ResNet-50 at batch 256: 784 tiles = 3.06 rounds -> 250 + 6 images).
@@ -759,7 +762,7 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
         Gemm256Args g;
         g.debug = 0;
         g.conv = 0;
-        if (!(a.R == 1 && a.S == 1)) {      // candidates 7 / 9 / 10 as a convolution
+        if (as_conv) {      // candidates 7 / 9 / 10 as a convolution
             g.conv = 1;
             g.cH = a.H; g.cW = a.W; g.cWo = a.Wo; g.cHoWo = a.HoWo; g.csh = a.sh; g.csw = a.sw; g.cph = a.ph; g.cpw = a.pw;
             g.ctaps = a.R * a.S;
