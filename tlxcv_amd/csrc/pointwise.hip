@@ -201,7 +201,18 @@ __global__ void global_avgpool_kernel(const T* __restrict__ x, T* __restrict__ y
 #pragma unroll
         for (int e = 0; e < V; ++e) acc[e] = 0.f;
         const T* p = x + n * HW * x_ld + cg * V;
-        for (int k = 0; k < HW; ++k) {
+        // seven loads in flight per lane (7 x 7 maps: resnet.py:295-296); the additions keep their pixel order
+        int k = 0;
+        for (; k + 7 <= HW; k += 7) {
+            float v[7][V];
+#pragma unroll
+            for (int u = 0; u < 7; ++u) Chunk<T>::load(p + (long)(k + u) * x_ld, v[u]);
+#pragma unroll
+            for (int u = 0; u < 7; ++u)
+#pragma unroll
+                for (int e = 0; e < V; ++e) acc[e] += v[u][e];
+        }
+        for (; k < HW; ++k) {
             float v[V];
             Chunk<T>::load(p + (long)k * x_ld, v);
 #pragma unroll

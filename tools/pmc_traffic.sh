@@ -24,7 +24,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
                 continue
             if any(t in row["Kernel_Name"] for t in FAMILY):
                 s += float(row["Counter_Value"]); k += 1
-            elif "nchw_to_nhwc" in row["Kernel_Name"]:
+            elif "to_nhwc_s2d" in row["Kernel_Name"]:
                 f += 1          # exactly one layout transform per forward: counts the forwards of the run
     tot[c] = s; n[c] = k; fwd[c] = f
 forwards = max(fwd["FETCH_SIZE"], 1)
