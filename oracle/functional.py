@@ -7,6 +7,8 @@ TensorLayerX layer semantics assumed (restated from its documentation; not verif
 conv = cross-correlation with symmetric zero padding; BatchNorm eval = (x-mean)/sqrt(var+eps)*g+b,
 eps 1e-5; MaxPool pads -inf; LayerNorm biased variance; GELU exact erf; Linear y = x @ W(in,out) + b.
 """
+import math
+
 import torch
 import torch.nn.functional as F
 
@@ -170,6 +172,78 @@ def resnext(p, x, layers=50, cardinality=32):
             x = F.relu(short + y)                                             # :117-118
     x = F.adaptive_avg_pool2d(x, 1).reshape(x.shape[0], -1)                   # :210-211
     return linear(p, "out", x)                                                # :212
+
+
+# ---------------------------------------------------------------------------------------------
+# EfficientNet-B0..B7 — models/classification/efficientnet.py
+# ---------------------------------------------------------------------------------------------
+EFFNET_ARCH = {   # efficientnet.py:465-547: (width_mult, depth_mult, BatchNorm epsilon)
+    "efficientnet_b0": (1.0, 1.0, 1e-5), "efficientnet_b1": (1.0, 1.1, 1e-5), "efficientnet_b2": (1.1, 1.2, 1e-5),
+    "efficientnet_b3": (1.2, 1.4, 1e-5), "efficientnet_b4": (1.4, 1.8, 1e-5), "efficientnet_b5": (1.6, 2.2, 1e-3),
+    "efficientnet_b6": (1.8, 2.6, 1e-3), "efficientnet_b7": (2.0, 3.1, 1e-3),
+}
+EFFNET_STAGES = [  # efficientnet.py:446-454: expand ratio, kernel, stride, in, out, layers
+    (1, 3, 1, 32, 16, 1), (6, 3, 2, 16, 24, 2), (6, 5, 2, 24, 40, 2), (6, 3, 2, 40, 80, 3),
+    (6, 5, 1, 80, 112, 3), (6, 5, 2, 112, 192, 4), (6, 3, 1, 192, 320, 1),
+]
+
+
+def effnet_divisible(v, divisor=8, min_value=None):
+    """_make_divisible, efficientnet.py:181-194."""
+    if min_value is None:
+        min_value = divisor
+    new_v = max(min_value, int(v + divisor / 2) // divisor * divisor)
+    if new_v < 0.9 * v:
+        new_v += divisor
+    return new_v
+
+
+def same_pad(x, k, stride, dilation=1):
+    """padding='SAME' of TensorLayerX's torch backend [TLX-recalled]: TensorFlow's rule, odd unit bottom / right."""
+    pads = []
+    for i in (x.shape[3], x.shape[2]):          # F.pad order: W first
+        total = max(0, (-(-i // stride) - 1) * stride + dilation * (k - 1) + 1 - i)
+        pads += [total // 2, total - total // 2]
+    return F.pad(x, pads)
+
+
+def _effnet_cna(p, pre, x, stride, groups, silu, eps):
+    """ConvNormActivation efficientnet.py:92-125: GroupConv2d('SAME', bias) -> BatchNorm2d -> SiLU (:13-18) or nothing."""
+    w = _t(p, pre + ".0.filters")
+    y = F.conv2d(same_pad(x, w.shape[-1], stride), w, _t(p, pre + ".0.biases"), stride, 0, 1, groups)
+    y = bn(p, pre + ".1", y, eps)
+    return y * torch.sigmoid(y) if silu else y
+
+
+def efficientnet(p, x, arch="efficientnet_b0"):
+    """EfficientNet.forward efficientnet.py:426-431; MBConv.forward :302-307; SqueezeExcitation :169-178."""
+    wm, dm, eps = EFFNET_ARCH[arch]
+    adj = lambda c, m: effnet_divisible(c * m, 8)                              # MBConvConfig.adjust_channels :218-222
+    x = _effnet_cna(p, "features.0", x, 2, 1, True, eps)                      # :354-363  3x3 / 2
+    out_last = None
+    for si, (t, k, s, cin, cout, n) in enumerate(EFFNET_STAGES):
+        cin, cout, n = adj(cin, wm), adj(cout, wm), int(math.ceil(n * dm))   # :213-215, :225-226
+        for bi in range(n):
+            pre = f"features.{si + 1}.{bi}.block"
+            in_c, stride = (cin, s) if bi == 0 else (cout, 1)                  # :372-374
+            expanded = adj(in_c, t)                                            # :248-249
+            y, idx = x, 0
+            if expanded != in_c:                                               # :250-259 expand 1x1
+                y = _effnet_cna(p, f"{pre}.0", y, 1, 1, True, eps)
+                idx = 1
+            y = _effnet_cna(p, f"{pre}.{idx}", y, stride, expanded, True, eps)   # :261-271 depthwise k x k
+            se = f"{pre}.{idx + 1}"                                            # :273-282 squeeze = max(1, in_c // 4)
+            sc = F.adaptive_avg_pool2d(y, 1)
+            sc = F.conv2d(sc, _t(p, se + ".fc1.filters"), _t(p, se + ".fc1.biases"))
+            sc = sc * torch.sigmoid(sc)
+            sc = torch.sigmoid(F.conv2d(sc, _t(p, se + ".fc2.filters"), _t(p, se + ".fc2.biases")))
+            y = sc * y                                                         # :176-178
+            y = _effnet_cna(p, f"{pre}.{idx + 2}", y, 1, 1, False, eps)        # :284-293 project, no activation
+            x = y + x if (stride == 1 and in_c == cout) else y                 # :303-306 (StochasticDepth = identity in eval)
+        out_last = cout
+    x = _effnet_cna(p, f"features.{len(EFFNET_STAGES) + 1}", x, 1, 1, True, eps)   # :387-397 1x1 -> 4 * out_last
+    x = F.adaptive_avg_pool2d(x, 1).flatten(1)                                # :428-429
+    return linear(p, "classifier.1", x)                                       # :430 (Dropout = identity)
 
 
 def predict(logits):

@@ -88,6 +88,10 @@ def zeros(shape, dtype=torch.float32, device=None):
     return torch.zeros(tuple(shape), dtype=dtype)
 
 
+def ones(shape, dtype=torch.float32, device=None):
+    return torch.ones(tuple(shape), dtype=dtype)
+
+
 def ones_like(x):
     return torch.ones_like(x)
 

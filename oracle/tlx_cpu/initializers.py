@@ -36,8 +36,16 @@ class random_uniform:
         return torch.rand(tuple(shape), generator=_g) * (self.maxval - self.minval) + self.minval
 
 
+class he_normal:
+    def __init__(self, a=0, mode="fan_in", nonlinearity="leaky_relu", seed=None):
+        pass
+
+    def __call__(self, shape, dtype=None):
+        return torch.randn(tuple(shape), generator=_g) * 0.05
+
+
 def str_to_init(s):
     if callable(s):
         return s
     return {"zeros": Constant(0.0), "ones": Constant(1.0), "constant": Constant(0.0), None: Constant(0.0),
-            "truncated_normal": TruncatedNormal(stddev=0.02), "xavier_uniform": xavier_uniform()}[s]
+            "truncated_normal": TruncatedNormal(stddev=0.02), "xavier_uniform": xavier_uniform(), "he_normal": he_normal()}[s]

@@ -128,23 +128,48 @@ def _back(y, data_format):
 
 
 class GroupConv2d(Module):
+    """padding='SAME' follows TensorLayerX's torch backend [TLX-recalled]: TensorFlow's rule — total padding
+    max(0, (ceil(in/stride) - 1) * stride + dilation * (k - 1) + 1 - in), the odd unit on the bottom / right — which for
+    odd kernels at stride 1 is the symmetric (k - 1) // 2.  in_channels=None defers the filter to the first call
+    (efficientnet.py:92-125 builds every layer that way and runs one forward at construction, :433-441)."""
+
     def __init__(self, out_channels=32, kernel_size=(1, 1), stride=(1, 1), n_group=1, act=None, padding="SAME",
                  data_format="channels_last", dilation=(1, 1), W_init="truncated_normal", b_init="constant",
                  in_channels=None, name=None):
         super().__init__(name=name)
         self.kernel_size, self.stride, self.dilation = _tup2(kernel_size), _tup2(stride), _tup2(dilation)
         self.n_group, self.data_format, self.act = n_group, data_format, str_to_act(act)
+        self.out_channels = out_channels
+        self.same = False
         if isinstance(padding, str):
-            self.padding = (0, 0) if padding.upper() == "VALID" else tuple(
-                d * (k - 1) // 2 for k, d in zip(self.kernel_size, self.dilation))
+            self.same = padding.upper() == "SAME"
+            self.padding = (0, 0)
         else:
             self.padding = _tup2(padding)
-        self.filters = Parameter(str_to_init(W_init)(shape=(out_channels, in_channels // n_group) + self.kernel_size))
-        self.biases = None if _falsy_bias(b_init) else Parameter(torch.zeros(out_channels))
+        self._w_init, self._has_bias = W_init, not _falsy_bias(b_init)
+        self.filters = self.biases = None
+        if in_channels is not None:
+            self._build(in_channels)
+
+    def _build(self, in_channels):
+        self.filters = Parameter(str_to_init(self._w_init)(shape=(self.out_channels, in_channels // self.n_group) + self.kernel_size))
+        self.biases = Parameter(torch.zeros(self.out_channels)) if self._has_bias else None
 
     def forward(self, x):
-        y = F.conv2d(_nchw(x, self.data_format), self.filters, self.biases, self.stride, self.padding, self.dilation,
-                     self.n_group)
+        x = _nchw(x, self.data_format)
+        if self.filters is None:
+            self._build(x.shape[1])
+        pad = self.padding
+        if self.same:
+            lo = []
+            hi = []
+            for i, k, s_, d in zip(x.shape[2:], self.kernel_size, self.stride, self.dilation):
+                total = max(0, (-(-i // s_) - 1) * s_ + d * (k - 1) + 1 - i)
+                lo.append(total // 2)
+                hi.append(total - total // 2)
+            x = F.pad(x, (lo[1], hi[1], lo[0], hi[0]))
+            pad = (0, 0)
+        y = F.conv2d(x, self.filters, self.biases, self.stride, pad, self.dilation, self.n_group)
         y = _back(y, self.data_format)
         return self.act(y) if self.act is not None else y
 
@@ -163,16 +188,26 @@ class BatchNorm2d(Module):
                  name=None):
         super().__init__(name=name)
         self.epsilon, self.data_format, self.act = epsilon, data_format, str_to_act(act)
+        self._inits = (gamma_init, beta_init, moving_mean_init, moving_var_init)
+        self.gamma = None
+        if num_features is not None:
+            self._build(num_features)
+
+    def _build(self, num_features):
         n = (num_features,)
-        self.gamma = Parameter(str_to_init(gamma_init)(shape=n))
-        self.beta = Parameter(str_to_init(beta_init)(shape=n))
-        self.register_buffer("moving_mean", str_to_init(moving_mean_init)(shape=n))
-        self.register_buffer("moving_var", str_to_init(moving_var_init)(shape=n))
+        gi, bi, mi, vi = self._inits
+        self.gamma = Parameter(str_to_init(gi)(shape=n))
+        self.beta = Parameter(str_to_init(bi)(shape=n))
+        self.register_buffer("moving_mean", str_to_init(mi)(shape=n))
+        self.register_buffer("moving_var", str_to_init(vi)(shape=n))
 
     def forward(self, x):
+        xn = _nchw(x, self.data_format)
+        if self.gamma is None:          # deferred build (efficientnet.py:433-441): shapes only, the values are never used
+            self._build(xn.shape[1])
+            return x
         assert not self.is_train, "oracle stand-in is eval-only: call set_eval()"
-        y = F.batch_norm(_nchw(x, self.data_format), self.moving_mean, self.moving_var, self.gamma, self.beta, False,
-                         0.0, self.epsilon)
+        y = F.batch_norm(xn, self.moving_mean, self.moving_var, self.gamma, self.beta, False, 0.0, self.epsilon)
         y = _back(y, self.data_format)
         return self.act(y) if self.act is not None else y
 
@@ -197,11 +232,19 @@ class Linear(Module):
     def __init__(self, out_features=None, act=None, W_init="truncated_normal", b_init="constant", in_features=None,
                  name=None):
         super().__init__(name=name)
-        self.act = act
-        self.weights = Parameter(str_to_init(W_init)(shape=(in_features, out_features)))
-        self.biases = None if _falsy_bias(b_init) else Parameter(torch.zeros(out_features))
+        self.act = str_to_act(act)
+        self.out_features, self._w_init, self._has_bias = out_features, W_init, not _falsy_bias(b_init)
+        self.weights = self.biases = None
+        if in_features is not None:
+            self._build(in_features)
+
+    def _build(self, in_features):
+        self.weights = Parameter(str_to_init(self._w_init)(shape=(in_features, self.out_features)))
+        self.biases = Parameter(torch.zeros(self.out_features)) if self._has_bias else None
 
     def forward(self, x):
+        if self.weights is None:
+            self._build(x.shape[-1])
         y = torch.matmul(x, self.weights)
         if self.biases is not None:
             y = y + self.biases
@@ -247,6 +290,11 @@ class Dropout(Module):
 
     def forward(self, x):
         return x
+
+
+class Flatten(Module):
+    def forward(self, x):
+        return x.reshape(x.shape[0], -1)
 
 
 class _A(Module):
