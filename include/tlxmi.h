@@ -117,8 +117,10 @@ typedef struct tlxmi_conv2d_desc {
     int32_t Cout;            /* true output channels */
     int32_t R, S;            /* filter height, width */
     int32_t stride_h, stride_w, pad_h, pad_w, dil_h, dil_w;
-    int32_t Ho, Wo;          /* output extent: at most the full-correlation extent of (H,W,pad,R,S,stride,dil);
-                              * smaller values crop (asymmetric padding of the space-to-depth stem) */
+    int32_t Ho, Wo;          /* output extent.  Below the full-correlation extent of (H,W,pad,R,S,stride,dil) it crops
+                              * (asymmetric padding of the space-to-depth stem); above it, the last windows run past the
+                              * bottom / right edge and read zeros (one-sided end padding: padding='SAME' at stride 2,
+                              * efficientnet.py:92-125); every window must start inside the image or its leading pad */
     int32_t x_ld, y_ld, res_ld; /* pixel strides in elements (x_ld >= C, y_ld >= Cout) */
     int32_t y_nstride;       /* elements between images of y; 0 = dense (Ho*Wo*y_ld).  Lets the   */
     int32_t res_nstride;     /* patch-embed conv write rows 1.. of a [B][1+P][D] token matrix     */

@@ -320,3 +320,33 @@ def test_conv3x3_image_axis_tail_split(dev):
     """270 tiles of 256 x 128 on 256 CUs: the dispatcher keeps 83 images on the antiphase kernel and runs the last 5 as
     a convolution of their own on small tiles; the seam (an image boundary) must be invisible.  Residual + ReLU."""
     run_case(dev, torch.float16, 88, 128, 128, 3, 1, 1, 28, 28, act=1, with_res=True, seed=37)
+
+
+# ---- padding='SAME' at stride 2 (efficientnet.py:92-125): TensorFlow's rule puts the odd unit of padding at the bottom /
+# right, i.e. the last windows run past the edge (one-sided end padding of tlxmi_conv2d / tlxmi_dwconv2d)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["fp32", "fp16"])
+@pytest.mark.parametrize("cfg", [(2, 8, 32, 3, 2, 1, 24, 24), (1, 16, 24, 3, 2, 1, 17, 31), (1, 96, 96, 3, 2, 96, 28, 28),
+                                 (2, 144, 144, 5, 2, 144, 14, 14), (1, 40, 40, 5, 2, 40, 15, 9), (1, 64, 64, 3, 1, 64, 12, 12),
+                                 (1, 32, 64, 2, 1, 1, 9, 9), (1, 24, 24, 4, 2, 1, 10, 10)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_same_padding_one_sided(dev, dtype, cfg):
+    import tlxcv_amd
+    from tlxcv_amd.tlx import nn
+    N, Cin, Cout, k, stride, groups, H, W = cfg
+    tlxcv_amd.set_precision("fp32" if dtype == torch.float32 else "fp16")
+    try:
+        rng = np.random.default_rng(43)
+        conv = nn.GroupConv2d(Cout, (k, k), (stride, stride), groups, None, "SAME", in_channels=Cin, data_format="channels_first")
+        w, bias = rnd(rng, (Cout, Cin // groups, k, k), (2.0 / (Cin // groups * k * k)) ** 0.5), rnd(rng, (Cout,), 0.1)
+        x = rnd(rng, (N, Cin, H, W))
+        if dtype == torch.float16:
+            w, x = q16(w), q16(x)
+        conv.load_dict({"filters": w, "biases": bias})
+        conv = conv.to(dev).set_eval()
+        want = torch.nn.functional.conv2d(OF.same_pad(x, k, stride), w, bias, stride, 0, 1, groups)
+        got = conv.run_nhwc(nchw_to_engine(x, dtype, dev))
+        torch.cuda.synchronize()
+        assert got.shape[1:3] == (-(-H // stride), -(-W // stride))
+        torch.testing.assert_close(engine_to_nchw(got), want, **tol(dtype))
+    finally:
+        tlxcv_amd.set_precision("fp16")

@@ -137,6 +137,44 @@ def test_resnext_fp16_tracks_golden(dev, fp16_mode, fname):
     assert (y.argmax(1)[safe] == g["argmax"][safe]).all()
 
 
+# EfficientNet: fixtures from the reference's own efficientnet.py; 'SAME' padding at stride 2 is the
+# one-sided end padding of tlxmi_conv2d / tlxmi_dwconv2d, squeeze widths 4 / 6 / 10 go through zero-padded buffers
+EFFNET = ["efficientnet_b0_b2.npz", "efficientnet_b2_b1.npz"]
+
+
+def _effnet(g, dev):
+    from tlxcv_amd import models
+    m = models.efficientnet(str(g["arch"]))
+    m.load_dict(seeded.fill(seeded.shapes_of(m), int(g["weight_seed"])))
+    x = torch.from_numpy(seeded.image_batch(int(g["batch"]), int(g["input_seed"]), int(g["hw"]))).to(dev)
+    return m.to(dev).set_eval(), x
+
+
+@pytest.mark.parametrize("fname", EFFNET, ids=[f[:-4] for f in EFFNET])
+def test_efficientnet_fp32_matches_golden_1e4_and_argmax_exact(dev, fp32_mode, fname):
+    g = np.load(os.path.join(GOLDEN, fname))
+    m, x = _effnet(g, dev)
+    y = m(x)
+    ref = g["logits"]
+    err = np.abs(y.cpu().numpy() - ref).max()
+    assert err <= 1e-4 * max(1.0, np.abs(ref).max()), err
+    from tlxcv_amd.tasks import ImageClassification
+    assert (ImageClassification(m).predict(x).cpu().numpy() == g["argmax"]).all()
+
+
+@pytest.mark.parametrize("fname", EFFNET, ids=[f[:-4] for f in EFFNET])
+def test_efficientnet_fp16_tracks_golden(dev, fp16_mode, fname):
+    g = np.load(os.path.join(GOLDEN, fname))
+    m, x = _effnet(g, dev)
+    y = m(x).float().cpu().numpy()
+    ref = g["logits"]
+    err = np.abs(y - ref).max()
+    assert err <= 0.02 * (ref.max() - ref.min()), err
+    s = np.sort(ref, axis=1)
+    safe = (s[:, -1] - s[:, -2]) > 2 * err
+    assert (y.argmax(1)[safe] == g["argmax"][safe]).all()
+
+
 def _close(got, ref, dtype):
     got = got.float().cpu().numpy()
     scale = np.abs(ref).max()

@@ -103,6 +103,23 @@ def test_resnext_restatement_reproduces_golden_and_parameter_tree_matches_the_re
         assert np.abs(y.numpy() - g["logits"]).max() <= 1e-3 and (y.argmax(-1).numpy() == g["argmax"]).all()
 
 
+def test_efficientnet_restatement_reproduces_golden_and_parameter_tree_matches_the_reference():
+    """Fixtures written by the reference's own efficientnet.py, which creates its weights by a forward of ones at
+    construction (:433-441); the engine-side constructor derives the same tree from the MBConvConfig arithmetic."""
+    from tlxcv_amd import models
+    for fname in ("efficientnet_b0_b2.npz", "efficientnet_b2_b1.npz"):
+        g = np.load(os.path.join(GOLDEN, fname))
+        m = models.efficientnet(str(g["arch"]))
+        shapes = seeded.shapes_of(m)
+        assert list(shapes.keys()) == [str(n) for n in g["param_names"]]
+        p = {k: torch.from_numpy(v) for k, v in seeded.fill(shapes, int(g["weight_seed"])).items()}
+        x = torch.from_numpy(seeded.image_batch(int(g["batch"]), int(g["input_seed"]), int(g["hw"])))
+        with torch.no_grad():
+            y = OF.efficientnet(p, x, str(g["arch"]))
+        assert str(g["pinned_by"]) == "reference-file-on-tlx_cpu"
+        assert np.abs(y.numpy() - g["logits"]).max() <= 1e-4 and (y.argmax(-1).numpy() == g["argmax"]).all()
+
+
 def test_swin_helpers_against_their_definitions():
     """The restated index / mask helpers checked against independent brute-force definitions."""
     ws = 7

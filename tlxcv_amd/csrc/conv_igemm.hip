@@ -65,6 +65,7 @@ struct ConvArgs {
     int nchunk;
     int gx, gy, gres, gc;       // per-chunk byte offsets into x / y / res pixels, channel offset of scale / shift
     unsigned gw;                // bytes between the packed filters of consecutive chunks
+    int overhang;               // 1: some windows run past the bottom / right edge (implicit GEMM gather only)
     int diag;                   // 1: 64 -> 64 channel chunks whose filter is block-diagonal at 32 channels (fp16): the wave
                                 // that owns output channels 32c..32c+31 needs only the K half 32c..32c+31 of every tap
 };
@@ -578,7 +579,7 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
         const int PB = a.C * 2;
         int forced_h = -1;
         { const char* e = getenv("TLXMI_HALO"); if (e && *e) forced_h = atoi(e); }   // 0: off (A/B runs)
-        if (forced_h != 0 && a.nchunk == 1 && a.sh == 1 && a.sw == 1 && a.dh == 1 && a.dw == 1 && (a.R > 1 || a.S > 1) && conv_halo_tile_pixels(a.R, a.S, PB) > 0 &&
+        if (forced_h != 0 && a.nchunk == 1 && !a.overhang && a.sh == 1 && a.sw == 1 && a.dh == 1 && a.dw == 1 && (a.R > 1 || a.S > 1) && conv_halo_tile_pixels(a.R, a.S, PB) > 0 &&
             conv_halo_act_ok(a.act) && !a.strided_n && a.vec_io && a.Cout % 8 == 0 && a.Cout <= 128 && a.y_bytes != 0 &&
             a.HoWo >= 1024 && (!a.res || (long long)a.M * a.res_ld * 2 < (1ll << 31))) {
             HaloArgs h;
@@ -626,7 +627,7 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
     // (also the strided 1x1 projection shortcuts, resnet.py:246-261: one "tap", rows gathered at stride 2)
     const bool strided1x1 = a.R == 1 && a.S == 1 && a.ph == 0 && a.pw == 0 && (a.sh > 1 || a.sw > 1);
     const bool as_conv = !(a.R == 1 && a.S == 1 && a.ph == 0 && a.pw == 0 && a.sh == 1 && a.sw == 1);   // needs the gather of CONV mode
-    const bool pp_conv128_ok = a.nchunk == 1 && ((a.S == 3 && a.R <= 3) || strided1x1) && a.dh == 1 && a.dw == 1 && !a.strided_n &&
+    const bool pp_conv128_ok = a.nchunk == 1 && !a.overhang && ((a.S == 3 && a.R <= 3) || strided1x1) && a.dh == 1 && a.dw == 1 && !a.strided_n &&
                                a.vec_io && a.Cout % 8 == 0 && a.Cout >= 128 && a.y_bytes != 0 && a.cpt % 8 == 0 && (tpk & (tpk - 1)) == 0 &&
                                (!a.res || (long long)a.M * a.res_ld * (long long)sizeof(T) < (1ll << 31));
     const bool pp_conv_ok = pp_conv128_ok && a.Cout >= 256;
@@ -820,8 +821,13 @@ static int conv2d_impl(const tlxmi_conv2d_desc* d, int nchunk, const void* x, co
     TLXMI_REQUIRE(d->y_ld >= d->Cout, TLXMI_ERR_BAD_ARG, "conv2d: y_ld=%d < Cout=%d", d->y_ld, d->Cout);
     const int Ho = (d->H + 2 * d->pad_h - d->dil_h * (d->R - 1) - 1) / d->stride_h + 1;
     const int Wo = (d->W + 2 * d->pad_w - d->dil_w * (d->S - 1) - 1) / d->stride_w + 1;
-    TLXMI_REQUIRE(d->Ho > 0 && d->Wo > 0 && d->Ho <= Ho && d->Wo <= Wo, TLXMI_ERR_BAD_ARG,
-                  "conv2d: output extent %dx%d exceeds the correlation extent %dx%d", d->Ho, d->Wo, Ho, Wo);
+    // Ho / Wo below the full-correlation extent crop; above it, the last windows run past the bottom / right edge and read
+    // zeros there (one-sided end padding: TensorFlow-style 'SAME' at stride 2, efficientnet.py:92-125) — allowed as long
+    // as every window starts inside the image or its leading padding.
+    const int Ho_max = (d->H - 1 + d->pad_h) / d->stride_h + 1, Wo_max = (d->W - 1 + d->pad_w) / d->stride_w + 1;
+    TLXMI_REQUIRE(d->Ho > 0 && d->Wo > 0 && d->Ho <= Ho_max && d->Wo <= Wo_max, TLXMI_ERR_BAD_ARG,
+                  "conv2d: output extent %dx%d exceeds %dx%d (windows must start inside the padded image)", d->Ho, d->Wo, Ho_max, Wo_max);
+    const bool overhang = d->Ho > Ho || d->Wo > Wo;
     TLXMI_REQUIRE(d->act >= TLXMI_ACT_NONE && d->act <= TLXMI_ACT_SILU, TLXMI_ERR_BAD_ARG, "conv2d: bad act %d", d->act);
     TLXMI_REQUIRE(!res || d->res_ld >= d->Cout, TLXMI_ERR_BAD_ARG, "conv2d: res_ld=%d < Cout", d->res_ld);
     const long long M = (long long)d->N * d->Ho * d->Wo;
@@ -860,6 +866,7 @@ static int conv2d_impl(const tlxmi_conv2d_desc* d, int nchunk, const void* x, co
     a.gc = nchunk > 1 ? cw_out : 0;
     a.gw = nchunk > 1 ? a.w_bytes : 0u;
     a.diag = diag32 && es == 2 && cw_in == 64 && cw_out == 64 ? 1 : 0;
+    a.overhang = overhang ? 1 : 0;
     const int vecn = 16 / es;  // elements per 16 bytes
     const bool bcast = res && (d->flags & TLXMI_EPI_RES_BCAST_N);
     TLXMI_REQUIRE(d->y_nstride >= 0 && d->res_nstride >= 0, TLXMI_ERR_BAD_ARG, "conv2d: negative batch stride");

@@ -584,9 +584,13 @@ extern "C" int tlxmi_dwconv2d(const tlxmi_dwconv2d_desc* d, const void* x, const
                   TLXMI_ERR_BAD_ARG, "dwconv2d: bad extent");
     const int Ho = (d->H + 2 * d->pad_h - d->dil_h * (d->R - 1) - 1) / d->stride_h + 1;
     const int Wo = (d->W + 2 * d->pad_w - d->dil_w * (d->S - 1) - 1) / d->stride_w + 1;
-    TLXMI_REQUIRE(Ho == d->Ho && Wo == d->Wo && Ho > 0 && Wo > 0, TLXMI_ERR_BAD_ARG, "dwconv2d: output extent mismatch");
+    // the full-correlation extent, or more: windows past the bottom / right edge read zeros (one-sided end padding, as
+    // tlxmi_conv2d), as long as every window starts inside the image or its leading padding
+    const int Ho_max = (d->H - 1 + d->pad_h) / d->stride_h + 1, Wo_max = (d->W - 1 + d->pad_w) / d->stride_w + 1;
+    TLXMI_REQUIRE(Ho > 0 && Wo > 0 && d->Ho >= Ho && d->Wo >= Wo && d->Ho <= Ho_max && d->Wo <= Wo_max, TLXMI_ERR_BAD_ARG,
+                  "dwconv2d: output extent %dx%d outside [%dx%d, %dx%d]", d->Ho, d->Wo, Ho, Wo, Ho_max, Wo_max);
     TLXMI_REQUIRE(d->act >= TLXMI_ACT_NONE && d->act <= TLXMI_ACT_SILU, TLXMI_ERR_BAD_ARG, "dwconv2d: bad act");
-    const long work = (long)d->N * Ho * Wo * (d->C / VECN(d->dtype));
+    const long work = (long)d->N * d->Ho * d->Wo * (d->C / VECN(d->dtype));
     dim3 g(grid_for(work)), b(256);
     if (d->dtype == TLXMI_F16)
         hipLaunchKernelGGL((dwconv_kernel<half_t>), g, b, 0, as_stream(stream), (const half_t*)x, (const half_t*)w, scale, shift, (half_t*)y, *d);

@@ -214,7 +214,7 @@ def _pair(v):
 
 def conv2d(x, pk, stride=1, padding=0, dilation=1, scale=None, shift=None, res=None, act=ACT_NONE,
            act_param=0.0, res_after_act=False, out=None, out_ld=None, y_nstride=0, res_nstride=0,
-           res_bcast=False, res_ld=None, out_hw=None):
+           res_bcast=False, res_ld=None, out_hw=None, overhang=False):
     """x (N,H,W,C>=Cin_pad...) NHWC -> y (N,Ho,Wo,Cout).  `out` may be a wider/pre-offset buffer."""
     need_gpu(x, "input")
     N, H, W, ld = x.shape
@@ -229,8 +229,8 @@ def conv2d(x, pk, stride=1, padding=0, dilation=1, scale=None, shift=None, res=N
     Wo = (W + 2 * pw - dw * (pk.S - 1) - 1) // sw + 1
     if Ho <= 0 or Wo <= 0:
         raise RuntimeError(f"conv2d: empty output {Ho}x{Wo} for input {H}x{W}")
-    if out_hw is not None:      # crop (asymmetric padding of a space-to-depth stem)
-        Ho, Wo = min(Ho, out_hw[0]), min(Wo, out_hw[1])
+    if out_hw is not None:      # crop (asymmetric padding of a space-to-depth stem), or one-sided end padding ('SAME' at stride 2)
+        Ho, Wo = (int(out_hw[0]), int(out_hw[1])) if overhang else (min(Ho, out_hw[0]), min(Wo, out_hw[1]))
     if out is None:
         out = torch.empty((N, Ho, Wo, pk.Cout), dtype=x.dtype, device=x.device)
         out_ld = pk.Cout
@@ -382,7 +382,7 @@ def linear_ln(x, prep, eps, act=ACT_NONE):
     return y
 
 
-def dwconv2d(x, w_rsc, stride=1, padding=0, dilation=1, scale=None, shift=None, act=ACT_NONE, act_param=0.0):
+def dwconv2d(x, w_rsc, stride=1, padding=0, dilation=1, scale=None, shift=None, act=ACT_NONE, act_param=0.0, out_hw=None):
     need_gpu(x, "input")
     N, H, W, Cc = x.shape
     R, S, Cw = w_rsc.shape
@@ -391,6 +391,8 @@ def dwconv2d(x, w_rsc, stride=1, padding=0, dilation=1, scale=None, shift=None, 
     dh, dw = _pair(dilation)
     Ho = (H + 2 * ph - dh * (R - 1) - 1) // sh + 1
     Wo = (W + 2 * pw - dw * (S - 1) - 1) // sw + 1
+    if out_hw is not None:      # one-sided end padding ('SAME' at stride 2): the last windows read zeros past the edge
+        Ho, Wo = int(out_hw[0]), int(out_hw[1])
     y = torch.empty((N, Ho, Wo, Cc), dtype=x.dtype, device=x.device)
     d = _lib.DwConvDesc(dtype=dt_code(x.dtype), N=N, H=H, W=W, C=Cw, R=R, S=S, stride_h=sh, stride_w=sw, pad_h=ph,
                         pad_w=pw, dil_h=dh, dil_w=dw, Ho=Ho, Wo=Wo, x_ld=Cc, y_ld=Cc, act=act,

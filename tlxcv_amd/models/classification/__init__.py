@@ -13,3 +13,4 @@ from .vgg import VGG, vgg11, vgg13, vgg16, vgg19  # noqa: F401
 from .alexnet import AlexNet, alexnet  # noqa: F401
 from .resnext import (ResNeXt, resnext50_32x4d, resnext50_64x4d, resnext101_32x4d, resnext101_64x4d,  # noqa: F401
                       resnext152_32x4d, resnext152_64x4d)
+from .efficientnet import efficientnet, EfficientNet  # noqa: F401

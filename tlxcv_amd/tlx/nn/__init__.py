@@ -362,11 +362,17 @@ class GroupConv2d(Module):
         self.n_group = int(n_group)
         if self.in_channels % self.n_group or self.out_channels % self.n_group:
             raise ValueError("The number of input/output channels must be divisible by n_group")
+        self.same = False
         if isinstance(padding, str):
             p = padding.upper()
             if p == "VALID":
                 self.padding = (0, 0)
             elif p == "SAME":
+                # TensorFlow's rule [TLX-recalled: conv2d_same_padding of the torch backend]: total padding
+                # max(0, (ceil(in / s) - 1) * s + d * (k - 1) + 1 - in), the odd unit at the bottom / right.  For odd
+                # kernels at stride 1 that is the symmetric value stored here; other cases are resolved per input
+                # size in _same() (efficientnet.py:92-125: 'SAME' at stride 2).
+                self.same = True
                 self.padding = tuple(d * (k - 1) // 2 for k, d in zip(self.kernel_size, self.dilation))
             else:
                 raise ValueError(f"unsupported padding {padding!r}")
@@ -383,10 +389,28 @@ class GroupConv2d(Module):
             bi = str_to_init(b_init) if isinstance(b_init, str) else (b_init if callable(b_init) else Constant(0.0))
             self.biases = Parameter(data=bi(shape=(self.out_channels,)))
 
+    def _same(self, H, W):
+        """padding='SAME' for this input size -> (leading padding, output extent or None when the symmetric form is exact)."""
+        lead, out, odd = [], [], False
+        for i, k, s_, d in zip((H, W), self.kernel_size, self.stride, self.dilation):
+            o = -(-i // s_)
+            total = max(0, (o - 1) * s_ + d * (k - 1) + 1 - i)
+            lead.append(total // 2)
+            out.append(o)
+            odd = odd or (total % 2 == 1)
+        return tuple(lead), (tuple(out) if odd else None)
+
     # fused entry point used by the model graphs: conv (+bn) (+act) (+residual) in one launch
     def run_nhwc(self, x, bn=None, act=E.ACT_NONE, act_param=0.0, res=None, res_after_act=False, **kw):
         self._require_eval()
         dt = E.precision()
+        padding = self.padding
+        if self.same:
+            padding, out_hw = self._same(x.shape[1], x.shape[2])
+            if out_hw is not None:
+                kw = dict(kw, out_hw=out_hw)
+                if self.n_group == 1 or self.n_group != self.in_channels:
+                    kw["overhang"] = True
         if self.n_group == 1:
             pk = self._cached("pk", lambda: E.PackedFilter(self.filters, dt))
         elif self.n_group == self.in_channels == self.out_channels:
@@ -398,14 +422,16 @@ class GroupConv2d(Module):
         else:
             scale, shift = None, (self._cached("bias", lambda: E._f32(self.biases)) if self.biases is not None else None)
         if self.n_group == 1:
-            return E.conv2d(x, pk, self.stride, self.padding, self.dilation, scale, shift, res, act, act_param,
+            return E.conv2d(x, pk, self.stride, padding, self.dilation, scale, shift, res, act, act_param,
                             res_after_act, **kw)
         if isinstance(pk, E.PackedGroupFilter):
-            return E.group_conv2d(x, pk, self.stride, self.padding, self.dilation, scale, shift, res, act, act_param,
+            if kw.get("out_hw") is not None:
+                raise NotImplementedError("grouped conv with one-sided 'SAME' padding")
+            return E.group_conv2d(x, pk, self.stride, padding, self.dilation, scale, shift, res, act, act_param,
                                   res_after_act)
         if res is not None:
             raise NotImplementedError("depthwise conv with fused residual")
-        return E.dwconv2d(x, pk, self.stride, self.padding, self.dilation, scale, shift, act, act_param)
+        return E.dwconv2d(x, pk, self.stride, padding, self.dilation, scale, shift, act, act_param, out_hw=kw.get("out_hw"))
 
     def run_stem(self, x_nchw, b, bn=None, act=E.ACT_NONE, act_param=0.0, **kw):
         """Few-channel first conv (RGB stem / patch embedding) on a b x b space-to-depth input: the 3-channel
