@@ -246,6 +246,74 @@ def efficientnet(p, x, arch="efficientnet_b0"):
     return linear(p, "classifier.1", x)                                       # :430 (Dropout = identity)
 
 
+# ---------------------------------------------------------------------------------------------
+# ResNeSt — models/classification/resnest.py
+# ---------------------------------------------------------------------------------------------
+RESNEST_ARCH = {   # resnest.py:692-735: layers, radix, groups, stem_width, avd_first  (deep_stem, avd, avg_down always on)
+    "resnest50_fast_1s1x64d": ([3, 4, 6, 3], 1, 1, 32, True),
+    "resnest50": ([3, 4, 6, 3], 2, 1, 32, False),
+    "resnest101": ([3, 4, 23, 3], 2, 1, 64, False),
+}
+
+
+def _rs_convbn(p, pre, x, stride=1, groups=1, relu=False):
+    """ConvBNLayer.forward resnest.py:48-51 (padding (k-1)//2 :32, no bias :35, BatchNorm(act) :39-45)."""
+    k = _t(p, pre + "._conv.filters").shape[-1]
+    y = bn(p, pre + ".batch_norm", conv(p, pre + "._conv", x, stride, (k - 1) // 2, 1, groups))
+    return F.relu(y) if relu else y
+
+
+def _rs_splat(p, pre, x, radix, cardinality):
+    """SplatConv.forward resnest.py:147-166; rSoftmax.forward :65-81."""
+    x = _rs_convbn(p, pre + ".conv1", x, 1, cardinality * radix, True)        # :148  3x3, groups = cardinality * radix
+    B, rc = x.shape[0], x.shape[1]
+    if radix > 1:
+        splited = torch.chunk(x, radix, dim=1)                                # :150-151
+        gap = sum(splited[1:], splited[0])                                    # :152
+    else:
+        gap = x
+    gap = F.adaptive_avg_pool2d(gap, 1)                                       # :155
+    gap = _rs_convbn(p, pre + ".conv2", gap, 1, cardinality, True)            # :156  1x1, groups = cardinality
+    att = conv(p, pre + ".conv3", gap, 1, 0, 1, cardinality)                  # :157  1x1, no bias, no norm
+    if radix > 1:                                                             # rSoftmax :69-78
+        att = att.reshape(B, cardinality, radix, rc // cardinality // radix).transpose(1, 2)
+        att = torch.softmax(att, dim=1).reshape(B, rc, 1, 1)
+        attens = torch.chunk(att, radix, dim=1)                               # :160-161
+        return sum(a * s_ for a, s_ in zip(attens, splited))                  # :162-163
+    return x * torch.sigmoid(att)                                             # :80, :165
+
+
+def resnest(p, x, arch="resnest50"):
+    """ResNeSt.forward resnest.py:679-689; BottleneckBlock.forward :311-328; ResNeStLayer :331-438."""
+    layers, radix, card, stem_width, avd_first = RESNEST_ARCH[arch]
+    x = _rs_convbn(p, "stem.conv1", x, 2, 1, True)                            # :479-513 deep stem: 3x3/2, 3x3, 3x3
+    x = _rs_convbn(p, "stem.conv2", x, 1, 1, True)
+    x = _rs_convbn(p, "stem.conv3", x, 1, 1, True)
+    x = F.max_pool2d(x, 3, 2, 1)                                              # :527-532
+    inplanes = stem_width * 2
+    for li, (planes, n) in enumerate(zip((64, 128, 256, 512), layers), start=1):
+        for bi in range(n):
+            pre = f"layer{li}.layer{li}_bottleneck_{bi}"
+            stride = 2 if (bi == 0 and li > 1) else 1                          # :533-676 (no dilation in these archs)
+            is_first = li > 1 and bi == 0                                      # layer1 passes is_first=False :545; default True :347
+            pool = stride > 1 or is_first                                      # avd pooling condition :313, :316
+            short = x
+            y = _rs_convbn(p, pre + ".conv1", x, 1, 1, True)                   # :312
+            if avd_first and pool:
+                y = F.avg_pool2d(y, 3, stride, 1)                              # :313-314 (zero padding counts in the mean)
+            y = _rs_splat(p, pre + ".conv2", y, radix, card)                   # :315 (radix >= 1 -> SplatConv :219-233)
+            if (not avd_first) and pool:
+                y = F.avg_pool2d(y, 3, stride, 1)                              # :316-317
+            y = _rs_convbn(p, pre + ".conv3", y)                               # :318
+            if stride != 1 or inplanes != planes * 4:                          # :319-323 avg_down shortcut
+                short = F.avg_pool2d(short, stride, stride, 0)                 # :271-277 (kernel = stride)
+                short = bn(p, pre + ".batch_norm", conv(p, pre + ".conv4", short, 1, 0))
+            x = F.relu(short + y)                                              # :324-326
+            inplanes = planes * 4
+    x = F.adaptive_avg_pool2d(x, 1).reshape(x.shape[0], -1)                   # :686-687
+    return linear(p, "out", x)                                                # :688
+
+
 def predict(logits):
     """ImageClassification.predict, tasks/image_classification.py:20-23."""
     return torch.argmax(logits, dim=-1)

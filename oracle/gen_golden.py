@@ -172,6 +172,25 @@ def gen_efficientnet(arch, batch, hw, wseed, xseed, fname):
         param_names=np.array(list(shapes.keys())), torch_version=torch.__version__)
 
 
+def gen_resnest(arch, batch, hw, wseed, xseed, fname):
+    ref = import_reference("tlxcv/models/classification/resnest.py", "ref_resnest")
+    model = getattr(ref, arch)()
+    shapes = seeded.shapes_of(model)
+    params = seeded.fill(shapes, wseed)
+    model.load_dict(params)
+    model.set_eval()
+    x = torch.from_numpy(seeded.image_batch(batch, xseed, hw))
+    with torch.no_grad():
+        ref_out = model(x)
+        re_out = OF.resnest({k: torch.from_numpy(v) for k, v in params.items()}, x, arch)
+    d = _check(arch, ref_out, re_out)
+    np.savez_compressed(
+        os.path.join(OUT, fname), arch=arch, weight_seed=wseed, input_seed=xseed, batch=batch, hw=hw,
+        logits=ref_out.numpy().astype(np.float32), argmax=ref_out.argmax(-1).numpy().astype(np.int64),
+        restatement_max_abs_diff=np.float64(d), pinned_by="reference-file-on-tlx_cpu",
+        param_names=np.array(list(shapes.keys())), torch_version=torch.__version__)
+
+
 def gen_alexnet(batch, wseed, xseed, fname):
     ref = import_reference("tlxcv/models/classification/alexnet.py", "ref_alexnet")
     model = ref.alexnet()
@@ -272,6 +291,8 @@ def main():
     gen_alexnet(2, 12, 10, "alexnet_b2.npz")
     gen_resnext(50, 32, 2, 96, 13, 11, "resnext50_32x4d_b2.npz")
     gen_resnext(50, 64, 1, 64, 14, 12, "resnext50_64x4d_b1.npz")
+    gen_resnest("resnest50", 2, 96, 17, 15, "resnest50_b2.npz")
+    gen_resnest("resnest50_fast_1s1x64d", 1, 64, 18, 16, "resnest50_fast_b1.npz")     # radix 1 (sigmoid gate), avd_first
     gen_efficientnet("efficientnet_b0", 2, 224, 15, 13, "efficientnet_b0_b2.npz")
     gen_efficientnet("efficientnet_b2", 1, 130, 16, 14, "efficientnet_b2_b1.npz")     # width / depth multipliers, odd extents under 'SAME' 
     gen_darknet(1, 64, 5, 2, "darknet53_b1.npz")

@@ -72,6 +72,17 @@ def matmul(a, b, transpose_a=False, transpose_b=False):
     return torch.matmul(a, b)
 
 
+def add_n(inputs):
+    out = inputs[0]
+    for t in inputs[1:]:
+        out = out + t
+    return out
+
+
+def multiply(x, y):
+    return x * y
+
+
 def add(value, bias):
     return value + bias
 

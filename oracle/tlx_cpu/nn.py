@@ -94,6 +94,10 @@ class Identity(Module):
 class Sequential(Module):
     def __init__(self, *layers, name=None):
         super().__init__(name=name)
+        if len(layers) == 1 and isinstance(layers[0], dict):     # OrderedDict of named layers (resnest.py:479-513)
+            for k, l in layers[0].items():
+                self.add_module(k, l)
+            return
         if len(layers) == 1 and isinstance(layers[0], (list, tuple)):
             layers = layers[0]
         for i, l in enumerate(layers):
@@ -263,6 +267,23 @@ class MaxPool2d(Module):
 
     def forward(self, x):
         return _back(F.max_pool2d(_nchw(x, self.data_format), self.kernel_size, self.stride, self.padding),
+                     self.data_format)
+
+
+class AvgPool2d(Module):
+    """nn.AvgPool2d(kernel_size, stride, padding, data_format) — resnest.py:212-218, 250-256, 271-286.  Zero padding
+    counts in the divisor (torch's default, which TensorLayerX's torch backend forwards to) [TLX-recalled]."""
+
+    def __init__(self, kernel_size, stride=None, padding="SAME", ceil_mode=False, data_format="channels_last", name=None):
+        super().__init__(name=name)
+        self.kernel_size = _tup2(kernel_size)
+        self.stride = _tup2(stride if stride is not None else kernel_size)
+        self.padding = _tup2(padding) if not isinstance(padding, str) else (
+            (0, 0) if padding.upper() == "VALID" else tuple((k - 1) // 2 for k in self.kernel_size))
+        self.data_format = data_format
+
+    def forward(self, x):
+        return _back(F.avg_pool2d(_nchw(x, self.data_format), self.kernel_size, self.stride, self.padding),
                      self.data_format)
 
 

@@ -33,6 +33,9 @@ def _is_last_bn_of_block(name):
     # ResNet: bn3 of a bottleneck / bn2 of a basic block / the downsample BN feed the residual add;
     # DarkNet: the BatchNorm of BasicBlock.conv2 (darknet.py:142-153) does.
     # MobileNetV2/V3: the BatchNorm of the linear projection (mobilenetv2.py:30-33, mobilenetv3.py:107-110).
+    # ResNeSt: conv3's BatchNorm and the shortcut BatchNorm of a bottleneck (resnest.py:258-309).
+    if "_bottleneck_" in name and name.rsplit("_bottleneck_", 1)[1].split(".", 1)[1:] in (["conv3.batch_norm"], ["batch_norm"]):
+        return True
     return name.endswith(("bn3", "downsample.1", "conv2.batch_norm", "linear_conv.1")) or name.endswith(".bn2")
 
 
