@@ -176,6 +176,20 @@ int tlxmi_dwconv2d(const tlxmi_dwconv2d_desc* d, const void* x, const void* w_rs
 int tlxmi_maxpool2d(const void* x, void* y, int dtype, int N, int H, int W, int C, int x_ld, int y_ld,
                     int R, int S, int stride_h, int stride_w, int pad_h, int pad_w, int Ho, int Wo,
                     void* stream);
+/* nn.AvgPool2d(kernel, stride, padding) with zero padding counted in the divisor (always R*S): the anti-aliasing
+ * down-sampling of ResNeSt, resnest.py:212-218, 250-256 (3x3, stride s, pad 1) and :271-286 (s x s, stride s, pad 0). */
+int tlxmi_avgpool2d(const void* x, void* y, int dtype, int N, int H, int W, int C, int x_ld, int y_ld,
+                    int R, int S, int stride_h, int stride_w, int pad_h, int pad_w, int Ho, int Wo, void* stream);
+
+/* Split attention of ResNeSt's SplatConv (resnest.py:147-166; rSoftmax :53-82).  x: [N][HW][x_ld >= radix*C], split r =
+ * channels [r*C, (r+1)*C);  g: [N][g_ld >= C];  logit: [N][l_ld >= radix*C] in the channel order conv3 (:157) produces;
+ *   tlxmi_radix_gap:        g[n][c] = mean_p sum_r x[n][p][r*C + c]                               (:150-155)
+ *   tlxmi_split_attention:  y[n][p][c] = sum_r a_r(n,c) * x[n][p][r*C + c]                        (:158-165)
+ * with, for radix > 1, a_r(n,c) = softmax over r of logit[n][(k*radix + r)*cpg + c'] (c = k*cpg + c', cpg = C/cardinality:
+ * rSoftmax's reshape-transpose-softmax(axis=1)-reshape), and for radix == 1, a = sigmoid(logit[n][c]). */
+int tlxmi_radix_gap(const void* x, void* g, int dtype, int N, int HW, int C, int radix, int x_ld, int g_ld, void* stream);
+int tlxmi_split_attention(const void* x, const void* logit, void* y, int dtype, int N, int HW, int C, int radix,
+                          int cardinality, int x_ld, int l_ld, int y_ld, void* stream);
 /* y[n][c] = mean over H*W of x[n][.][.][c];  y pixel stride y_ld */
 int tlxmi_global_avgpool(const void* x, void* y, int dtype, int N, int HW, int C, int x_ld, int y_ld,
                          void* stream);

@@ -175,6 +175,43 @@ def test_efficientnet_fp16_tracks_golden(dev, fp16_mode, fname):
     assert (y.argmax(1)[safe] == g["argmax"][safe]).all()
 
 
+# ResNeSt: fixtures from the reference's own resnest.py; split attention, anti-aliasing average pools
+RESNEST = ["resnest50_b2.npz", "resnest50_fast_b1.npz"]
+
+
+def _resnest(g, dev):
+    from tlxcv_amd import models
+    m = getattr(models, str(g["arch"]))()
+    m.load_dict(seeded.fill(seeded.shapes_of(m), int(g["weight_seed"])))
+    x = torch.from_numpy(seeded.image_batch(int(g["batch"]), int(g["input_seed"]), int(g["hw"]))).to(dev)
+    return m.to(dev).set_eval(), x
+
+
+@pytest.mark.parametrize("fname", RESNEST, ids=[f[:-4] for f in RESNEST])
+def test_resnest_fp32_matches_golden_1e4_and_argmax_exact(dev, fp32_mode, fname):
+    g = np.load(os.path.join(GOLDEN, fname))
+    m, x = _resnest(g, dev)
+    y = m(x)
+    ref = g["logits"]
+    err = np.abs(y.cpu().numpy() - ref).max()
+    assert err <= 1e-4 * max(1.0, np.abs(ref).max()), err
+    from tlxcv_amd.tasks import ImageClassification
+    assert (ImageClassification(m).predict(x).cpu().numpy() == g["argmax"]).all()
+
+
+@pytest.mark.parametrize("fname", RESNEST, ids=[f[:-4] for f in RESNEST])
+def test_resnest_fp16_tracks_golden(dev, fp16_mode, fname):
+    g = np.load(os.path.join(GOLDEN, fname))
+    m, x = _resnest(g, dev)
+    y = m(x).float().cpu().numpy()
+    ref = g["logits"]
+    err = np.abs(y - ref).max()
+    assert err <= 0.02 * (ref.max() - ref.min()), err
+    s = np.sort(ref, axis=1)
+    safe = (s[:, -1] - s[:, -2]) > 2 * err
+    assert (y.argmax(1)[safe] == g["argmax"][safe]).all()
+
+
 def _close(got, ref, dtype):
     got = got.float().cpu().numpy()
     scale = np.abs(ref).max()

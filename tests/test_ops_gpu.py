@@ -245,3 +245,48 @@ def test_rgb_space_to_depth_fold(dev, shape, offset):
     assert got.shape[:3] == (N, H // 2, W // 2) and got.shape[3] >= 4 * Cc
     torch.testing.assert_close(got[..., :4 * Cc].float().cpu(), want.half().float(), atol=0, rtol=0)
     assert (got[..., 4 * Cc:] == 0).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["fp32", "fp16"])
+@pytest.mark.parametrize("cfg", [(2, 64, 14, 14, 3, 2, 1), (1, 128, 9, 15, 3, 1, 1), (2, 256, 8, 8, 2, 2, 0), (1, 32, 7, 7, 3, 2, 1)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_avgpool2d_counts_the_zero_padding(dev, dtype, cfg):
+    """nn.AvgPool2d of resnest.py:212-218, 250-256, 271-286 = F.avg_pool2d (padding included in the divisor)."""
+    N, Cc, H, W, k, s, p = cfg
+    rng = np.random.default_rng(47)
+    x = rnd(rng, (N, Cc, H, W))
+    if dtype == torch.float16:
+        x = q16(x)
+    want = torch.nn.functional.avg_pool2d(x, k, s, p)
+    got = E.avgpool2d(nchw_to_engine(x, dtype, dev), k, s, p)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(engine_to_nchw(got), want, **tol(dtype))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["fp32", "fp16"])
+@pytest.mark.parametrize("cfg", [(2, 64, 2, 1, 10, 12), (1, 128, 2, 4, 7, 7), (3, 32, 1, 1, 5, 9), (1, 64, 4, 2, 6, 6), (2, 48, 1, 3, 4, 4)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_split_attention_and_radix_gap(dev, dtype, cfg):
+    """SplatConv.forward resnest.py:149-165 after conv1, with rSoftmax :65-81 restated in torch (the oracle's _rs_splat body)."""
+    N, Cc, radix, card, H, W = cfg
+    rng = np.random.default_rng(53)
+    x = rnd(rng, (N, radix * Cc, H, W))
+    logit = rnd(rng, (N, radix * Cc), 2.0)
+    if dtype == torch.float16:
+        x, logit = q16(x), q16(logit)
+    # gap
+    splits = torch.chunk(x, radix, dim=1)
+    want_gap = sum(splits[1:], splits[0]).mean(dim=(2, 3))
+    # attention
+    if radix > 1:
+        a = logit.reshape(N, card, radix, Cc // card).transpose(1, 2)
+        a = torch.softmax(a, dim=1).reshape(N, radix * Cc, 1, 1)
+        want = sum(t * s_ for t, s_ in zip(torch.chunk(a, radix, dim=1), splits))
+    else:
+        want = x * torch.sigmoid(logit).reshape(N, Cc, 1, 1)
+    xe = nchw_to_engine(x, dtype, dev)
+    got_gap = E.radix_gap(xe, radix)
+    got = E.split_attention(xe, logit.to(dtype).to(dev), radix, card)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(got_gap.float().cpu(), want_gap, **tol(dtype))
+    torch.testing.assert_close(engine_to_nchw(got), want, **tol(dtype))

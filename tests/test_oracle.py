@@ -120,6 +120,23 @@ def test_efficientnet_restatement_reproduces_golden_and_parameter_tree_matches_t
         assert np.abs(y.numpy() - g["logits"]).max() <= 1e-4 and (y.argmax(-1).numpy() == g["argmax"]).all()
 
 
+def test_resnest_restatement_reproduces_golden_and_parameter_tree_matches_the_reference():
+    """Fixtures written by the reference's own resnest.py (radix 2 with rSoftmax; radix 1 with the sigmoid gate and
+    avd_first)."""
+    from tlxcv_amd import models
+    for fname in ("resnest50_b2.npz", "resnest50_fast_b1.npz"):
+        g = np.load(os.path.join(GOLDEN, fname))
+        m = getattr(models, str(g["arch"]))()
+        shapes = seeded.shapes_of(m)
+        assert list(shapes.keys()) == [str(n) for n in g["param_names"]]
+        p = {k: torch.from_numpy(v) for k, v in seeded.fill(shapes, int(g["weight_seed"])).items()}
+        x = torch.from_numpy(seeded.image_batch(int(g["batch"]), int(g["input_seed"]), int(g["hw"])))
+        with torch.no_grad():
+            y = OF.resnest(p, x, str(g["arch"]))
+        assert str(g["pinned_by"]) == "reference-file-on-tlx_cpu"
+        assert np.abs(y.numpy() - g["logits"]).max() <= 1e-4 and (y.argmax(-1).numpy() == g["argmax"]).all()
+
+
 def test_swin_helpers_against_their_definitions():
     """The restated index / mask helpers checked against independent brute-force definitions."""
     ws = 7

@@ -188,6 +188,125 @@ __global__ void maxpool_kernel(const T* __restrict__ x, T* __restrict__ y, int N
     }
 }
 
+// AvgPool2d, zero padding counted in the divisor (R * S always): nn.AvgPool2d(3, stride, 1) / (stride, stride, 0) of
+// resnest.py:212-218, 250-256, 271-286.  Accumulation in window order, one division at the end (torch's CPU order).
+template <typename T>
+__global__ void avgpool_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C, int x_ld,
+                               int y_ld, int R, int S, int sh, int sw, int ph, int pw, int Ho, int Wo) {
+    constexpr int V = Chunk<T>::N;
+    const int nch = C / V;
+    const long total = (long)N * Ho * Wo * nch;
+    const float inv = 1.f / (float)(R * S);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % nch);
+        long p = i / nch;
+        const int wo = (int)(p % Wo);
+        p /= Wo;
+        const int ho = (int)(p % Ho);
+        const long n = p / Ho;
+        float m[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) m[e] = 0.f;
+        for (int r = 0; r < R; ++r) {
+            const int hi = ho * sh - ph + r;
+            if ((unsigned)hi >= (unsigned)H) continue;
+            for (int s = 0; s < S; ++s) {
+                const int wi = wo * sw - pw + s;
+                if ((unsigned)wi >= (unsigned)W) continue;
+                float v[V];
+                Chunk<T>::load(x + ((n * H + hi) * W + wi) * x_ld + cg * V, v);
+#pragma unroll
+                for (int e = 0; e < V; ++e) m[e] += v[e];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < V; ++e) m[e] *= inv;
+        Chunk<T>::store(y + ((n * Ho + ho) * Wo + wo) * y_ld + cg * V, m);
+    }
+}
+
+// Split attention of ResNeSt's SplatConv (resnest.py:147-166, rSoftmax :53-82).  x: [N][HW][radix * C], split r =
+// channels [r*C, (r+1)*C).
+//   radix_gap:  g[n][c] = mean_p sum_r x[n][p][r*C + c]                                   (:150-155)
+//   split_attention: y[n][p][c] = sum_r a_r(n, c) * x[n][p][r*C + c], where for radix > 1
+//       a_r(n, c) = softmax over r of logit[n][(k*radix + r)*cpg + c'],  c = k*cpg + c',  cpg = C / cardinality
+//   (the reshape / transpose / softmax(axis=1) / reshape of rSoftmax), and for radix == 1  a = sigmoid(logit[n][c]).
+template <typename T>
+__global__ void radix_gap_kernel(const T* __restrict__ x, T* __restrict__ g, int N, int HW, int C, int radix, int x_ld, int g_ld) {
+    constexpr int V = Chunk<T>::N;
+    const int nch = C / V;
+    const long total = (long)N * nch;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % nch);
+        const long n = i / nch;
+        float acc[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] = 0.f;
+        for (int k = 0; k < HW; ++k) {
+            float t[V];
+            Chunk<T>::load(x + (n * HW + k) * x_ld + cg * V, t);
+            for (int r = 1; r < radix; ++r) {           // the splits are added first (fp16 storage rounding aside), :152
+                float v[V];
+                Chunk<T>::load(x + (n * HW + k) * x_ld + r * C + cg * V, v);
+#pragma unroll
+                for (int e = 0; e < V; ++e) t[e] += v[e];
+            }
+#pragma unroll
+            for (int e = 0; e < V; ++e) acc[e] += t[e];
+        }
+        const float inv = 1.f / (float)HW;
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] *= inv;
+        Chunk<T>::store(g + n * g_ld + cg * V, acc);
+    }
+}
+
+template <typename T>
+__global__ void split_attention_kernel(const T* __restrict__ x, const T* __restrict__ logit, T* __restrict__ y, int N, int HW,
+                                       int C, int radix, int cardinality, int x_ld, int l_ld, int y_ld) {
+    constexpr int V = Chunk<T>::N;
+    const int nch = C / V, cpg = C / cardinality;
+    const long total = (long)N * HW * nch;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % nch);
+        const long pix = i / nch;
+        const long n = pix / HW;
+        float out[V];
+        if (radix == 1) {
+            float a[V], v[V];
+            Chunk<T>::load(logit + n * l_ld + cg * V, a);
+            Chunk<T>::load(x + pix * x_ld + cg * V, v);
+#pragma unroll
+            for (int e = 0; e < V; ++e) out[e] = v[e] * (1.f / (1.f + expf(-a[e])));
+        } else {
+            float mx[V], den[V];
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const int c = cg * V + e, k = c / cpg, cc = c - k * cpg;
+                const T* lp = logit + n * l_ld + (long)k * radix * cpg + cc;
+                float m = -INFINITY;
+                for (int r = 0; r < radix; ++r) m = fmaxf(m, (float)lp[r * cpg]);
+                float d = 0.f;
+                for (int r = 0; r < radix; ++r) d += expf((float)lp[r * cpg] - m);
+                mx[e] = m;
+                den[e] = d;
+                out[e] = 0.f;
+            }
+            for (int r = 0; r < radix; ++r) {
+                float v[V];
+                Chunk<T>::load(x + pix * x_ld + r * C + cg * V, v);
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    const int c = cg * V + e, k = c / cpg, cc = c - k * cpg;
+                    const float a = expf((float)logit[n * l_ld + ((long)k * radix + r) * cpg + cc] - mx[e]) / den[e];
+                    out[e] += a * v[e];
+                }
+            }
+        }
+        Chunk<T>::store(y + pix * y_ld + cg * V, out);
+    }
+}
+
 template <typename T>
 __global__ void global_avgpool_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int HW, int C, int x_ld,
                                       int y_ld) {
@@ -527,6 +646,54 @@ extern "C" int tlxmi_maxpool2d(const void* x, void* y, int dt, int N, int H, int
     else
         hipLaunchKernelGGL((maxpool_kernel<float>), g, b, 0, as_stream(stream), (const float*)x, (float*)y, N, H, W, C, x_ld, y_ld, R, S, sh, sw, ph, pw, Ho, Wo);
     return check_launch("maxpool2d");
+}
+
+extern "C" int tlxmi_avgpool2d(const void* x, void* y, int dt, int N, int H, int W, int C, int x_ld, int y_ld, int R,
+                               int S, int sh, int sw, int ph, int pw, int Ho, int Wo, void* stream) {
+    TLXMI_REQUIRE(x && y, TLXMI_ERR_BAD_ARG, "avgpool2d: null buffer");
+    REQUIRE_CHUNKED("avgpool2d", dt, C, x_ld, y_ld);
+    TLXMI_REQUIRE(aligned16(x) && aligned16(y), TLXMI_ERR_ALIGNMENT, "avgpool2d: buffers must be 16-byte aligned");
+    TLXMI_REQUIRE(N > 0 && H > 0 && W > 0 && R > 0 && S > 0 && sh > 0 && sw > 0 && ph >= 0 && pw >= 0, TLXMI_ERR_BAD_ARG,
+                  "avgpool2d: bad extent");
+    TLXMI_REQUIRE(2 * ph <= R && 2 * pw <= S, TLXMI_ERR_BAD_ARG, "avgpool2d: padding must be at most half the window");
+    TLXMI_REQUIRE(Ho == (H + 2 * ph - R) / sh + 1 && Wo == (W + 2 * pw - S) / sw + 1 && Ho > 0 && Wo > 0, TLXMI_ERR_BAD_ARG,
+                  "avgpool2d: output extent mismatch");
+    const long work = (long)N * Ho * Wo * (C / VECN(dt));
+    dim3 g(grid_for(work)), b(256);
+    if (dt == TLXMI_F16)
+        hipLaunchKernelGGL((avgpool_kernel<half_t>), g, b, 0, as_stream(stream), (const half_t*)x, (half_t*)y, N, H, W, C, x_ld, y_ld, R, S, sh, sw, ph, pw, Ho, Wo);
+    else
+        hipLaunchKernelGGL((avgpool_kernel<float>), g, b, 0, as_stream(stream), (const float*)x, (float*)y, N, H, W, C, x_ld, y_ld, R, S, sh, sw, ph, pw, Ho, Wo);
+    return check_launch("avgpool2d");
+}
+
+extern "C" int tlxmi_radix_gap(const void* x, void* g, int dt, int N, int HW, int C, int radix, int x_ld, int g_ld, void* stream) {
+    TLXMI_REQUIRE(x && g && N > 0 && HW > 0 && radix >= 1, TLXMI_ERR_BAD_ARG, "radix_gap: bad argument");
+    REQUIRE_CHUNKED("radix_gap", dt, C, g_ld);
+    TLXMI_REQUIRE(x_ld >= radix * C && x_ld % VECN(dt) == 0 && aligned16(x) && aligned16(g), TLXMI_ERR_ALIGNMENT, "radix_gap: bad stride / alignment");
+    const long work = (long)N * (C / VECN(dt));
+    dim3 gr(grid_for(work, 64)), b(64);
+    if (dt == TLXMI_F16)
+        hipLaunchKernelGGL((radix_gap_kernel<half_t>), gr, b, 0, as_stream(stream), (const half_t*)x, (half_t*)g, N, HW, C, radix, x_ld, g_ld);
+    else
+        hipLaunchKernelGGL((radix_gap_kernel<float>), gr, b, 0, as_stream(stream), (const float*)x, (float*)g, N, HW, C, radix, x_ld, g_ld);
+    return check_launch("radix_gap");
+}
+
+extern "C" int tlxmi_split_attention(const void* x, const void* logit, void* y, int dt, int N, int HW, int C, int radix,
+                                     int cardinality, int x_ld, int l_ld, int y_ld, void* stream) {
+    TLXMI_REQUIRE(x && logit && y && N > 0 && HW > 0 && radix >= 1 && cardinality >= 1, TLXMI_ERR_BAD_ARG, "split_attention: bad argument");
+    REQUIRE_CHUNKED("split_attention", dt, C, y_ld);
+    TLXMI_REQUIRE(C % cardinality == 0, TLXMI_ERR_BAD_ARG, "split_attention: C=%d is not divisible by cardinality=%d", C, cardinality);
+    TLXMI_REQUIRE(x_ld >= radix * C && x_ld % VECN(dt) == 0 && l_ld >= radix * C && l_ld % VECN(dt) == 0 && aligned16(x) && aligned16(logit) && aligned16(y),
+                  TLXMI_ERR_ALIGNMENT, "split_attention: bad stride / alignment");
+    const long work = (long)N * HW * (C / VECN(dt));
+    dim3 g(grid_for(work)), b(256);
+    if (dt == TLXMI_F16)
+        hipLaunchKernelGGL((split_attention_kernel<half_t>), g, b, 0, as_stream(stream), (const half_t*)x, (const half_t*)logit, (half_t*)y, N, HW, C, radix, cardinality, x_ld, l_ld, y_ld);
+    else
+        hipLaunchKernelGGL((split_attention_kernel<float>), g, b, 0, as_stream(stream), (const float*)x, (const float*)logit, (float*)y, N, HW, C, radix, cardinality, x_ld, l_ld, y_ld);
+    return check_launch("split_attention");
 }
 
 extern "C" int tlxmi_global_avgpool(const void* x, void* y, int dt, int N, int HW, int C, int x_ld, int y_ld,

@@ -418,6 +418,42 @@ def maxpool2d(x, kernel, stride, padding):
     return y
 
 
+def avgpool2d(x, kernel, stride, padding):
+    """nn.AvgPool2d on an NHWC map; zero padding counts in the divisor."""
+    need_gpu(x, "input")
+    N, H, W, Cc = x.shape
+    R, S = _pair(kernel)
+    sh, sw = _pair(stride)
+    ph, pw = _pair(padding)
+    Ho = (H + 2 * ph - R) // sh + 1
+    Wo = (W + 2 * pw - S) // sw + 1
+    y = torch.empty((N, Ho, Wo, Cc), dtype=x.dtype, device=x.device)
+    _lib.call("tlxmi_avgpool2d", _p(x), _p(y), dt_code(x.dtype), N, H, W, Cc, Cc, Cc, R, S, sh, sw, ph, pw, Ho, Wo, _stream())
+    return y
+
+
+def radix_gap(x, radix):
+    """(N,H,W,radix*C) -> (N,C): mean over pixels of the sum of the radix splits (resnest.py:150-155)."""
+    need_gpu(x, "input")
+    N, H, W, RC = x.shape
+    Cc = RC // radix
+    g = torch.empty((N, Cc), dtype=x.dtype, device=x.device)
+    _lib.call("tlxmi_radix_gap", _p(x), _p(g), dt_code(x.dtype), N, H * W, Cc, radix, RC, Cc, _stream())
+    return g
+
+
+def split_attention(x, logit, radix, cardinality):
+    """x (N,H,W,radix*C), logit (N,radix*C) -> (N,H,W,C): rSoftmax over the radix axis (sigmoid for radix 1) and the
+    weighted sum of the splits (resnest.py:53-82, 158-165)."""
+    need_gpu(x, "input")
+    N, H, W, RC = x.shape
+    Cc = RC // radix
+    y = torch.empty((N, H, W, Cc), dtype=x.dtype, device=x.device)
+    _lib.call("tlxmi_split_attention", _p(x), _p(logit), _p(y), dt_code(x.dtype), N, H * W, Cc, radix, cardinality, RC,
+              logit.shape[-1], Cc, _stream())
+    return y
+
+
 def global_avgpool(x):
     """(N,H,W,C) or (N,L,C) -> (N,C) mean over the middle axes."""
     need_gpu(x, "input")

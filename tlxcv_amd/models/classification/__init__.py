@@ -14,3 +14,4 @@ from .alexnet import AlexNet, alexnet  # noqa: F401
 from .resnext import (ResNeXt, resnext50_32x4d, resnext50_64x4d, resnext101_32x4d, resnext101_64x4d,  # noqa: F401
                       resnext152_32x4d, resnext152_64x4d)
 from .efficientnet import efficientnet, EfficientNet  # noqa: F401
+from .resnest import resnest50_fast_1s1x64d, resnest50, resnest101, ResNeSt  # noqa: F401

@@ -202,6 +202,10 @@ class Sequential(Module):
 
     def __init__(self, *layers, name=None):
         super().__init__(name=name)
+        if len(layers) == 1 and isinstance(layers[0], dict):     # OrderedDict of named layers (resnest.py:479-513)
+            for k, l in layers[0].items():
+                self.add_module(k, l)
+            return
         if len(layers) == 1 and isinstance(layers[0], (list, tuple)):
             layers = layers[0]
         for i, l in enumerate(layers):
@@ -590,6 +594,29 @@ class MaxPool2d(Module):
 
     def run_nhwc(self, x):
         return E.maxpool2d(x, self.kernel_size, self.stride, self.padding)
+
+    def forward(self, x):
+        return from_nhwc(self.run_nhwc(as_nhwc(x, self.data_format)), self.data_format)
+
+
+class AvgPool2d(Module):
+    """nn.AvgPool2d(kernel_size, stride, padding, data_format) — resnest.py:212-218, 250-256, 271-286; zero padding counts
+    in the divisor [TLX-recalled: the torch backend forwards to F.avg_pool2d's default]."""
+
+    def __init__(self, kernel_size, stride=None, padding="SAME", ceil_mode=False, data_format="channels_last", name=None):
+        super().__init__(name=name)
+        self.kernel_size = _tup2(kernel_size)
+        self.stride = _tup2(stride if stride is not None else kernel_size)
+        if isinstance(padding, str):
+            self.padding = (0, 0) if padding.upper() == "VALID" else tuple((k - 1) // 2 for k in self.kernel_size)
+        else:
+            self.padding = _tup2(padding)
+        self.data_format = data_format
+
+    def run_nhwc(self, v):
+        if self.kernel_size == (1, 1) and self.stride == (1, 1):
+            return v
+        return E.avgpool2d(v, self.kernel_size, self.stride, self.padding)
 
     def forward(self, x):
         return from_nhwc(self.run_nhwc(as_nhwc(x, self.data_format)), self.data_format)

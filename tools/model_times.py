@@ -12,7 +12,7 @@ from tlxcv_amd import seeded, models  # noqa: E402
 dev = torch.device("cuda:0")
 CASES = [("resnet18", 256, 224, False), ("resnet34", 256, 224, False), ("resnet50", 256, 224, False), ("resnet101", 128, 224, False),
          ("vgg16", 64, 224, False), ("alexnet", 256, 224, False), ("resnext50_32x4d", 256, 224, False),
-         ("resnext101_64x4d", 64, 224, False), ("efficientnet_b0", 256, 224, False),
+         ("resnext101_64x4d", 64, 224, False), ("efficientnet_b0", 256, 224, False), ("resnest50", 128, 224, False),
          ("MobileNetV1", 256, 224, False), ("mobilenet_v2", 256, 224, False), ("mobilenet_v3_small", 256, 224, False),
          ("mobilenet_v3_large", 256, 224, False), ("DarkNet", 64, 256, True), ("YOLOv3", 32, 416, True),
          ("vit_small_patch16_224", 256, 224, False), ("vit_base_patch16_224", 256, 224, False),
