@@ -188,8 +188,9 @@ int tlxmi_avgpool2d(const void* x, void* y, int dtype, int N, int H, int W, int 
  * with, for radix > 1, a_r(n,c) = softmax over r of logit[n][(k*radix + r)*cpg + c'] (c = k*cpg + c', cpg = C/cardinality:
  * rSoftmax's reshape-transpose-softmax(axis=1)-reshape), and for radix == 1, a = sigmoid(logit[n][c]). */
 int tlxmi_radix_gap(const void* x, void* g, int dtype, int N, int HW, int C, int radix, int x_ld, int g_ld, void* stream);
-int tlxmi_split_attention(const void* x, const void* logit, void* y, int dtype, int N, int HW, int C, int radix,
-                          int cardinality, int x_ld, int l_ld, int y_ld, void* stream);
+/* att_ws: caller-owned fp32 scratch of N * radix * C values (the attention weights in split order; two launches). */
+int tlxmi_split_attention(const void* x, const void* logit, float* att_ws, void* y, int dtype, int N, int HW, int C,
+                          int radix, int cardinality, int x_ld, int l_ld, int y_ld, void* stream);
 /* y[n][c] = mean over H*W of x[n][.][.][c];  y pixel stride y_ld */
 int tlxmi_global_avgpool(const void* x, void* y, int dtype, int N, int HW, int C, int x_ld, int y_ld,
                          void* stream);

@@ -49,7 +49,7 @@ PROTOTYPES = {
     "tlxmi_maxpool2d": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "tlxmi_avgpool2d": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "tlxmi_radix_gap": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
-    "tlxmi_split_attention": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "tlxmi_split_attention": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "tlxmi_global_avgpool": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "tlxmi_adaptive_avgpool2d": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "tlxmi_affine_act": [_vp, _vp, _vp, _vp, _vp, _i, _l, _i, _i, _i, _i, _i, _f, _u, _vp],

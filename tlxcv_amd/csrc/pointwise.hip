@@ -231,29 +231,39 @@ __global__ void avgpool_kernel(const T* __restrict__ x, T* __restrict__ y, int N
 //   split_attention: y[n][p][c] = sum_r a_r(n, c) * x[n][p][r*C + c], where for radix > 1
 //       a_r(n, c) = softmax over r of logit[n][(k*radix + r)*cpg + c'],  c = k*cpg + c',  cpg = C / cardinality
 //   (the reshape / transpose / softmax(axis=1) / reshape of rSoftmax), and for radix == 1  a = sigmoid(logit[n][c]).
+// One workgroup per (image, slab of up to 32 channel chunks): the 256 threads are (pixel lane, chunk), every thread sums
+// its pixels pl, pl + PL, ... of all radix splits, the pixel lanes are reduced through LDS.
 template <typename T>
-__global__ void radix_gap_kernel(const T* __restrict__ x, T* __restrict__ g, int N, int HW, int C, int radix, int x_ld, int g_ld) {
+__global__ __launch_bounds__(256) void radix_gap_kernel(const T* __restrict__ x, T* __restrict__ g, int N, int HW, int C, int radix,
+                                                        int x_ld, int g_ld, int cpb, int nslab) {
     constexpr int V = Chunk<T>::N;
+    __shared__ float red[256][V];
     const int nch = C / V;
-    const long total = (long)N * nch;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int cg = (int)(i % nch);
-        const long n = i / nch;
-        float acc[V];
+    const int pl_n = 256 / cpb;                      // pixel lanes
+    const int slab = blockIdx.x % nslab;
+    const long n = blockIdx.x / nslab;
+    const int cl = threadIdx.x % cpb, pl = threadIdx.x / cpb;
+    const int cg = slab * cpb + cl;
+    float acc[V];
 #pragma unroll
-        for (int e = 0; e < V; ++e) acc[e] = 0.f;
-        for (int k = 0; k < HW; ++k) {
-            float t[V];
-            Chunk<T>::load(x + (n * HW + k) * x_ld + cg * V, t);
-            for (int r = 1; r < radix; ++r) {           // the splits are added first (fp16 storage rounding aside), :152
+    for (int e = 0; e < V; ++e) acc[e] = 0.f;
+    if (pl < pl_n && cg < nch) {
+        for (int k = pl; k < HW; k += pl_n) {
+            for (int r = 0; r < radix; ++r) {
                 float v[V];
                 Chunk<T>::load(x + (n * HW + k) * x_ld + r * C + cg * V, v);
 #pragma unroll
-                for (int e = 0; e < V; ++e) t[e] += v[e];
+                for (int e = 0; e < V; ++e) acc[e] += v[e];
             }
-#pragma unroll
-            for (int e = 0; e < V; ++e) acc[e] += t[e];
         }
+    }
+#pragma unroll
+    for (int e = 0; e < V; ++e) red[threadIdx.x][e] = acc[e];
+    __syncthreads();
+    if (pl == 0 && cg < nch) {
+        for (int q = 1; q < pl_n; ++q)
+#pragma unroll
+            for (int e = 0; e < V; ++e) acc[e] += red[q * cpb + cl][e];
         const float inv = 1.f / (float)HW;
 #pragma unroll
         for (int e = 0; e < V; ++e) acc[e] *= inv;
@@ -261,47 +271,50 @@ __global__ void radix_gap_kernel(const T* __restrict__ x, T* __restrict__ g, int
     }
 }
 
+// att[n][r*C + c] (fp32, split order) from logit[n][(k*radix + r)*cpg + c'] (conv3's channel order): softmax over r, or
+// sigmoid for radix 1 — one thread per (image, channel).
 template <typename T>
-__global__ void split_attention_kernel(const T* __restrict__ x, const T* __restrict__ logit, T* __restrict__ y, int N, int HW,
-                                       int C, int radix, int cardinality, int x_ld, int l_ld, int y_ld) {
+__global__ void radix_softmax_kernel(const T* __restrict__ logit, float* __restrict__ att, int N, int C, int radix, int cardinality,
+                                     int l_ld) {
+    const int cpg = C / cardinality;
+    const long total = (long)N * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const long n = i / C;
+        const int k = c / cpg, cc = c - k * cpg;
+        const T* lp = logit + n * l_ld + (long)k * radix * cpg + cc;
+        float* ap = att + n * (long)radix * C + c;
+        if (radix == 1) {
+            ap[0] = 1.f / (1.f + expf(-(float)lp[0]));
+            continue;
+        }
+        float m = -INFINITY;
+        for (int r = 0; r < radix; ++r) m = fmaxf(m, (float)lp[r * cpg]);
+        float d = 0.f;
+        for (int r = 0; r < radix; ++r) d += expf((float)lp[r * cpg] - m);
+        for (int r = 0; r < radix; ++r) ap[(long)r * C] = expf((float)lp[r * cpg] - m) / d;
+    }
+}
+
+template <typename T>
+__global__ void split_attention_kernel(const T* __restrict__ x, const float* __restrict__ att, T* __restrict__ y, int N, int HW,
+                                       int C, int radix, int x_ld, int y_ld) {
     constexpr int V = Chunk<T>::N;
-    const int nch = C / V, cpg = C / cardinality;
+    const int nch = C / V;
     const long total = (long)N * HW * nch;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int cg = (int)(i % nch);
         const long pix = i / nch;
         const long n = pix / HW;
         float out[V];
-        if (radix == 1) {
-            float a[V], v[V];
-            Chunk<T>::load(logit + n * l_ld + cg * V, a);
-            Chunk<T>::load(x + pix * x_ld + cg * V, v);
 #pragma unroll
-            for (int e = 0; e < V; ++e) out[e] = v[e] * (1.f / (1.f + expf(-a[e])));
-        } else {
-            float mx[V], den[V];
+        for (int e = 0; e < V; ++e) out[e] = 0.f;
+        for (int r = 0; r < radix; ++r) {
+            float v[V];
+            Chunk<T>::load(x + pix * x_ld + r * C + cg * V, v);
+            const float* ap = att + (n * radix + r) * (long)C + cg * V;
 #pragma unroll
-            for (int e = 0; e < V; ++e) {
-                const int c = cg * V + e, k = c / cpg, cc = c - k * cpg;
-                const T* lp = logit + n * l_ld + (long)k * radix * cpg + cc;
-                float m = -INFINITY;
-                for (int r = 0; r < radix; ++r) m = fmaxf(m, (float)lp[r * cpg]);
-                float d = 0.f;
-                for (int r = 0; r < radix; ++r) d += expf((float)lp[r * cpg] - m);
-                mx[e] = m;
-                den[e] = d;
-                out[e] = 0.f;
-            }
-            for (int r = 0; r < radix; ++r) {
-                float v[V];
-                Chunk<T>::load(x + pix * x_ld + r * C + cg * V, v);
-#pragma unroll
-                for (int e = 0; e < V; ++e) {
-                    const int c = cg * V + e, k = c / cpg, cc = c - k * cpg;
-                    const float a = expf((float)logit[n * l_ld + ((long)k * radix + r) * cpg + cc] - mx[e]) / den[e];
-                    out[e] += a * v[e];
-                }
-            }
+            for (int e = 0; e < V; ++e) out[e] += ap[e] * v[e];
         }
         Chunk<T>::store(y + pix * y_ld + cg * V, out);
     }
@@ -671,28 +684,35 @@ extern "C" int tlxmi_radix_gap(const void* x, void* g, int dt, int N, int HW, in
     TLXMI_REQUIRE(x && g && N > 0 && HW > 0 && radix >= 1, TLXMI_ERR_BAD_ARG, "radix_gap: bad argument");
     REQUIRE_CHUNKED("radix_gap", dt, C, g_ld);
     TLXMI_REQUIRE(x_ld >= radix * C && x_ld % VECN(dt) == 0 && aligned16(x) && aligned16(g), TLXMI_ERR_ALIGNMENT, "radix_gap: bad stride / alignment");
-    const long work = (long)N * (C / VECN(dt));
-    dim3 gr(grid_for(work, 64)), b(64);
+    const int nch = C / VECN(dt);
+    const int cpb = nch < 32 ? nch : 32, nslab = (nch + cpb - 1) / cpb;
+    dim3 gr((unsigned)((long)N * nslab)), b(256);
     if (dt == TLXMI_F16)
-        hipLaunchKernelGGL((radix_gap_kernel<half_t>), gr, b, 0, as_stream(stream), (const half_t*)x, (half_t*)g, N, HW, C, radix, x_ld, g_ld);
+        hipLaunchKernelGGL((radix_gap_kernel<half_t>), gr, b, 0, as_stream(stream), (const half_t*)x, (half_t*)g, N, HW, C, radix, x_ld, g_ld, cpb, nslab);
     else
-        hipLaunchKernelGGL((radix_gap_kernel<float>), gr, b, 0, as_stream(stream), (const float*)x, (float*)g, N, HW, C, radix, x_ld, g_ld);
+        hipLaunchKernelGGL((radix_gap_kernel<float>), gr, b, 0, as_stream(stream), (const float*)x, (float*)g, N, HW, C, radix, x_ld, g_ld, cpb, nslab);
     return check_launch("radix_gap");
 }
 
-extern "C" int tlxmi_split_attention(const void* x, const void* logit, void* y, int dt, int N, int HW, int C, int radix,
-                                     int cardinality, int x_ld, int l_ld, int y_ld, void* stream) {
-    TLXMI_REQUIRE(x && logit && y && N > 0 && HW > 0 && radix >= 1 && cardinality >= 1, TLXMI_ERR_BAD_ARG, "split_attention: bad argument");
+extern "C" int tlxmi_split_attention(const void* x, const void* logit, float* att_ws, void* y, int dt, int N, int HW, int C,
+                                     int radix, int cardinality, int x_ld, int l_ld, int y_ld, void* stream) {
+    TLXMI_REQUIRE(x && logit && att_ws && y && N > 0 && HW > 0 && radix >= 1 && cardinality >= 1, TLXMI_ERR_BAD_ARG, "split_attention: bad argument");
     REQUIRE_CHUNKED("split_attention", dt, C, y_ld);
     TLXMI_REQUIRE(C % cardinality == 0, TLXMI_ERR_BAD_ARG, "split_attention: C=%d is not divisible by cardinality=%d", C, cardinality);
-    TLXMI_REQUIRE(x_ld >= radix * C && x_ld % VECN(dt) == 0 && l_ld >= radix * C && l_ld % VECN(dt) == 0 && aligned16(x) && aligned16(logit) && aligned16(y),
+    TLXMI_REQUIRE(x_ld >= radix * C && x_ld % VECN(dt) == 0 && l_ld >= radix * C && aligned16(x) && aligned16(y) && aligned16(att_ws),
                   TLXMI_ERR_ALIGNMENT, "split_attention: bad stride / alignment");
+    hipStream_t st = as_stream(stream);
+    {
+        dim3 g(grid_for((long)N * C)), b(256);
+        if (dt == TLXMI_F16) hipLaunchKernelGGL((radix_softmax_kernel<half_t>), g, b, 0, st, (const half_t*)logit, att_ws, N, C, radix, cardinality, l_ld);
+        else hipLaunchKernelGGL((radix_softmax_kernel<float>), g, b, 0, st, (const float*)logit, att_ws, N, C, radix, cardinality, l_ld);
+    }
     const long work = (long)N * HW * (C / VECN(dt));
     dim3 g(grid_for(work)), b(256);
     if (dt == TLXMI_F16)
-        hipLaunchKernelGGL((split_attention_kernel<half_t>), g, b, 0, as_stream(stream), (const half_t*)x, (const half_t*)logit, (half_t*)y, N, HW, C, radix, cardinality, x_ld, l_ld, y_ld);
+        hipLaunchKernelGGL((split_attention_kernel<half_t>), g, b, 0, st, (const half_t*)x, att_ws, (half_t*)y, N, HW, C, radix, x_ld, y_ld);
     else
-        hipLaunchKernelGGL((split_attention_kernel<float>), g, b, 0, as_stream(stream), (const float*)x, (const float*)logit, (float*)y, N, HW, C, radix, cardinality, x_ld, l_ld, y_ld);
+        hipLaunchKernelGGL((split_attention_kernel<float>), g, b, 0, st, (const float*)x, att_ws, (float*)y, N, HW, C, radix, x_ld, y_ld);
     return check_launch("split_attention");
 }
 

@@ -449,8 +449,9 @@ def split_attention(x, logit, radix, cardinality):
     N, H, W, RC = x.shape
     Cc = RC // radix
     y = torch.empty((N, H, W, Cc), dtype=x.dtype, device=x.device)
-    _lib.call("tlxmi_split_attention", _p(x), _p(logit), _p(y), dt_code(x.dtype), N, H * W, Cc, radix, cardinality, RC,
-              logit.shape[-1], Cc, _stream())
+    ws = torch.empty((N, RC), dtype=torch.float32, device=x.device)      # attention weights, split order
+    _lib.call("tlxmi_split_attention", _p(x), _p(logit), _p(ws), _p(y), dt_code(x.dtype), N, H * W, Cc, radix, cardinality,
+              RC, logit.shape[-1], Cc, _stream())
     return y
 
 
