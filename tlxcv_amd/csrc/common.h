@@ -43,7 +43,7 @@ __device__ __forceinline__ float apply_act(float x, int act, float p) {
         case TLXMI_ACT_HARDSIGMOID: return fminf(fmaxf(x + 3.f, 0.f), 6.f) * (1.f / 6.f);
         case TLXMI_ACT_GELU: return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));
         case TLXMI_ACT_SIGMOID: return 1.f / (1.f + __expf(-x));
-        case TLXMI_ACT_SILU: return x / (1.f + __expf(-x));
+        case TLXMI_ACT_SILU: return x * __builtin_amdgcn_rcpf(1.f + __expf(-x));     // rcp: 1 ulp, no division sequence
         default: return x;
     }
 }
@@ -58,7 +58,7 @@ template <int ACT> __device__ __forceinline__ float apply_act_t(float x, float p
     else if constexpr (ACT == TLXMI_ACT_HARDSIGMOID) return fminf(fmaxf(x + 3.f, 0.f), 6.f) * (1.f / 6.f);
     else if constexpr (ACT == TLXMI_ACT_GELU) return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));
     else if constexpr (ACT == TLXMI_ACT_SIGMOID) return 1.f / (1.f + __expf(-x));
-    else if constexpr (ACT == TLXMI_ACT_SILU) return x / (1.f + __expf(-x));
+    else if constexpr (ACT == TLXMI_ACT_SILU) return x * __builtin_amdgcn_rcpf(1.f + __expf(-x));
     else return x;
 }
 template <int V> struct IntTag { static constexpr int value = V; };
