@@ -481,15 +481,21 @@ __global__ __launch_bounds__(256) void dwconv_strip_kernel(const T* __restrict__
     typedef T rawv __attribute__((ext_vector_type(V)));
     const int nch = d.C / V;
     const int wt = (d.Wo + TW - 1) / TW;
-    const long total = (long)d.N * d.Ho * wt * nch;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int cg = (int)(i % nch);
-        long p = i / nch;
-        const int ws = (int)(p % wt);
-        p /= wt;
-        const int ho = (int)(p % d.Ho);
-        const long n = p / d.Ho;
+    // one output row per workgroup column: the (image, row) pair comes from the block index (scalar arithmetic, once),
+    // the thread only splits its position inside the row into (strip, channel chunk)
+    const int per_row = wt * nch, bx = (per_row + 255) / 256;
+    const int row = blockIdx.x / bx, idx = (blockIdx.x - row * bx) * 256 + threadIdx.x;
+    if (idx < per_row) {
+        const int ws = idx / nch, cg = idx - ws * nch;
+        const long n = row / d.Ho;
+        const int ho = row - (int)n * d.Ho;
         const int wo0 = ws * TW, wi0 = wo0 * SW - d.pad_w;
+        float sc[V], sf[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            sc[e] = scale ? scale[cg * V + e] : 1.f;
+            sf[e] = shift ? shift[cg * V + e] : 0.f;
+        }
         float acc[TW][V];
 #pragma unroll
         for (int t = 0; t < TW; ++t)
@@ -521,12 +527,7 @@ __global__ __launch_bounds__(256) void dwconv_strip_kernel(const T* __restrict__
         for (int t = 0; t < TW; ++t) {
             if (wo0 + t >= d.Wo) break;
 #pragma unroll
-            for (int e = 0; e < V; ++e) {
-                float v = acc[t][e];
-                if (scale) v *= scale[cg * V + e];
-                if (shift) v += shift[cg * V + e];
-                acc[t][e] = apply_act(v, d.act, d.act_param);
-            }
+            for (int e = 0; e < V; ++e) acc[t][e] = apply_act(acc[t][e] * sc[e] + sf[e], d.act, d.act_param);
             Chunk<T>::store(y + ((n * d.Ho + ho) * d.Wo + wo0 + t) * d.y_ld + cg * V, acc[t]);
         }
     }
@@ -857,8 +858,10 @@ extern "C" int tlxmi_dwconv2d(const tlxmi_dwconv2d_desc* d, const void* x, const
     static const int strip_on = [] { const char* e = getenv("TLXMI_DWSTRIP"); return e ? atoi(e) : 1; }();
     if (strip_on && d->dil_h == 1 && d->dil_w == 1 && (d->S == 3 || d->S == 5) && (d->stride_w == 1 || d->stride_w == 2) && d->Wo >= 4) {
         constexpr int TW = 4;
-        const long work = (long)d->N * d->Ho * ((d->Wo + TW - 1) / TW) * (d->C / VECN(d->dtype));
-        dim3 g(grid_for(work)), b(256);
+        const int per_row = ((d->Wo + TW - 1) / TW) * (d->C / VECN(d->dtype));
+        const long blocks = (long)d->N * d->Ho * ((per_row + 255) / 256);
+        TLXMI_REQUIRE(blocks < (1l << 31), TLXMI_ERR_UNSUPPORTED, "dwconv2d: too many rows");
+        dim3 g((unsigned)blocks), b(256);
         hipStream_t st = as_stream(stream);
 #define TLXMI_DW_CASE(TT, SS, WW)                                                                                                  \
         hipLaunchKernelGGL((dwconv_strip_kernel<TT, TW, SS, WW>), g, b, 0, st, (const TT*)x, (const TT*)w, scale, shift, (TT*)y, *d)
