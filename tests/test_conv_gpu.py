@@ -350,3 +350,28 @@ def test_same_padding_one_sided(dev, dtype, cfg):
         torch.testing.assert_close(engine_to_nchw(got), want, **tol(dtype))
     finally:
         tlxcv_amd.set_precision("fp16")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["fp32", "fp16"])
+@pytest.mark.parametrize("k,H,W", [(3, 64, 64), (3, 30, 46), (5, 32, 32)])
+def test_space_to_depth_stem_with_same_padding(dev, dtype, k, H, W):
+    """The 'SAME' stride-2 RGB stem (efficientnet.py:354-363) on the 2 x 2 space-to-depth image: leading padding from
+    TensorFlow's rule, the odd unit as windows past the bottom / right edge."""
+    import tlxcv_amd
+    from tlxcv_amd.tlx import nn
+    tlxcv_amd.set_precision("fp32" if dtype == torch.float32 else "fp16")
+    try:
+        rng = np.random.default_rng(59)
+        conv = nn.GroupConv2d(32, (k, k), (2, 2), 1, None, "SAME", in_channels=3, data_format="channels_first")
+        w, bias = rnd(rng, (32, 3, k, k), 0.2), rnd(rng, (32,), 0.1)
+        x = rnd(rng, (2, 3, H, W))
+        if dtype == torch.float16:
+            w, x = q16(w), q16(x)
+        conv.load_dict({"filters": w, "biases": bias})
+        conv = conv.to(dev).set_eval()
+        want = torch.nn.functional.conv2d(OF.same_pad(x, k, 2), w, bias, 2)
+        got = conv.run_stem(x.to(dev), 2)
+        torch.cuda.synchronize()
+        torch.testing.assert_close(engine_to_nchw(got), want, **tol(dtype))
+    finally:
+        tlxcv_amd.set_precision("fp16")

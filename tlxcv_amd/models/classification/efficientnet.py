@@ -209,11 +209,16 @@ class EfficientNet(nn.Module):
         )
 
     def forward(self, x):
-        v = as_nhwc(x, self.data_format)
-        if v.dtype != E.precision() or v.shape[-1] % E.vec(E.precision()):
-            # the RGB image: channels padded to a whole 16-byte chunk (the first conv's packed filter pads with zeros)
-            v = E.nchw_to_nhwc(x if self.data_format == "channels_first" else x.permute(0, 3, 1, 2), E.precision())
-        for m in self.features:
+        feats = list(self.features)
+        first = list(feats[0])
+        if (self.data_format == "channels_first" and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
+                and not x.permute(0, 2, 3, 1).is_contiguous()):
+            # 3x3 / 2 'SAME' stem on the 2x2 space-to-depth image: 2x2 taps over 12 channels, K dense (:354-363)
+            v = first[0].run_stem(x, 2, first[1], first[2].ACT)
+        else:
+            # the RGB image with channels padded to a whole 16-byte chunk (the packed filter pads with zeros)
+            v = feats[0].run_nhwc(E.nchw_to_nhwc(x if self.data_format == "channels_first" else x.permute(0, 3, 1, 2), E.precision()))
+        for m in feats[1:]:
             if isinstance(m, ConvNormActivation):
                 v = m.run_nhwc(v)
             else:

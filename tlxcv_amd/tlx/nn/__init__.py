@@ -446,17 +446,23 @@ class GroupConv2d(Module):
         if self.data_format != "channels_first" or self.n_group != 1 or self.dilation != (1, 1):
             raise NotImplementedError("run_stem: channels_first, dense, undilated convs only")
         sh, sw = self.stride
-        if sh % b or sw % b or sh != sw or self.padding[0] != self.padding[1]:
+        N, Cc, H, W = x_nchw.shape
+        pad, same_hw = self.padding, None
+        if self.same:       # 'SAME' (efficientnet.py:354-363): leading padding for this size; an odd total runs past the end
+            pad, same_hw = self._same(H, W)
+        if sh % b or sw % b or sh != sw or pad[0] != pad[1]:
             raise NotImplementedError("run_stem: stride must be a multiple of the fold")
         dt = E.precision()
-        N, Cc, H, W = x_nchw.shape
-        Ho = (H + 2 * self.padding[0] - self.kernel_size[0]) // sh + 1
-        Wo = (W + 2 * self.padding[1] - self.kernel_size[1]) // sw + 1
+        Ho = (H + 2 * pad[0] - self.kernel_size[0]) // sh + 1
+        Wo = (W + 2 * pad[1] - self.kernel_size[1]) // sw + 1
+        if same_hw is not None:
+            Ho, Wo = same_hw
+            kw = dict(kw, overhang=True)
 
         def build():
-            w2, pad2 = E.s2d_filter(self.filters, b, self.padding[0])
+            w2, pad2 = E.s2d_filter(self.filters, b, pad[0])
             return E.PackedFilter(w2, dt), pad2
-        pk, pad2 = self._cached(("s2d", b), build)
+        pk, pad2 = self._cached(("s2d", b, pad[0]), build)
         if bn is not None:
             scale, shift = self._cached(("bn", id(bn)), lambda: bn.folded(self.biases))
         else:
