@@ -101,18 +101,16 @@ __global__ __launch_bounds__(128) void nchw_to_nhwc_s2d_kernel(const TS* __restr
 // The RGB stem case (b = 2, C = 3, fp32 image, W even): per (channel, row parity) one 8-byte load brings the two
 // horizontal neighbours, six loads per output pixel instead of twelve, consecutive lanes read consecutive 8 bytes.
 template <typename TD>
-__global__ __launch_bounds__(256) void nchw3_to_nhwc_s2d2_kernel(const float* __restrict__ src, TD* __restrict__ dst, int H, int W,
-                                                               int Cpad, long total) {
+__global__ __launch_bounds__(128) void nchw3_to_nhwc_s2d2_kernel(const float* __restrict__ src, TD* __restrict__ dst, int H, int W,
+                                                               int Cpad, int cb) {
     constexpr int V = Chunk<TD>::N;
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;    // output pixel
-    if (i >= total) return;
     const int H2 = H >> 1, W2 = W >> 1;
-    const long row = i / W2;                                  // n*H2 + h2
-    const int w2 = (int)(i - row * W2);
-    const long n = row / H2;
-    const int h2 = (int)(row - n * H2);
+    // one output row (or a 128-pixel piece of it) per workgroup: image / row indices are scalar arithmetic
+    const int row = blockIdx.x / cb, w2 = (blockIdx.x - row * cb) * 128 + threadIdx.x;   // row = n*H2 + h2
+    if (w2 >= W2) return;
+    const int n = row / H2, h2 = row - n * H2;
     const long HW = (long)H * W;
-    const float* sp = src + n * 3 * HW + (long)(2 * h2) * W + 2 * w2;
+    const float* sp = src + (long)n * 3 * HW + (long)(2 * h2) * W + 2 * w2;
     float v16[16];
 #pragma unroll
     for (int e = 12; e < 16; ++e) v16[e] = 0.f;
@@ -124,7 +122,7 @@ __global__ __launch_bounds__(256) void nchw3_to_nhwc_s2d2_kernel(const float* __
             v16[(ph * 2 + 0) * 3 + c] = t.x;
             v16[(ph * 2 + 1) * 3 + c] = t.y;
         }
-    TD* dp = dst + i * Cpad;
+    TD* dp = dst + ((long)row * W2 + w2) * Cpad;
 #pragma unroll
     for (int cg = 0; cg < 16 / V; ++cg) Chunk<TD>::store(dp + cg * V, v16 + cg * V);
 }
@@ -162,14 +160,13 @@ __global__ void maxpool_kernel(const T* __restrict__ x, T* __restrict__ y, int N
                                int y_ld, int R, int S, int sh, int sw, int ph, int pw, int Ho, int Wo) {
     constexpr int V = Chunk<T>::N;
     const int nch = C / V;
-    const long total = (long)N * Ho * Wo * nch;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int cg = (int)(i % nch);
-        long p = i / nch;
-        const int wo = (int)(p % Wo);
-        p /= Wo;
-        const int ho = (int)(p % Ho);
-        const long n = p / Ho;
+    // one output row per workgroup column (scalar image / row index), threads split (pixel, channel chunk) in 32 bits
+    const int per_row = Wo * nch, bx = (per_row + 255) / 256;
+    const int row = blockIdx.x / bx, idx = (blockIdx.x - row * bx) * 256 + threadIdx.x;
+    if (idx < per_row) {
+        const int wo = idx / nch, cg = idx - wo * nch;
+        const long n = row / Ho;
+        const int ho = row - (int)n * Ho;
         float m[V];
 #pragma unroll
         for (int e = 0; e < V; ++e) m[e] = -INFINITY;
@@ -655,10 +652,8 @@ extern "C" int tlxmi_nchw_to_nhwc_s2d(const void* src, int sdt, void* dst, int d
     dim3 g((unsigned)blocks), blk(128);
     hipStream_t st = as_stream(stream);
     if (sdt == TLXMI_F32 && b == 2 && C == 3 && Cpad == 16 && W % 2 == 0 && ((uintptr_t)src % 8) == 0) {
-        const long total = (long)N * (H / 2) * (W / 2);
-        const dim3 g2((unsigned)((total + 255) / 256));
-        if (ddt == TLXMI_F16) hipLaunchKernelGGL((nchw3_to_nhwc_s2d2_kernel<half_t>), g2, dim3(256), 0, st, (const float*)src, (half_t*)dst, H, W, Cpad, total);
-        else hipLaunchKernelGGL((nchw3_to_nhwc_s2d2_kernel<float>), g2, dim3(256), 0, st, (const float*)src, (float*)dst, H, W, Cpad, total);
+        if (ddt == TLXMI_F16) hipLaunchKernelGGL((nchw3_to_nhwc_s2d2_kernel<half_t>), g, blk, 0, st, (const float*)src, (half_t*)dst, H, W, Cpad, cb);
+        else hipLaunchKernelGGL((nchw3_to_nhwc_s2d2_kernel<float>), g, blk, 0, st, (const float*)src, (float*)dst, H, W, Cpad, cb);
         return check_launch("nchw_to_nhwc_s2d");
     }
     if (sdt == TLXMI_F32 && ddt == TLXMI_F16)
@@ -719,8 +714,9 @@ extern "C" int tlxmi_maxpool2d(const void* x, void* y, int dt, int N, int H, int
     TLXMI_REQUIRE(ph < R && pw < S, TLXMI_ERR_BAD_ARG, "maxpool2d: padding must be smaller than the window");
     TLXMI_REQUIRE(Ho == (H + 2 * ph - R) / sh + 1 && Wo == (W + 2 * pw - S) / sw + 1, TLXMI_ERR_BAD_ARG,
                   "maxpool2d: output extent mismatch");
-    const long work = (long)N * Ho * Wo * (C / VECN(dt));
-    dim3 g(grid_for(work)), b(256);
+    const long mp_blocks = (long)N * Ho * (((long)Wo * (C / VECN(dt)) + 255) / 256);
+    TLXMI_REQUIRE(mp_blocks < (1l << 31), TLXMI_ERR_UNSUPPORTED, "maxpool2d: too many rows");
+    dim3 g((unsigned)mp_blocks), b(256);
     if (dt == TLXMI_F16)
         hipLaunchKernelGGL((maxpool_kernel<half_t>), g, b, 0, as_stream(stream), (const half_t*)x, (half_t*)y, N, H, W, C, x_ld, y_ld, R, S, sh, sw, ph, pw, Ho, Wo);
     else
