@@ -290,3 +290,20 @@ def test_split_attention_and_radix_gap(dev, dtype, cfg):
     torch.cuda.synchronize()
     torch.testing.assert_close(got_gap.float().cpu(), want_gap, **tol(dtype))
     torch.testing.assert_close(engine_to_nchw(got), want, **tol(dtype))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["fp32", "fp16"])
+@pytest.mark.parametrize("shape,b", [((2, 3, 224, 224), 16), ((1, 3, 64, 96), 4), ((3, 3, 32, 48), 16), ((1, 5, 24, 24), 4),
+                                     ((1, 3, 384, 384), 16)], ids=lambda v: "x".join(map(str, v)) if isinstance(v, tuple) else str(v))
+def test_patch_space_to_depth_fold(dev, dtype, shape, b):
+    """tlxmi_nchw_to_nhwc_s2d for the patch-embedding folds (vision_transformer.py:197-220 b = 16, swin_transformer.py:490 b = 4):
+    channel (ph*b + pw)*C + c of output pixel (h2, w2) = x[n, c, b*h2 + ph, b*w2 + pw]; padding channels are zero."""
+    N, Cc, H, W = shape
+    g = torch.Generator().manual_seed(61)
+    x = torch.randn(shape, generator=g)
+    want = x.view(N, Cc, H // b, b, W // b, b).permute(0, 2, 4, 3, 5, 1).reshape(N, H // b, W // b, b * b * Cc)
+    got = E.nchw_to_nhwc_s2d(x.to(dev), b, dtype)
+    torch.cuda.synchronize()
+    assert got.shape[:3] == (N, H // b, W // b) and got.shape[3] >= b * b * Cc
+    torch.testing.assert_close(got[..., :b * b * Cc].float().cpu(), want.to(dtype).float(), atol=0, rtol=0)
+    assert (got[..., b * b * Cc:] == 0).all()

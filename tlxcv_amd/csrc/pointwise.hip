@@ -98,6 +98,40 @@ __global__ __launch_bounds__(128) void nchw_to_nhwc_s2d_kernel(const TS* __restr
     }
 }
 
+// Large folds (b = 16 patch embedding of ViT, b = 4 of Swin): one workgroup per output row of patches.  The b input rows of
+// every channel are read with consecutive lanes on consecutive floats (the per-pixel kernel above reads 4-byte elements
+// b floats apart), the folded row is assembled in LDS and leaves as whole 16-byte chunks.
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_s2d_rows_kernel(const TS* __restrict__ src, TD* __restrict__ dst, int C, int H,
+                                                                  int W, int b, int Cpad) {
+    extern __shared__ __attribute__((aligned(16))) char s2d_smem[];
+    TD* tile = reinterpret_cast<TD*>(s2d_smem);            // [W2][Cpad]
+    const int H2 = H / b, W2 = W / b;
+    const int row = blockIdx.x, n = row / H2, h2 = row - n * H2;
+    const long HW = (long)H * W;
+    const int Cs = b * b * C;
+    // zero the padding channels once
+    for (int i = threadIdx.x; i < W2 * (Cpad - Cs); i += 256) {
+        const int px = i / (Cpad - Cs), c = Cs + i - px * (Cpad - Cs);
+        tile[px * Cpad + c] = (TD)0.f;
+    }
+    const TS* sp = src + (long)n * C * HW + (long)(h2 * b) * W;
+    for (int cp = 0; cp < C * b; ++cp) {                   // (channel, row inside the patch): W consecutive floats each
+        const int c = cp / b, ph = cp - c * b;
+        const TS* rp = sp + c * HW + (long)ph * W;
+        for (int w = threadIdx.x; w < W; w += 256) {
+            const int px = w / b, pw = w - px * b;
+            tile[px * Cpad + (ph * b + pw) * C + c] = (TD)(float)rp[w];
+        }
+    }
+    __syncthreads();
+    constexpr int V = Chunk<TD>::N;
+    const int nchunk = W2 * Cpad / V;
+    const u32x4* tv = reinterpret_cast<const u32x4*>(tile);
+    u32x4* dv = reinterpret_cast<u32x4*>(dst + (long)row * W2 * Cpad);
+    for (int i = threadIdx.x; i < nchunk; i += 256) dv[i] = tv[i];
+}
+
 // The RGB stem case (b = 2, C = 3, fp32 image, W even): per (channel, row parity) one 8-byte load brings the two
 // horizontal neighbours, six loads per output pixel instead of twelve, consecutive lanes read consecutive 8 bytes.
 template <typename TD>
@@ -655,6 +689,21 @@ extern "C" int tlxmi_nchw_to_nhwc_s2d(const void* src, int sdt, void* dst, int d
         if (ddt == TLXMI_F16) hipLaunchKernelGGL((nchw3_to_nhwc_s2d2_kernel<half_t>), g, blk, 0, st, (const float*)src, (half_t*)dst, H, W, Cpad, cb);
         else hipLaunchKernelGGL((nchw3_to_nhwc_s2d2_kernel<float>), g, blk, 0, st, (const float*)src, (float*)dst, H, W, Cpad, cb);
         return check_launch("nchw_to_nhwc_s2d");
+    }
+    {
+        const size_t lds = (size_t)(W / b) * Cpad * elt_size(ddt);
+        if (b >= 4 && lds <= 64 * 1024) {
+            const dim3 gr((unsigned)((long)N * (H / b)));
+            if (sdt == TLXMI_F32 && ddt == TLXMI_F16)
+                hipLaunchKernelGGL((nchw_to_nhwc_s2d_rows_kernel<float, half_t>), gr, dim3(256), lds, st, (const float*)src, (half_t*)dst, C, H, W, b, Cpad);
+            else if (sdt == TLXMI_F32 && ddt == TLXMI_F32)
+                hipLaunchKernelGGL((nchw_to_nhwc_s2d_rows_kernel<float, float>), gr, dim3(256), lds, st, (const float*)src, (float*)dst, C, H, W, b, Cpad);
+            else if (sdt == TLXMI_F16 && ddt == TLXMI_F16)
+                hipLaunchKernelGGL((nchw_to_nhwc_s2d_rows_kernel<half_t, half_t>), gr, dim3(256), lds, st, (const half_t*)src, (half_t*)dst, C, H, W, b, Cpad);
+            else
+                hipLaunchKernelGGL((nchw_to_nhwc_s2d_rows_kernel<half_t, float>), gr, dim3(256), lds, st, (const half_t*)src, (float*)dst, C, H, W, b, Cpad);
+            return check_launch("nchw_to_nhwc_s2d");
+        }
     }
     if (sdt == TLXMI_F32 && ddt == TLXMI_F16)
         hipLaunchKernelGGL((nchw_to_nhwc_s2d_kernel<float, half_t>), g, blk, 0, st, (const float*)src, (half_t*)dst, N, C, H, W, b, Cpad, cb);
