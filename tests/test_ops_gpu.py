@@ -307,3 +307,17 @@ def test_patch_space_to_depth_fold(dev, dtype, shape, b):
     assert got.shape[:3] == (N, H // b, W // b) and got.shape[3] >= b * b * Cc
     torch.testing.assert_close(got[..., :b * b * Cc].float().cpu(), want.to(dtype).float(), atol=0, rtol=0)
     assert (got[..., b * b * Cc:] == 0).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["fp32", "fp16"])
+@pytest.mark.parametrize("shape", [(3, 40, 7, 9), (2, 96, 28, 28), (1, 8, 1, 1)], ids=lambda s: "x".join(map(str, s)))
+def test_scale_channels(dev, dtype, shape):
+    """Squeeze-Excitation gate (mobilenetv3.py:47-56, efficientnet.py:176-178): y[n, c, h, w] = x[n, c, h, w] * s[n, c]."""
+    N, Cc, H, W = shape
+    rng = np.random.default_rng(67)
+    x, sc = rnd(rng, (N, Cc, H, W)), rnd(rng, (N, Cc))
+    if dtype == torch.float16:
+        x, sc = q16(x), q16(sc)
+    got = E.scale_channels(nchw_to_engine(x, dtype, dev), sc.to(dtype).to(dev))
+    torch.cuda.synchronize()
+    torch.testing.assert_close(engine_to_nchw(got), x * sc[:, :, None, None], **tol(dtype))

@@ -570,11 +570,14 @@ __global__ void scale_channels_kernel(const T* __restrict__ x, const T* __restri
                                       int HW, int C, int x_ld, int s_ld, int y_ld) {
     constexpr int V = Chunk<T>::N;
     const int nch = C / V;
-    const long total = (long)N * HW * nch;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int cg = (int)(i % nch);
-        const long p = i / nch;
-        const long n = p / HW;
+    // the image index comes from the block index (scalar); a thread splits its position inside the image in 32 bits
+    const long per_img = (long)HW * nch;
+    const int bx = (int)((per_img + 255) / 256);
+    const long n = blockIdx.x / bx;
+    const long idx = (long)(blockIdx.x - n * bx) * 256 + threadIdx.x;
+    if (idx < per_img) {
+        const int pl = (int)idx / nch, cg = (int)idx - pl * nch;
+        const long p = n * HW + pl;
         float xv[V], sv[V];
         Chunk<T>::load(x + p * x_ld + cg * V, xv);
         Chunk<T>::load(s + n * s_ld + cg * V, sv);
@@ -938,8 +941,11 @@ extern "C" int tlxmi_scale_channels(const void* x, const void* sc, void* y, int 
     TLXMI_REQUIRE(x && sc && y && N > 0 && HW > 0, TLXMI_ERR_BAD_ARG, "scale_channels: bad argument");
     REQUIRE_CHUNKED("scale_channels", dt, C, x_ld, s_ld, y_ld);
     TLXMI_REQUIRE(aligned16(x) && aligned16(sc) && aligned16(y), TLXMI_ERR_ALIGNMENT, "scale_channels: buffers must be 16-byte aligned");
-    const long work = (long)N * HW * (C / VECN(dt));
-    dim3 g(grid_for(work)), b(256);
+    const long sc_per_img = (long)HW * (C / VECN(dt));
+    TLXMI_REQUIRE(sc_per_img < (1l << 31), TLXMI_ERR_UNSUPPORTED, "scale_channels: image too large");
+    const long sc_blocks = (long)N * ((sc_per_img + 255) / 256);
+    TLXMI_REQUIRE(sc_blocks < (1l << 31), TLXMI_ERR_UNSUPPORTED, "scale_channels: too many blocks");
+    dim3 g((unsigned)sc_blocks), b(256);
     if (dt == TLXMI_F16)
         hipLaunchKernelGGL((scale_channels_kernel<half_t>), g, b, 0, as_stream(stream), (const half_t*)x, (const half_t*)sc, (half_t*)y, N, HW, C, x_ld, s_ld, y_ld);
     else
