@@ -152,6 +152,17 @@ int tlxmi_group_conv2d(const tlxmi_conv2d_desc* d, int groups, const void* x, co
                        const float* scale, const float* shift, const void* res, void* y, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * nn.Linear with few rows and a large filter — the classifier heads: resnet.py:234-237, vgg.py:42-50 (25088 -> 4096),
+ * alexnet.py:162-168, vision_transformer.py:333.  K is cut into `splits` slices that run side by side (K % splits == 0,
+ * (K/splits)*elt % 128 == 0); `partials` is a caller-owned scratch of splits*rows*Cout elements of dtype; the partial
+ * sums are added in slice order (deterministic), then y = act((sum)*scale + shift (+res)) as tlxmi_conv2d.
+ * w_packed: tlxmi_pack_filter of the [Cout][K] weight (1x1).
+ * ---------------------------------------------------------------------------------------- */
+int tlxmi_linear_splitk(int dtype, int64_t rows, int K, int Cout, int x_ld, const void* x, const void* w_packed,
+                        int splits, void* partials, const float* scale, const float* shift, const void* res,
+                        int res_ld, int act, float act_param, uint32_t flags, void* y, int y_ld, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Depthwise conv (groups == C == Cout), HBM-bound, no MFMA.
  * Replaces nn.GroupConv2d(n_group=C)+BN+act: mobilenetv1.py:79-88, mobilenetv2.py:30,
  * mobilenetv3.py (k3/k5).   w: [R][S][C] dtype.

@@ -149,3 +149,35 @@ def test_row_stats(dev):
     rstd = 1.0 / torch.sqrt(x.var(1, unbiased=False) + 1e-5)
     torch.testing.assert_close(stats[:, 0].cpu(), rstd, atol=1e-5, rtol=1e-5)
     torch.testing.assert_close(stats[:, 1].cpu(), -mean * rstd, atol=1e-5, rtol=1e-5)
+
+
+# ---- classifier heads: few rows, large filter -> K slices side by side + deterministic reduction (tlxmi_linear_splitk)
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32], ids=["fp16", "fp32"])
+@pytest.mark.parametrize("shape,act,res", [((64, 25088, 512), E.ACT_RELU, False), ((256, 4096, 1000), E.ACT_NONE, False),
+                                           ((4, 4096, 4096), E.ACT_RELU, False), ((130, 9216, 520), E.ACT_NONE, True),
+                                           ((1, 8192, 1000), E.ACT_NONE, False)], ids=lambda v: str(v).replace(" ", ""))
+def test_linear_splitk(dev, dtype, shape, act, res):
+    M, K, Cout = shape
+    rng = np.random.default_rng(71)
+    x = rnd(rng, (M, K))
+    w = rnd(rng, (Cout, K), (1.0 / K) ** 0.5)
+    b = rnd(rng, (Cout,), 0.2)
+    r = rnd(rng, (M, Cout)) if res else None
+    if dtype == torch.float16:
+        x, w = q16(x), q16(w)
+        r = q16(r) if r is not None else None
+    want = x @ w.t() + b
+    if r is not None:
+        want = want + r
+    if act == E.ACT_RELU:
+        want = torch.relu(want)
+    pk = E.PackedFilter(w.to(dev), dtype)
+    xd = x.to(dtype).to(dev)
+    assert E._linear_splits(M, K, pk, xd) >= 2          # the shapes above take the split path
+    got = E.linear(xd, pk, b.to(dev), r.to(dtype).to(dev) if r is not None else None, act)
+    got2 = E.linear(xd, pk, b.to(dev), r.to(dtype).to(dev) if r is not None else None, act)
+    torch.cuda.synchronize()
+    assert torch.equal(got, got2)                         # fixed summation order
+    # partial sums are stored in the working dtype: fp16 adds one rounding per slice
+    t = dict(atol=1e-4, rtol=1e-4) if dtype == torch.float32 else dict(atol=6e-3, rtol=6e-3)
+    torch.testing.assert_close(got.float().cpu(), want, **t)

@@ -43,6 +43,7 @@ PROTOTYPES = {
     "tlxmi_pack_filter": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     "tlxmi_fold_bn": [_vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp],
     "tlxmi_conv2d": [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "tlxmi_linear_splitk": [_i, _l, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _u, _vp, _i, _vp],
     "tlxmi_group_conv2d": [C.POINTER(ConvDesc), _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "tlxmi_pack_group_filter": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "tlxmi_dwconv2d": [C.POINTER(DwConvDesc), _vp, _vp, _vp, _vp, _vp, _vp],

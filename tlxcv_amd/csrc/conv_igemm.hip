@@ -30,6 +30,7 @@
 #include "gemm256.h"
 #include "conv_halo.h"
 #include <stdlib.h>
+#include <string.h>
 
 namespace tlxmi {
 
@@ -805,8 +806,11 @@ using namespace tlxmi;
 
 // nchunk launch chunks of (C / nchunk) -> (Cout / nchunk) channels each; nchunk == 1: the dense convolution
 // diag32: the filter of every chunk is block-diagonal at a granularity that divides 32 channels (in == out per group)
+// ksplit: the nchunk launch chunks are K slices of ONE dense GEMM (tlxmi_linear_splitk): chunk g reads input channels
+// [g*C/nchunk, (g+1)*C/nchunk) of x and of every packed filter row and writes its partial sums to y + g * ksplit_ystride.
 static int conv2d_impl(const tlxmi_conv2d_desc* d, int nchunk, const void* x, const void* w_packed,
-                       const float* scale, const float* shift, const void* res, void* y, void* stream, bool diag32 = false) {
+                       const float* scale, const float* shift, const void* res, void* y, void* stream, bool diag32 = false,
+                       bool ksplit = false, long long ksplit_ystride = 0) {
     TLXMI_REQUIRE(d && x && w_packed && y, TLXMI_ERR_BAD_ARG, "conv2d: null descriptor or buffer");
     TLXMI_REQUIRE(d->dtype == TLXMI_F16 || d->dtype == TLXMI_F32, TLXMI_ERR_BAD_ARG, "conv2d: bad dtype %d", d->dtype);
     TLXMI_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->C > 0 && d->Cout > 0 && d->R > 0 && d->S > 0,
@@ -838,7 +842,7 @@ static int conv2d_impl(const tlxmi_conv2d_desc* d, int nchunk, const void* x, co
     ConvArgs a;
     a.x = (const char*)x; a.w = (const char*)w_packed; a.y = (char*)y;
     a.scale = scale; a.shift = shift; a.res = (const char*)res;
-    const int cw_in = d->C / nchunk, cw_out = d->Cout / nchunk;   // channels of one launch chunk
+    const int cw_in = d->C / nchunk, cw_out = ksplit ? d->Cout : d->Cout / nchunk;   // channels of one launch chunk
     a.N = d->N; a.H = d->H; a.W = d->W; a.C = cw_in; a.Cout = cw_out; a.R = d->R; a.S = d->S;
     a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_h; a.pw = d->pad_w; a.dh = d->dil_h; a.dw = d->dil_w;
     a.Ho = d->Ho; a.Wo = d->Wo; a.x_ld = d->x_ld; a.y_ld = d->y_ld; a.res_ld = res ? d->res_ld : 0;
@@ -859,12 +863,23 @@ static int conv2d_impl(const tlxmi_conv2d_desc* d, int nchunk, const void* x, co
         a.y_bytes = yb < (1ll << 31) ? (unsigned)yb : 0u;
         a.store_policy = (a.y_bytes && !d->y_nstride) ? pol : 0;
     }
+    if (ksplit) {      // the packed rows keep the pitch of the whole K; a chunk walks its slice of them
+        const int kc_all = d->R * d->S * (d->C * es / 16);
+        a.Kp_bytes = (kc_all + 7) / 8 * 128;
+    }
     a.w_bytes = (unsigned)(((size_t)(cw_out + 127) / 128 * 128) * (size_t)a.Kp_bytes);
     a.nchunk = nchunk;
     a.gx = nchunk > 1 ? cw_in * es : 0;
     a.gy = a.gres = nchunk > 1 ? cw_out * es : 0;
     a.gc = nchunk > 1 ? cw_out : 0;
     a.gw = nchunk > 1 ? a.w_bytes : 0u;
+    if (ksplit) {
+        a.gw = (unsigned)(cw_in * es);
+        a.gy = (int)ksplit_ystride;
+        a.gres = 0;
+        a.gc = 0;
+        a.y_bytes = (unsigned)(ksplit_ystride * nchunk);     // the whole partial buffer: chunk g sees what is left after its offset
+    }
     a.diag = diag32 && es == 2 && cw_in == 64 && cw_out == 64 ? 1 : 0;
     a.overhang = overhang ? 1 : 0;
     const int vecn = 16 / es;  // elements per 16 bytes
@@ -947,6 +962,70 @@ extern "C" int tlxmi_group_conv2d(const tlxmi_conv2d_desc* d, int groups, const 
     TLXMI_REQUIRE((d->y_ld * (int)elt_size(d->dtype)) % 16 == 0, TLXMI_ERR_ALIGNMENT, "group_conv2d: y_ld=%d", d->y_ld);
     const int cgi = d->C / groups, cgo = d->Cout / groups;
     return conv2d_impl(d, nchunk, x, w_packed, scale, shift, res, y, stream, cgi == cgo && 32 % cgi == 0);
+}
+
+// ------------------------------------------------------------------------------------------
+// Linear layers with few rows and a large filter (the classifier heads: resnet.py:234-237, vgg.py:42-50 25088 -> 4096,
+// alexnet.py fc6-8): with M <= a few hundred rows the GEMM has only M/64 x Cout/64 tiles, each walking all of K in
+// sequence — the filter streams from HBM at a fraction of the bandwidth (measured 0.74 TB/s on VGG's fc1).  Here K is
+// cut into `splits` slices that run as the launch chunks of the implicit GEMM (blockIdx.y; `splits` x more tiles in
+// flight), each writing its partial sums, and a small second kernel adds them in slice order (deterministic), applies
+// scale / shift / residual / activation and stores.
+// ------------------------------------------------------------------------------------------
+namespace tlxmi {
+template <typename T>
+__global__ void splitk_reduce_kernel(const T* __restrict__ part, int splits, long rows, int Cout, long pstride, const float* __restrict__ scale,
+                                     const float* __restrict__ shift, const T* __restrict__ res, int res_ld, int act, float act_param,
+                                     unsigned flags, T* __restrict__ y, int y_ld) {
+    const long total = rows * Cout;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long m = i / Cout;
+        const int n = (int)(i - m * Cout);
+        float v = 0.f;
+        for (int g = 0; g < splits; ++g) v += (float)part[g * pstride + i];
+        if (scale) v *= scale[n];
+        if (shift) v += shift[n];
+        const bool res_after = (flags & TLXMI_EPI_RES_AFTER_ACT) != 0;
+        const float r = res ? (float)res[m * res_ld + n] : 0.f;
+        if (res && !res_after) v += r;
+        v = apply_act(v, act, act_param);
+        if (res && res_after) v += r;
+        y[m * y_ld + n] = (T)v;
+    }
+}
+}  // namespace tlxmi
+
+extern "C" int tlxmi_linear_splitk(int dtype, int64_t rows, int K, int Cout, int x_ld, const void* x, const void* w_packed,
+                                   int splits, void* partials, const float* scale, const float* shift, const void* res,
+                                   int res_ld, int act, float act_param, uint32_t flags, void* y, int y_ld, void* stream) {
+    TLXMI_REQUIRE(x && w_packed && y && partials, TLXMI_ERR_BAD_ARG, "linear_splitk: null buffer");
+    TLXMI_REQUIRE(dtype == TLXMI_F16 || dtype == TLXMI_F32, TLXMI_ERR_BAD_ARG, "linear_splitk: bad dtype %d", dtype);
+    TLXMI_REQUIRE(rows > 0 && rows < (1ll << 24) && K > 0 && Cout > 0 && x_ld >= K && y_ld >= Cout && splits >= 2 && splits <= 256, TLXMI_ERR_BAD_ARG,
+                  "linear_splitk: bad extent");
+    TLXMI_REQUIRE(act >= TLXMI_ACT_NONE && act <= TLXMI_ACT_SILU, TLXMI_ERR_BAD_ARG, "linear_splitk: bad act %d", act);
+    TLXMI_REQUIRE(!res || res_ld >= Cout, TLXMI_ERR_BAD_ARG, "linear_splitk: res_ld=%d < Cout", res_ld);
+    const int es = (int)elt_size(dtype);
+    TLXMI_REQUIRE(K % splits == 0 && ((K / splits) * es) % 128 == 0, TLXMI_ERR_ALIGNMENT,
+                  "linear_splitk: K=%d must split into %d slices of whole 128-byte K tiles", K, splits);
+    const long long pstride = (long long)rows * Cout;          // elements between the partial sums of consecutive slices
+    TLXMI_REQUIRE(pstride * es * splits < (1ll << 31) && aligned16(partials) && (Cout * es) % 16 == 0, TLXMI_ERR_UNSUPPORTED,
+                  "linear_splitk: partial buffer of %lld bytes per slice", pstride * es);
+    tlxmi_conv2d_desc d;
+    memset(&d, 0, sizeof d);
+    d.dtype = dtype; d.N = (int)rows; d.H = d.W = 1; d.C = K; d.Cout = Cout; d.R = d.S = 1;
+    d.stride_h = d.stride_w = d.dil_h = d.dil_w = 1; d.Ho = d.Wo = 1;
+    d.x_ld = x_ld; d.y_ld = Cout; d.act = TLXMI_ACT_NONE;
+    const int rc = conv2d_impl(&d, splits, x, w_packed, nullptr, nullptr, nullptr, partials, stream, false, true, pstride * es);
+    if (rc != TLXMI_OK) return rc;
+    const long total = (long)rows * Cout;
+    const unsigned grid = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if (dtype == TLXMI_F16)
+        hipLaunchKernelGGL((splitk_reduce_kernel<half_t>), dim3(grid), dim3(256), 0, as_stream(stream), (const half_t*)partials, splits, (long)rows, Cout,
+                           (long)pstride, scale, shift, (const half_t*)res, res_ld, act, act_param, flags, (half_t*)y, y_ld);
+    else
+        hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3(grid), dim3(256), 0, as_stream(stream), (const float*)partials, splits, (long)rows, Cout,
+                           (long)pstride, scale, shift, (const float*)res, res_ld, act, act_param, flags, (float*)y, y_ld);
+    return check_launch("linear_splitk");
 }
 
 // LayerNorm + Linear in one launch (vision_transformer.py:144-159 norm1 -> attn.qkv, norm2 -> mlp.fc1;

@@ -208,6 +208,9 @@ def fold_bn(gamma, beta, mean, var, eps, conv_bias=None):
 # ---------------------------------------------------------------------------------------------
 # conv / linear
 # ---------------------------------------------------------------------------------------------
+_cus = {}
+
+
 def _pair(v):
     return (v, v) if isinstance(v, int) else (int(v[0]), int(v[1]))
 
@@ -317,11 +320,40 @@ def linear(x, pk, bias=None, res=None, act=ACT_NONE, out=None):
     o4 = None
     if out is not None:
         o4 = out.view(rows, 1, 1, pk.Cout)
+    splits = _linear_splits(rows, shp[-1], pk, x) if (out is None and _probe is None and pk.R == 1 and pk.S == 1) else 0
+    if splits:
+        # few rows, large filter (classifier heads): K slices side by side + a deterministic reduction (tlxmi_linear_splitk)
+        part = torch.empty((splits, rows, pk.Cout), dtype=x.dtype, device=x.device)
+        y = torch.empty((rows, pk.Cout), dtype=x.dtype, device=x.device)
+        _lib.call("tlxmi_linear_splitk", dt_code(x.dtype), rows, shp[-1], pk.Cout, shp[-1], _p(x), _p(pk.buf), splits, _p(part),
+                  None, _p(bias), _p(res), pk.Cout if res is not None else 0, act, C.c_float(0.0), 0, _p(y), pk.Cout, _stream())
+        return y.view(*shp[:-1], pk.Cout)
     y = conv2d(x4, pk, shift=bias, res=r4, act=act, out=o4)
     return y.view(*shp[:-1], pk.Cout)
 
 
-_cus = {}
+def _linear_splits(rows, K, pk, x):
+    """Number of K slices for a Linear with few rows (0: run it as one GEMM).  TLXMI_SPLITK=0 turns the path off (A/B)."""
+    if os.environ.get("TLXMI_SPLITK", "1") == "0" or rows > 512 or pk.Cin != K or pk.Cin_pad != K:
+        return 0
+    es = x.element_size()
+    if K * es < 8192 or pk.Cout * K * es < 8000000 or (pk.Cout * es) % 16:      # a filter of >= 8 MB with K >= 4096 (fp16)
+        return 0
+    idx = x.device.index if x.device.index is not None else torch.cuda.current_device()
+    if idx not in _cus:
+        _cus[idx] = torch.cuda.get_device_properties(idx).multi_processor_count
+    tiles = ((rows + 63) // 64) * ((pk.Cout + 63) // 64)
+    kt = K * es // 128                      # K tiles of 128 bytes
+    best = 0
+    for s_ in range(2, 65):
+        if kt % s_ or kt // s_ < 4:         # at least 4 K tiles per slice: the partial sums stay a small share of the traffic
+            continue
+        best = s_
+        if tiles * s_ >= 3 * _cus[idx]:
+            break
+    if best and rows * pk.Cout * es * best >= (1 << 31):
+        return 0
+    return best
 
 
 def linear_ln_supported(K, Cout, dtype, rows=None, device=None):
