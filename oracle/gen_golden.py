@@ -6,11 +6,14 @@ For each torch-capable reference model file it
   2. fills it and the restatement (oracle/functional.py) from the same seeded numpy recipe;
   3. requires restatement == reference graph (max abs diff <= 1e-5, same argmax);
   4. writes a small fixture: recipe ids + expected fp32 logits + argmax.
-Paddle-only reference files (swin, mobilenetv2/v3) cannot be imported; their fixtures come from the
-restatement alone and are marked `pinned_by="restatement-only"`.
+The Paddle-converted files (swin_transformer.py, mobilenetv2.py, mobilenetv3.py) and detection/yolov3.py are loaded the
+same way — unmodified, by path — with the packages they hard-import and this image lacks (paddle, paddle2tlx,
+decorator, torchvision) resolved to the small import shims of oracle/shims/ (README there lists what each provides).
 
-    python -m oracle.gen_golden            # writes tests/golden/
+    python -m oracle.gen_golden            # writes every fixture of tests/golden/
+    python -m oracle.gen_golden swin yolo  # only the fixtures whose file name contains one of the words
 """
+import importlib
 import importlib.util
 import os
 import sys
@@ -27,21 +30,62 @@ from oracle import functional as OF  # noqa: E402
 from tlxcv_amd import seeded  # noqa: E402
 
 
-def import_reference(relpath, modname):
-    """Load one reference source file by path with tensorlayerx -> oracle.tlx_cpu."""
+SHIMS = os.path.join(REPO, "oracle", "shims")
+_TLX_KEYS = ("tensorlayerx", "tensorlayerx.nn", "tensorlayerx.ops", "tensorlayerx.nn.initializers", "tensorlayerx.initializers")
+_SHIM_KEYS = ("paddle", "paddle2tlx", "paddle2tlx.pd2tlx", "paddle2tlx.pd2tlx.ops", "paddle2tlx.pd2tlx.ops.tlxops",
+              "paddle2tlx.pd2tlx.utils", "decorator", "torchvision", "torchvision.ops",
+              # mobilenetv2.py:6-7 / mobilenetv3.py:10-11 import their siblings as TOP-LEVEL packages (`from utils.common_func
+              # import ...`, `from ops.ops_fusion import ...`): they resolve with the classification directory on sys.path
+              "utils", "utils.common_func", "ops", "ops.ops_fusion", "ops.theseus_layer")
+
+
+def import_reference(relpath, modname, paddle=False, package=None):
+    """Load one reference source file UNMODIFIED, by path, with `tensorlayerx` resolved to the oracle's torch-CPU
+    stand-in (oracle/tlx_cpu).  paddle=True: the file is one of the Paddle-converted ones — `paddle`, `paddle2tlx`,
+    `decorator`, `torchvision` resolve to oracle/shims/ (see its README) and the functions of the stand-in return
+    PdTensor (Paddle tensor-method spellings, oracle/tlx_cpu/pd.py).  package=(name, dir): load the file as module
+    `name.<stem>` of a synthetic parent package rooted at `dir`, so its relative imports resolve against the reference
+    tree without running the parent's __init__ (detection/__init__.py pulls detr / ssd / ppyoloe)."""
+    import types
     import oracle.tlx_cpu as tlx_cpu
-    saved = {k: sys.modules.get(k) for k in ("tensorlayerx", "tensorlayerx.nn", "tensorlayerx.ops",
-                                             "tensorlayerx.nn.initializers")}
-    sys.modules["tensorlayerx"] = tlx_cpu
+    from oracle.tlx_cpu import pd
+    saved = {k: sys.modules.get(k) for k in _TLX_KEYS + _SHIM_KEYS}
+    saved_path = list(sys.path)
+    tlx = tlx_cpu
+    ops = tlx_cpu.ops
+    if paddle:
+        ops = pd.pd_module(tlx_cpu.ops, "tensorlayerx.ops")
+        tlx = pd.pd_module(tlx_cpu, "tensorlayerx", ops=ops, arange=ops.arange, stack=ops.stack)
+    for k in _SHIM_KEYS:
+        sys.modules.pop(k, None)
+    sys.modules["tensorlayerx"] = tlx
     sys.modules["tensorlayerx.nn"] = tlx_cpu.nn
-    sys.modules["tensorlayerx.ops"] = tlx_cpu.ops
+    sys.modules["tensorlayerx.ops"] = ops
     sys.modules["tensorlayerx.nn.initializers"] = tlx_cpu.nn.initializers
+    sys.modules["tensorlayerx.initializers"] = tlx_cpu.nn.initializers
+    sys.path.insert(0, SHIMS)
+    sys.path.insert(0, os.path.join(REF, "tlxcv", "models", "classification"))
+    created = []
     try:
+        if package is not None:
+            pname, pdir = package
+            parent = types.ModuleType(pname)
+            parent.__path__ = [os.path.join(REF, pdir)]
+            parent.__package__ = pname
+            sys.modules[pname] = parent
+            created.append(pname)
+            stem = os.path.splitext(os.path.basename(relpath))[0]
+            mod = importlib.import_module(f"{pname}.{stem}")
+            created += [k for k in sys.modules if k.startswith(pname + ".")]
+            return mod
         spec = importlib.util.spec_from_file_location(modname, os.path.join(REF, relpath))
         mod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(mod)
         return mod
     finally:
+        sys.path[:] = saved_path
+        for k in created:
+            sys.modules.pop(k, None)
         for k, v in saved.items():
             if v is None:
                 sys.modules.pop(k, None)
@@ -230,78 +274,97 @@ def gen_darknet(batch, hw, wseed, xseed, fname):
 
 
 def gen_yolov3(batch, hw, wseed, xseed, fname):
-    """yolov3.py cannot be imported by path (relative imports into utils/ops.py -> decorator, torchvision):
-    backbone pinned above, neck + head fixture is restatement-only."""
-    from tlxcv_amd import models
-    m = models.YOLOv3()
-    shapes = seeded.shapes_of(m)
+    """detection/yolov3.py loaded unmodified as a module of a synthetic parent package (its relative imports resolve
+    against the reference tree; `decorator` / `torchvision` from oracle/shims).  YOLOv3.forward (yolov3.py:51-104) is
+    followed by hand up to the head outputs — backbone, neck, yolo_head of the reference's own model object — because
+    the next line, post_process, needs `yolo_box_func`, which is None off Paddle (detection/utils/ops.py:436-452)."""
+    ref = import_reference("tlxcv/models/detection/yolov3.py", "ref_yolov3", package=("refdet", "tlxcv/models/detection"))
+    model = ref.YOLOv3()
+    shapes = seeded.shapes_of(model)
     params = seeded.fill(shapes, wseed)
+    model.load_dict(params)
+    model.set_eval()
     x = torch.from_numpy(seeded.image_batch(batch, xseed, hw=hw))
     with torch.no_grad():
-        body, neck, head = OF.yolov3({k: torch.from_numpy(v) for k, v in params.items()}, x)
-    print(f"[yolov3] restatement-only fixture, head shapes {[tuple(h.shape) for h in head]}")
+        body = model.backbone({"images": x})
+        neck = model.neck(body, model.for_mot)
+        head = model.yolo_head({"images": x, "neck_feats": neck})
+        _, neck_re, head_re = OF.yolov3({k: torch.from_numpy(v) for k, v in params.items()}, x)
+    d = max([_check(f"yolov3 head {i}", a, b) for i, (a, b) in enumerate(zip(head, head_re))]
+            + [_check(f"yolov3 neck {i}", a, b) for i, (a, b) in enumerate(zip(neck, neck_re))])
     np.savez_compressed(
         os.path.join(OUT, fname), arch="YOLOv3", weight_seed=wseed, input_seed=xseed, batch=batch, hw=hw,
         head0=head[0].numpy(), head1=head[1].numpy(), head2=head[2].numpy(), neck2=neck[2].numpy(),
-        pinned_by="restatement-only: yolov3.py imports utils/ops.py (decorator, torchvision, paddle); "
-                  "its DarkNet backbone is pinned by darknet53_b1.npz",
+        restatement_max_abs_diff=np.float64(d),
+        pinned_by="reference-file-on-tlx_cpu (backbone, neck, yolo_head of the reference's YOLOv3 object; decorator / "
+                  "torchvision from oracle/shims)",
         param_names=np.array(list(shapes.keys())), torch_version=torch.__version__)
 
 
-def gen_restatement_only(arch, ctor_name, fn, batch, wseed, xseed, fname, note, hw=224):
-    """Reference file is Paddle-only: fixture = oracle restatement output (reviewed against the cited lines)."""
-    from tlxcv_amd import models
-    m = getattr(models, ctor_name)()
-    shapes = seeded.shapes_of(m)
+def gen_paddle_converted(relpath, ctor_name, fn, batch, wseed, xseed, fname, hw=224):
+    """A Paddle-converted reference classifier (swin_transformer.py, mobilenetv2.py, mobilenetv3.py) loaded unmodified:
+    paddle / paddle2tlx from oracle/shims, Paddle tensor-method spellings from oracle/tlx_cpu/pd.py."""
+    from oracle.tlx_cpu import pd
+    ref = import_reference(relpath, "ref_" + ctor_name, paddle=True)
+    model = getattr(ref, ctor_name)()
+    shapes = seeded.shapes_of(model)
     params = seeded.fill(shapes, wseed)
+    model.load_dict(params)
+    model.set_eval()
     x = torch.from_numpy(seeded.image_batch(batch, xseed, hw=hw))
     with torch.no_grad():
-        out = fn({k: torch.from_numpy(v) for k, v in params.items()}, x)
-    print(f"[{arch}] restatement-only fixture, logits std {out.std().item():.3f}")
+        ref_out = pd.unwrap(model(pd.wrap(x)))
+        re_out = fn({k: torch.from_numpy(v) for k, v in params.items()}, x)
+    d = _check(ctor_name, ref_out, re_out)
     np.savez_compressed(
-        os.path.join(OUT, fname), arch=arch, weight_seed=wseed, input_seed=xseed, batch=batch,
-        logits=out.numpy().astype(np.float32), argmax=out.argmax(-1).numpy().astype(np.int64),
-        pinned_by="restatement-only: " + note, param_names=np.array(list(shapes.keys())),
-        torch_version=torch.__version__)
+        os.path.join(OUT, fname), arch=ctor_name, weight_seed=wseed, input_seed=xseed, batch=batch, hw=hw,
+        logits=ref_out.numpy().astype(np.float32), argmax=ref_out.argmax(-1).numpy().astype(np.int64),
+        restatement_max_abs_diff=np.float64(d),
+        pinned_by="reference-file-on-tlx_cpu (paddle / paddle2tlx import shims, Paddle tensor-method spellings: oracle/shims, oracle/tlx_cpu/pd.py)",
+        param_names=np.array(list(shapes.keys())), torch_version=torch.__version__)
 
 
-def main():
+def main(only=()):
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(os.cpu_count() or 1)
-    gen_resnet(50, 4, 1, 0, "resnet50_b4.npz")      # BASELINE.json configs[0]
-    gen_resnet(18, 2, 11, 10, "resnet18_b2.npz")
-    gen_vit("vit_base_patch16_224", 2, 2, 0, "vit_b16_b2.npz")       # BASELINE.json configs[2] graph
-    gen_vit("vit_small_patch16_224", 1, 12, 3, "vit_small_b1.npz")   # no qkv bias, qk_scale override, hd=96
-    gen_restatement_only("swintransformer_base_patch4_window7_224", "swintransformer_base_patch4_window7_224",
-                         lambda p, x: OF.swin(p, x, "swintransformer_base_patch4_window7_224"), 2, 3, 0,
-                         "swin_b_b2.npz", "reference swin_transformer.py hard-imports paddle/paddle2tlx")
-    gen_restatement_only("swintransformer_tiny_patch4_window7_224", "swintransformer_tiny_patch4_window7_224",
-                         lambda p, x: OF.swin(p, x, "swintransformer_tiny_patch4_window7_224"), 1, 13, 4,
-                         "swin_t_b1.npz", "reference swin_transformer.py hard-imports paddle/paddle2tlx")
-    note = "reference mobilenetv2/v3.py hard-import paddle and use broken package-relative imports"
-    gen_restatement_only("mobilenet_v2", "mobilenet_v2", lambda p, x: OF.mobilenetv2(p, x), 2, 7, 5,
-                         "mobilenetv2_b2.npz", note, hw=128)
-    gen_restatement_only("mobilenet_v3_small", "mobilenet_v3_small",
-                         lambda p, x: OF.mobilenetv3(p, x, OF.MBV3_SMALL), 2, 8, 6, "mobilenetv3_small_b2.npz", note, hw=128)
-    gen_restatement_only("mobilenet_v3_large", "mobilenet_v3_large",
-                         lambda p, x: OF.mobilenetv3(p, x, OF.MBV3_LARGE), 1, 9, 7, "mobilenetv3_large_b1.npz", note, hw=128)
-    gen_mobilenetv1(2, 4, 1, "mobilenetv1_b2.npz")
-    gen_vgg("vgg16", False, 1, 10, 8, "vgg16_b1.npz")
-    gen_vgg("vgg11", True, 2, 11, 9, "vgg11_bn_b2.npz")
-    gen_alexnet(2, 12, 10, "alexnet_b2.npz")
-    gen_resnext(50, 32, 2, 96, 13, 11, "resnext50_32x4d_b2.npz")
-    gen_resnext(50, 64, 1, 64, 14, 12, "resnext50_64x4d_b1.npz")
-    gen_resnest("resnest50", 2, 96, 17, 15, "resnest50_b2.npz")
-    gen_resnest("resnest50_fast_1s1x64d", 1, 64, 18, 16, "resnest50_fast_b1.npz")     # radix 1 (sigmoid gate), avd_first
-    gen_efficientnet("efficientnet_b0", 2, 224, 15, 13, "efficientnet_b0_b2.npz")
-    gen_efficientnet("efficientnet_b2", 1, 130, 16, 14, "efficientnet_b2_b1.npz")     # width / depth multipliers, odd extents under 'SAME' 
-    gen_darknet(1, 64, 5, 2, "darknet53_b1.npz")
-    gen_yolov3(1, 64, 6, 3, "yolov3_b1.npz")
-    for extra in EXTRA:
-        extra()
+    jobs = []
 
+    def job(fn, *args, **kw):
+        fname = next(a for a in args if isinstance(a, str) and a.endswith('.npz'))
+        if not only or any(w in fname for w in only):
+            jobs.append((fn, args, kw))
 
-EXTRA = []
+    job(gen_resnet, 50, 4, 1, 0, "resnet50_b4.npz")      # BASELINE.json configs[0]
+    job(gen_resnet, 18, 2, 11, 10, "resnet18_b2.npz")
+    job(gen_vit, "vit_base_patch16_224", 2, 2, 0, "vit_b16_b2.npz")       # BASELINE.json configs[2] graph
+    job(gen_vit, "vit_small_patch16_224", 1, 12, 3, "vit_small_b1.npz")   # no qkv bias, qk_scale override, hd=96
+    swin = "tlxcv/models/classification/swin_transformer.py"
+    job(gen_paddle_converted, swin, "swintransformer_base_patch4_window7_224",
+                         lambda p, x: OF.swin(p, x, "swintransformer_base_patch4_window7_224"), 2, 3, 0, "swin_b_b2.npz")   # BASELINE.json configs[3] graph
+    job(gen_paddle_converted, swin, "swintransformer_tiny_patch4_window7_224",
+                         lambda p, x: OF.swin(p, x, "swintransformer_tiny_patch4_window7_224"), 1, 13, 4, "swin_t_b1.npz")
+    job(gen_paddle_converted, "tlxcv/models/classification/mobilenetv2.py", "mobilenet_v2", lambda p, x: OF.mobilenetv2(p, x),
+                         2, 7, 5, "mobilenetv2_b2.npz", hw=128)
+    mbv3 = "tlxcv/models/classification/mobilenetv3.py"
+    job(gen_paddle_converted, mbv3, "mobilenet_v3_small", lambda p, x: OF.mobilenetv3(p, x, OF.MBV3_SMALL), 2, 8, 6,
+                         "mobilenetv3_small_b2.npz", hw=128)
+    job(gen_paddle_converted, mbv3, "mobilenet_v3_large", lambda p, x: OF.mobilenetv3(p, x, OF.MBV3_LARGE), 1, 9, 7,
+                         "mobilenetv3_large_b1.npz", hw=128)
+    job(gen_mobilenetv1, 2, 4, 1, "mobilenetv1_b2.npz")
+    job(gen_vgg, "vgg16", False, 1, 10, 8, "vgg16_b1.npz")
+    job(gen_vgg, "vgg11", True, 2, 11, 9, "vgg11_bn_b2.npz")
+    job(gen_alexnet, 2, 12, 10, "alexnet_b2.npz")
+    job(gen_resnext, 50, 32, 2, 96, 13, 11, "resnext50_32x4d_b2.npz")
+    job(gen_resnext, 50, 64, 1, 64, 14, 12, "resnext50_64x4d_b1.npz")
+    job(gen_resnest, "resnest50", 2, 96, 17, 15, "resnest50_b2.npz")
+    job(gen_resnest, "resnest50_fast_1s1x64d", 1, 64, 18, 16, "resnest50_fast_b1.npz")     # radix 1 (sigmoid gate), avd_first
+    job(gen_efficientnet, "efficientnet_b0", 2, 224, 15, 13, "efficientnet_b0_b2.npz")
+    job(gen_efficientnet, "efficientnet_b2", 1, 130, 16, 14, "efficientnet_b2_b1.npz")     # width / depth multipliers, odd extents under 'SAME' 
+    job(gen_darknet, 1, 64, 5, 2, "darknet53_b1.npz")
+    job(gen_yolov3, 1, 64, 6, 3, "yolov3_b1.npz")
+    for fn, args, kw in jobs:
+        fn(*args, **kw)
+
 
 if __name__ == "__main__":
-    main()
+    main(tuple(sys.argv[1:]))

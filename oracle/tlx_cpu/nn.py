@@ -73,11 +73,23 @@ class Module(torch.nn.Module):
         self.register_buffer(var_name, p.data)
         return getattr(self, var_name)
 
+    # Paddle-backend Layer methods the converted files call (swin_transformer.py:141-145,163-165)
+    def create_parameter(self, shape, attr=None, dtype=None, is_bias=False, default_initializer=None):
+        init = default_initializer if default_initializer is not None else Constant(0.0)
+        return Parameter(data=init(shape=tuple(shape)))
+
+    def add_parameter(self, name, parameter):
+        if name in self.__dict__:
+            del self.__dict__[name]
+        self.register_parameter(name, parameter)
+        return parameter
+
     def load_dict(self, named, strict=True):
         self._adopt_lists()
         sd = self.state_dict()
         unknown = [k for k in named if k not in sd]
-        missing = [k for k in sd if k not in named and sd[k].is_floating_point() and not k.endswith(("attn_mask",))]
+        missing = [k for k in sd if k not in named and sd[k].is_floating_point()
+                   and not k.endswith(("attn_mask", "relative_position_bias"))]
         if strict and (unknown or missing):
             raise KeyError(f"load_dict: unknown={unknown[:4]} missing={missing[:4]}")
         with torch.no_grad():
