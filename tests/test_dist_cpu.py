@@ -35,6 +35,45 @@ def _worker(rank, world, port, total, q):
     dist.destroy_process_group()
 
 
+def _worker_fwd(rank, world, port, total, q):
+    """sharded_forward with a stand-in 'model' (a row-wise function, so shard results are position-independent):
+    global-batch form and per-rank-shard form must give the same rows in batch order on every rank."""
+    sys.path.insert(0, REPO)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from tlxcv_amd import dist as D
+    D.init(backend="gloo")
+    x = torch.arange(total * 6, dtype=torch.float32).reshape(total, 6)
+    model = lambda t: t[:, :4] * 2 + 1          # noqa: E731
+    want = model(x)
+    a = D.sharded_forward(model, x)
+    lo, hi = D.shard_bounds(total, rank, world)
+    b = D.sharded_forward(model, x[lo:hi], total=total)
+    bad_shape = False
+    try:
+        D.sharded_forward(model, x[lo:hi + 1] if hi < total else x[lo:hi - 1], total=total)
+    except ValueError:
+        bad_shape = True
+    q.put((rank, bool(torch.equal(a, want)), bool(torch.equal(b, want)), bad_shape))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [6, 5])
+def test_two_rank_sharded_forward_global_and_per_rank_forms(total):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_fwd, args=(r, 2, port, total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(a and b and bad for _, a, b, bad in res), res
+
+
 @pytest.mark.parametrize("total", [8, 7])
 def test_two_rank_all_gather_of_logits(total):
     ctx = mp.get_context("spawn")

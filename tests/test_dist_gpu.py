@@ -1,0 +1,56 @@
+"""BASELINE.json configs[4]'s code path with real engine output: two fresh child ranks on the box's one GPU run
+tlxcv_amd.dist.sharded_forward / sharded_predict on the resnet50_b4 golden images (2 + 2 images, and a ragged 2 + 1
+split handed over as per-rank shards), all-gather the logits, and BOTH ranks must hold the golden logits / class ids.
+The collective is gloo here (TLXMI_DIST_BACKEND=gloo: RCCL refuses two ranks on one device); on the 8-GPU node the same
+code runs over RCCL (bench.py --gpus N)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, REPO
+from util import check_fp16_logits
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_two_ranks_on_one_gpu_gather_the_golden_logits(dev, tmp_path):
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), TLXMI_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(REPO, "tests", "dist_gpu_worker.py"), str(tmp_path)],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o.decode(errors="replace"))
+    for rank, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {rank} failed:\n{o[-3000:]}"
+    g = np.load(os.path.join(GOLDEN, "resnet50_b4.npz"))
+    ref = g["logits"]
+    for rank in range(2):
+        r = np.load(os.path.join(str(tmp_path), f"rank{rank}.npz"))
+        assert r["logits_global4"].shape == (4, 1000) and r["logits_shard3"].shape == (3, 1000)
+        assert np.abs(r["logits_global4"] - ref).max() <= 1e-4, rank             # north_star: 1e-4 fp32, on every rank
+        assert np.abs(r["logits_shard3"] - ref[:3]).max() <= 1e-4, rank
+        assert (r["pred_global4"] == g["argmax"]).all(), rank                    # bit-exact class indices
+        check_fp16_logits(r["logits_fp16"], ref, g["argmax"], "resnet50_b4")
+    a, b = (np.load(os.path.join(str(tmp_path), f"rank{k}.npz")) for k in range(2))
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), k                                     # the ranks agree bit for bit

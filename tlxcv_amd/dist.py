@@ -53,14 +53,11 @@ def all_gather_logits(local_logits, total=None, group=None):
     local_logits = local_logits.contiguous()
     b, c = local_logits.shape
     if total is None or total % world == 0 and b * world == (total or b * world):
-        out = torch.empty((b * world, c), dtype=local_logits.dtype, device=local_logits.device)
-        dist.all_gather_into_tensor(out, local_logits, group=group)
-        return out
+        return _gather_rows(local_logits, group)
     bmax = (total + world - 1) // world
     pad = torch.zeros((bmax, c), dtype=local_logits.dtype, device=local_logits.device)
     pad[:b] = local_logits
-    out = torch.empty((bmax * world, c), dtype=local_logits.dtype, device=local_logits.device)
-    dist.all_gather_into_tensor(out, pad, group=group)
+    out = _gather_rows(pad, group)
     pieces = []
     for r in range(world):
         lo, hi = shard_bounds(total, r, world)
@@ -68,12 +65,43 @@ def all_gather_logits(local_logits, total=None, group=None):
     return torch.cat(pieces, 0)
 
 
-def sharded_predict(model, x_global):
-    """ImageClassification.predict over a batch sharded across ranks: every rank returns all class ids."""
+def _gather_rows(padded, group=None):
+    """all_gather_into_tensor of equal (rows, classes) blocks.  RCCL gathers device tensors in place; the gloo rehearsal
+    backend (several ranks sharing one GPU, or CPU tests) stages device tensors through the host."""
+    world = dist.get_world_size(group)
+    b, c = padded.shape
+    if padded.is_cuda and dist.get_backend(group) == "gloo":
+        host = padded.cpu()
+        out = torch.empty((b * world, c), dtype=host.dtype)
+        dist.all_gather_into_tensor(out, host, group=group)
+        return out.to(padded.device)
+    out = torch.empty((b * world, c), dtype=padded.dtype, device=padded.device)
+    dist.all_gather_into_tensor(out, padded, group=group)
+    return out
+
+
+def sharded_forward(model, x, total=None):
+    """Logits of a batch sharded across ranks, on every rank, in batch order.
+    total=None: `x` is the GLOBAL batch (every rank holds it, e.g. a broadcast request) and each rank runs its
+    contiguous shard; total=n: `x` is already THIS RANK'S shard of an n-image batch (shard_bounds(n, rank, world)) —
+    the form a data loader that reads per rank uses, no rank ever holds the other ranks' images."""
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
-    xs = shard_batch(x_global, rank, world)
-    logits = model(xs)
-    full = all_gather_logits(logits, total=x_global.shape[0])
+    if total is None:
+        total = x.shape[0]
+        xs = shard_batch(x, rank, world)
+    else:
+        lo, hi = shard_bounds(total, rank, world)
+        if x.shape[0] != hi - lo:
+            raise ValueError(f"rank {rank} of {world}: shard has {x.shape[0]} images, shard_bounds({total}) says {hi - lo}")
+        xs = x
+    if xs.shape[0] == 0:
+        raise ValueError(f"rank {rank}: empty shard (batch {total} over {world} ranks); use fewer ranks")
+    return all_gather_logits(model(xs), total=total)
+
+
+def sharded_predict(model, x, total=None):
+    """ImageClassification.predict over a batch sharded across ranks: every rank returns all class ids
+    (arguments as sharded_forward)."""
     from . import tlx
-    return tlx.argmax(full, axis=-1)
+    return tlx.argmax(sharded_forward(model, x, total), axis=-1)
