@@ -1,20 +1,29 @@
 #!/usr/bin/env python3
-"""bench.py — forward images/sec of the BASELINE.json workload on N MI355X GPUs of one node.
+"""bench.py — forward images/sec of the BASELINE.json workloads on N MI355X GPUs of one node.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload resnet50|vit_b16]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload resnet50|vit_b16|swin_b] [--no-also]
 
-Workload (config.workload): BASELINE.json configs[1] — ResNet-50 fp16 forward, batch 256 per GPU,
-synthetic ImageNet-shaped input already resident in HBM, seeded random weights of the real
-architecture.  A "step" is one forward of one batch on every rank followed, for N>1, by the RCCL
-all-gather of the (256, 1000) logits (the only exchange); scaling is weak.
-Prints ONE JSON line (rank 0).  Extra objects on the same line:
-  roofline      the implicit-GEMM kernel family (every conv + the classifier GEMM): algorithmic
-                bytes per launch / mean launch duration, timed with HIP events on the launch stream
-                in an instrumented pass right after the timed region; bound = HBM.
-  cpu_baseline  the CPU oracle (oracle/functional.py, torch fp32 on all host cores) on a bounded
-                sample — the stand-in for "TensorLayerX torch-CPU backend", which cannot be installed.
+Headline (config.workload): BASELINE.json configs[1] — ResNet-50 fp16 forward, batch 256 per GPU, synthetic
+ImageNet-shaped input already resident in HBM, seeded random weights of the real architecture.  A "step" is one forward
+of one batch on every rank followed, for N>1, by the RCCL all-gather of the (256, 1000) logits (the only exchange,
+SURVEY.md §8e); scaling is weak.  Prints ONE JSON line (rank 0).  On the same line:
+
+  also          (N=1, default workload) the other half of the metric and the third config, each measured the same way in
+                this same run: ViT-B/16 batch 256 (configs[2]) and Swin-B batch 128 (configs[3]), each with
+                value / ms_per_step / roofline.
+  roofline      the WHOLE FORWARD over the TIMED region: SURVEY.md §8d's algorithmic bytes (or FLOPs) per image x the
+                images of a step (+ the weights once per step), divided by the timed ms_per_step — so achieved and
+                value come from the same clock.  `kernel_family` (secondary) is the implicit-GEMM kernel family (every
+                conv / linear launch): Σ algorithmic bytes and FLOPs per launch from the launch descriptors, durations
+                from HIP events on the launch stream in an instrumented per-kernel pass; its share of that pass's
+                wall time is applied to the timed step, so family_ms_per_step <= ms_per_step by construction.
+                `traffic`: HBM bytes per forward from separate rocprofv3 --pmc passes (tools/pmc_traffic.sh), only when
+                the file under profiles/ was measured on exactly these kernel sources (sha of csrc/), else null.
+  cpu_baseline  the CPU oracle (oracle/functional.py, torch fp32 on the host cores) on a bounded sample — the stand-in
+                for "TensorLayerX torch-CPU backend", which cannot be installed.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -23,29 +32,49 @@ import time
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-import numpy as np  # noqa: E402
+import numpy as np  # noqa: E402,F401
 import torch  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
-MFMA_F16_PEAK_TF = 2500.0  # dense fp16 MFMA
-# measured on a box of this pool (tools/roofline_denominators.py -> profiles/r01/roofline_denominators.txt):
-MEASURED_HBM_COPY_GBS = 4750.0    # torch copy of 1-4 GiB, read + write bytes
-MEASURED_GEMM_F16_TF = 1333.0     # hipBLASLt (torch.matmul) 16384 x 4096 x 4096
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+HBM_ACHIEVABLE_GBS = 6290.0      # same guide: 6.29 TB/s measured float4 copy (79 % of spec)
+MFMA_F16_PEAK_TF = 2500.0        # dense fp16 MFMA, spec
+MEASURED_GEMM_F16_TF = 1333.0    # hipBLASLt (torch.matmul) 16384 x 4096 x 4096 on a box of this pool (profiles/r01/roofline_denominators.txt)
+PROFILE_ROUND = "r02"
+
+# SURVEY.md §8d / BASELINE.md §2: algorithmic work per image with every elementwise op fused into its producer
+WORK = {
+    #            ctor                                        batch  FLOP/img   bytes/img  weight bytes  bound
+    "resnet50": ("resnet50", 256, 8.178e9, 56.8e6, 51.0e6, "hbm"),
+    "vit_b16": ("vit_base_patch16_224", 256, 35.128e9, 79.9e6, 173e6, "mfma"),
+    "swin_b": ("swintransformer_base_patch4_window7_224", 128, 30.862e9, 137e6, 176e6, "hbm"),
+}
+LABEL = {"resnet50": "ResNet-50 fp16 forward, 224x224, batch {b} per GPU (BASELINE configs[1])",
+         "vit_b16": "ViT-B/16 fp16 forward, 224x224, batch {b} per GPU (BASELINE configs[2])",
+         "swin_b": "Swin-B (window 7) fp16 forward, 224x224, batch {b} per GPU (BASELINE configs[3])"}
+
+
+def csrc_sha():
+    """sha of the kernel sources: a PMC traffic file is only quoted for the build it was measured on."""
+    h = hashlib.sha256()
+    d = os.path.join(REPO, "tlxcv_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def build_model(workload, dev):
     from tlxcv_amd import models, seeded
-    ctor = {"resnet50": "resnet50", "vit_b16": "vit_base_patch16_224",
-            "swin_b": "swintransformer_base_patch4_window7_224"}[workload]
-    m = getattr(models, ctor)()
+    m = getattr(models, WORK[workload][0])()
     params = seeded.fill(seeded.shapes_of(m), 1)
     m.load_dict(params)
     return m.to(dev).set_eval(), params
 
 
-def cpu_baseline(workload, params, batch=16, warm=1, min_seconds=12.0, max_iters=200):
-    """Oracle restatement timed on the host cores (rank 0, N=1 only): forwards of `batch` images of the same
-    workload until about `min_seconds` of CPU work have been timed (a bounded sample, 10-30 s)."""
+def cpu_baseline(workload, params, batch=32, warm=2, min_iters=5, min_seconds=10.0, max_iters=200):
+    """Oracle restatement timed on the host cores (rank 0, N=1 only): BASELINE.md §4 — batch 32, fp32, 2 warm-up
+    forwards, then at least 5 timed forwards and at least ~10 s of CPU work (a bounded sample)."""
     from oracle import functional as OF
     from tlxcv_amd import seeded
     try:
@@ -67,52 +96,29 @@ def cpu_baseline(workload, params, batch=16, warm=1, min_seconds=12.0, max_iters
             fn()
             iters += 1
             dt = time.perf_counter() - t0
-            if dt >= min_seconds:
+            if iters >= min_iters and dt >= min_seconds:
                 break
     return {"value": round(batch * iters / dt, 2), "unit": "images/sec", "cores": torch.get_num_threads(),
-            "kind": "port", "sample": f"{iters} forwards of batch {batch}, fp32, oracle/functional.py on torch-CPU "
-            f"({dt:.1f} s)"}
+            "kind": "port", "sample": f"{iters} forwards of batch {batch} after {warm} warm-up, fp32, oracle/functional.py "
+            f"on torch-CPU ({dt:.1f} s); os.cpu_count() = {os.cpu_count()}"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=None, help="images per GPU (default 256; 128 for swin_b)")
-    ap.add_argument("--workload", default="resnet50", choices=["resnet50", "vit_b16", "swin_b"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="launch kernel by kernel instead of replaying a hipGraph")
-    a = ap.parse_args()
-    if a.batch is None:
-        a.batch = 128 if a.workload == "swin_b" else 256
-
-    import tlxcv_amd
+def measure(workload, batch, steps, warmup, dev, rank, world, graph=True, probe_family=True):
+    """Timed region + roofline of one workload on this rank.  Returns (fields, params, model)."""
     from tlxcv_amd import dist as D, engine as E, seeded
     import torch.distributed as dist
-
-    # rank / world from the launcher's environment; the process group (RCCL) is created only AFTER the model is built
-    # and its forward captured into a hipGraph, so no communicator thread exists while the capture is open
-    rank, world, local = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")))
-    if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
-    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path"
-    local = local % torch.cuda.device_count()   # (a 2-rank rehearsal on a 1-GPU box shares the device)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    tlxcv_amd.set_precision("fp16")
-
-    model, params = build_model(a.workload, dev)
-    x = torch.from_numpy(seeded.image_batch(min(a.batch, 32), rank)).to(dev)
-    x = x.repeat((a.batch + x.shape[0] - 1) // x.shape[0], 1, 1, 1)[: a.batch].contiguous()   # resident in HBM
+    model, params = build_model(workload, dev)
+    x = torch.from_numpy(seeded.image_batch(min(batch, 32), rank)).to(dev)
+    x = x.repeat((batch + x.shape[0] - 1) // x.shape[0], 1, 1, 1)[:batch].contiguous()   # resident in HBM
 
     fwd = model
-    if not a.no_graph:
+    if graph:
         from tlxcv_amd.graph import GraphedForward
         fwd = GraphedForward(model, x)       # the whole forward as one hipGraph; x is its static input
 
-    if world > 1:
+    if world > 1 and not dist.is_initialized():
+        # the process group (RCCL) is created only AFTER the forward is captured, so no communicator thread exists
+        # while the capture is open
         r2, w2, _ = D.init()
         assert (r2, w2) == (rank, world)
 
@@ -125,12 +131,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
+    for _ in range(warmup):
         y = step()
     fence()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    marks[0].record()
+    for i in range(steps):
         y = step()
+        marks[i + 1].record()               # one event record per step on the launch stream (no host sync)
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -138,63 +147,128 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert torch.isfinite(y.float()).all(), "non-finite logits"
-    total_images = a.batch * world * a.steps
-    value = total_images / dt
-
-    line = {
-        "metric": "images/sec fwd", "value": round(value, 1), "unit": "images/sec", "n_gpus": world,
-        "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-        "config": {"workload": {"resnet50": f"ResNet-50 fp16 forward, 224x224, batch {a.batch} per GPU (BASELINE configs[1])",
-                                "vit_b16": f"ViT-B/16 fp16 forward, 224x224, batch {a.batch} per GPU (BASELINE configs[2])",
-                                "swin_b": f"Swin-B (window 7) fp16 forward, 224x224, batch {a.batch} per GPU (BASELINE configs[3])"}[a.workload],
-                   "global_batch": a.batch * world, "per_gpu_batch": a.batch, "weights": "seeded random (tlxcv_amd.seeded, seed 1)",
-                   "parallelism": f"batch-sharded x{world}, all-gather logits" if world > 1 else "single GPU",
-                   "launch": "per-kernel" if a.no_graph else "hipGraph replay of the forward"},
-    }
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+    median_ms = per_step[steps // 2] if steps % 2 else 0.5 * (per_step[steps // 2 - 1] + per_step[steps // 2])
+    ms_per_step = 1e3 * dt / steps
+    value = batch * world * steps / dt
+    out = {"value": round(value, 1), "ms_per_step": round(ms_per_step, 4),
+           "ms_per_step_median": round(median_ms, 4), "value_at_median": round(batch * world / (median_ms * 1e-3), 1)}
 
     if rank == 0:
-        # ---- roofline of the implicit-GEMM kernel family: instrumented pass, HIP events per launch
-        probe = []
-        E.set_probe(probe)
-        nprobe = min(a.steps, 5)
-        for _ in range(nprobe):
-            model(x)
-        torch.cuda.synchronize()
-        E.set_probe(None)
-        ms = sum(e[0].elapsed_time(e[1]) for e in probe)
-        nl = len(probe)
-        alg_bytes = sum(e[2] for e in probe)
-        flops = sum(e[3] for e in probe)
-        per_launch_us = 1e3 * ms / nl
-        gbs = alg_bytes / (ms * 1e-3) / 1e9
-        tfs = flops / (ms * 1e-3) / 1e12
-        # ResNet-50's layer-by-layer arithmetic intensity (~144 FLOP/B) is below the machine balance
-        # (~312): HBM-bound.  ViT-B/16 (~436 FLOP/B) is MFMA-bound.  Both fractions are reported.
-        hbm_bound = a.workload == "resnet50"
-        # HBM bytes per launch from PMC counters cannot be collected inside this process: they come from the
-        # separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command
-        # (tools/pmc_traffic.sh; FETCH_SIZE doubled per MI355X_MICROARCH.md), committed under profiles/.
-        traffic = None
-        tj = os.path.join(REPO, "profiles", "r01", f"traffic_{a.workload}.json")
-        if os.path.exists(tj) and a.batch == (128 if a.workload == "swin_b" else 256):
-            tjd = json.load(open(tj))      # bytes per forward over the kernel family -> per conv2d / linear launch
-            traffic = int(tjd["hbm_bytes_per_forward"] / (nl // nprobe)) if "hbm_bytes_per_forward" in tjd else int(tjd["hbm_bytes_per_launch"])
-        line["roofline"] = {
-            "bound": "hbm" if hbm_bound else "mfma",
-            "achieved": round(gbs if hbm_bound else tfs, 1),
-            "peak": HBM_PEAK_GBS if hbm_bound else MFMA_F16_PEAK_TF,
-            "unit": "GB/s" if hbm_bound else "TFLOP/s",
-            "frac": round(gbs / HBM_PEAK_GBS if hbm_bound else tfs / MFMA_F16_PEAK_TF, 4), "traffic": traffic,
-            "peak_measured": MEASURED_HBM_COPY_GBS if hbm_bound else MEASURED_GEMM_F16_TF,
-            "frac_of_measured": round(gbs / MEASURED_HBM_COPY_GBS if hbm_bound else tfs / MEASURED_GEMM_F16_TF, 4),
-            "kernel": "tlxmi_conv2d kernel family: conv_igemm_kernel, gemm_pp_kernel, gemm_stream_kernel, gemm256_kernel (all instantiations; every conv / linear launch of one forward)",
-            "launches_per_step": nl // nprobe, "avg_launch_us": round(per_launch_us, 2),
-            "alg_bytes_per_launch": int(alg_bytes / nl), "alg_flops_per_launch": int(flops / nl),
+        _, _, flop_img, bytes_img, wbytes, bound = WORK[workload]
+        scale = batch                                    # per GPU: rank 0's own step
+        alg_bytes = bytes_img * scale + wbytes
+        alg_flops = flop_img * scale
+        gbs = alg_bytes / (ms_per_step * 1e-3) / 1e9
+        tfs = alg_flops / (ms_per_step * 1e-3) / 1e12
+        hbm = bound == "hbm"
+        roof = {
+            "bound": bound, "achieved": round(gbs if hbm else tfs, 1), "peak": HBM_PEAK_GBS if hbm else MFMA_F16_PEAK_TF,
+            "unit": "GB/s" if hbm else "TFLOP/s", "frac": round(gbs / HBM_PEAK_GBS if hbm else tfs / MFMA_F16_PEAK_TF, 4),
+            "traffic": None,
+            "scope": "whole forward of one step over the timed region (algorithmic work of SURVEY.md 8d / timed ms_per_step)",
+            "alg_bytes_per_step": int(alg_bytes), "alg_flops_per_step": int(alg_flops),
             "hbm_gbs": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
+            "hbm_frac_of_achievable_6290": round(gbs / HBM_ACHIEVABLE_GBS, 4),
             "mfma_tflops": round(tfs, 1), "mfma_frac": round(tfs / MFMA_F16_PEAK_TF, 4),
-            "gemm_ms_per_step": round(ms / nprobe, 3),
+            "mfma_frac_of_hipblaslt_1333": round(tfs / MEASURED_GEMM_F16_TF, 4),
+            "frac_at_median_step": round((gbs / HBM_PEAK_GBS if hbm else tfs / MFMA_F16_PEAK_TF) * ms_per_step / median_ms, 4),
         }
+        tj = os.path.join(REPO, "profiles", PROFILE_ROUND, f"traffic_{workload}.json")
+        if os.path.exists(tj) and batch == WORK[workload][1]:
+            tjd = json.load(open(tj))
+            if tjd.get("csrc_sha") == csrc_sha():        # measured on exactly these kernels, else stale -> null
+                roof["traffic"] = int(tjd["hbm_bytes_per_forward"])
+                roof["traffic_source"] = f"profiles/{PROFILE_ROUND}/traffic_{workload}.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, all kernels of a forward)"
+                roof["traffic_over_algorithmic"] = round(roof["traffic"] / alg_bytes, 3)
+        if probe_family:
+            # ---- secondary: the implicit-GEMM kernel family, HIP event pair per launch in a per-kernel pass
+            probe = []
+            nprobe = 3
+            model(x)
+            torch.cuda.synchronize()
+            w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            E.set_probe(probe)
+            w0.record()
+            for _ in range(nprobe):
+                model(x)
+            w1.record()
+            torch.cuda.synchronize()
+            E.set_probe(None)
+            fam_ms = sum(e[0].elapsed_time(e[1]) for e in probe)
+            wall_ms = w0.elapsed_time(w1)
+            nl = len(probe)
+            share = min(1.0, fam_ms / wall_ms)
+            fam_step_ms = share * ms_per_step
+            fb = sum(e[2] for e in probe) / nprobe
+            ff = sum(e[3] for e in probe) / nprobe
+            roof["kernel_family"] = {
+                "kernel": "tlxmi_conv2d family: conv_igemm / conv_halo / gemm_pp / gemm_stream / gemm256 / fused-block kernels (every conv / linear launch of one forward)",
+                "launches_per_step": nl // nprobe, "share_of_forward_time": round(share, 4),
+                "family_ms_per_step": round(fam_step_ms, 3), "avg_launch_us": round(1e3 * fam_step_ms / (nl // nprobe), 2),
+                "alg_bytes_per_launch": int(fb / (nl // nprobe)), "alg_flops_per_launch": int(ff / (nl // nprobe)),
+                "hbm_gbs": round(fb / (fam_step_ms * 1e-3) / 1e9, 1), "mfma_tflops": round(ff / (fam_step_ms * 1e-3) / 1e12, 1),
+                "frac": round((fb / (fam_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if hbm else (ff / (fam_step_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TF), 4),
+                "method": "per-launch HIP event pairs in an instrumented per-kernel pass; the family's share of that pass's wall time x the timed ms_per_step",
+            }
+        out["roofline"] = roof
+    return out, params, model
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU (default 256; 128 for swin_b)")
+    ap.add_argument("--workload", default="resnet50", choices=list(WORK))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="headline workload only (skip the ViT-B/16 and Swin-B lines)")
+    ap.add_argument("--no-graph", action="store_true", help="launch kernel by kernel instead of replaying a hipGraph")
+    a = ap.parse_args()
+    if a.batch is None:
+        a.batch = WORK[a.workload][1]
+
+    import tlxcv_amd
+    import torch.distributed as dist
+
+    rank, world, local = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path"
+    local = local % torch.cuda.device_count()   # (a 2-rank rehearsal on a 1-GPU box shares the device)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    tlxcv_amd.set_precision("fp16")
+
+    res, params, model = measure(a.workload, a.batch, a.steps, a.warmup, dev, rank, world, graph=not a.no_graph)
+    line = {
+        "metric": "images/sec fwd", "value": res["value"], "unit": "images/sec", "n_gpus": world,
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": res["ms_per_step"],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+        "ms_per_step_median": res["ms_per_step_median"], "value_at_median": res["value_at_median"],
+        "config": {"workload": LABEL[a.workload].format(b=a.batch),
+                   "global_batch": a.batch * world, "per_gpu_batch": a.batch, "weights": "seeded random (tlxcv_amd.seeded, seed 1)",
+                   "parallelism": f"batch-sharded x{world}, all-gather logits" if world > 1 else "single GPU",
+                   "launch": "per-kernel" if a.no_graph else "hipGraph replay of the forward",
+                   "csrc_sha": csrc_sha()},
+    }
+    if rank == 0:
+        line["roofline"] = res["roofline"]
+        if world == 1 and a.workload == "resnet50" and not a.no_also:
+            del model
+            torch.cuda.empty_cache()
+            also = []
+            for wl in ("vit_b16", "swin_b"):
+                b = WORK[wl][1]
+                r, _, m2 = measure(wl, b, min(a.steps, 30), min(a.warmup, 5), dev, 0, 1, graph=not a.no_graph)
+                del m2
+                torch.cuda.empty_cache()
+                also.append({"workload": LABEL[wl].format(b=b), "value": r["value"], "unit": "images/sec",
+                             "ms_per_step": r["ms_per_step"], "ms_per_step_median": r["ms_per_step_median"],
+                             "steps": min(a.steps, 30), "warmup": min(a.warmup, 5), "roofline": r["roofline"]})
+            line["also"] = also
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.workload, params)
     if world > 1:

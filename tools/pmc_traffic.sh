@@ -8,13 +8,14 @@ WL=${1:-resnet50}
 OUT=gpurun_out/traffic_$WL
 rm -rf $OUT; mkdir -p $OUT
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$c -- python3 bench.py --workload $WL --steps 3 --warmup 2 --no-cpu-baseline > $OUT/$c.log 2>&1
+  timeout -k 10 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$c -- python3 bench.py --workload $WL --steps 3 --warmup 2 --no-cpu-baseline --no-also > $OUT/$c.log 2>&1
   echo "pass $c rc=$?"
 done
 python3 - "$WL" <<'PY'
 import csv, glob, json, sys
+sys.path.insert(0, ".")
+import bench
 wl = sys.argv[1]
-FAMILY = ("conv_igemm", "gemm256", "gemm_pp", "gemm_stream", "conv_halo")
 tot, n, fwd = {}, {}, {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     s = 0.0; k = 0; f = 0
@@ -22,14 +23,13 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         for row in csv.DictReader(open(fn)):
             if row["Counter_Name"] != c:
                 continue
-            if any(t in row["Kernel_Name"] for t in FAMILY):
-                s += float(row["Counter_Value"]); k += 1
-            elif "to_nhwc_s2d" in row["Kernel_Name"]:
+            s += float(row["Counter_Value"]); k += 1      # every kernel of the run: all of them are forwards of the model
+            if "to_nhwc_s2d" in row["Kernel_Name"]:
                 f += 1          # exactly one layout transform per forward: counts the forwards of the run
     tot[c] = s; n[c] = k; fwd[c] = f
 forwards = max(fwd["FETCH_SIZE"], 1)
 fetch_kb, write_kb = tot["FETCH_SIZE"] / forwards, tot["WRITE_SIZE"] / max(fwd["WRITE_SIZE"], 1)
-res = {"workload": wl, "kernel": "tlxmi_conv2d kernel family (conv_igemm, conv_halo, gemm_pp, gemm_stream, gemm256; all instantiations)",
+res = {"workload": wl, "kernel": "every kernel of a forward", "csrc_sha": bench.csrc_sha(),
        "forwards": forwards, "kernel_launches_per_forward": n["FETCH_SIZE"] / forwards,
        "FETCH_SIZE_KB_raw_per_forward": fetch_kb, "WRITE_SIZE_KB_per_forward": write_kb,
        "gfx950_fetch_correction": 2.0,
