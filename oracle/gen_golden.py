@@ -324,6 +324,48 @@ def gen_paddle_converted(relpath, ctor_name, fn, batch, wseed, xseed, fname, hw=
         param_names=np.array(list(shapes.keys())), torch_version=torch.__version__)
 
 
+def gen_tlx_npz(fname):
+    """SURVEY 8f rank 1 — checkpoint interchange.  Two small instances of the reference's own classes (its
+    VisionTransformer at 32 x 32 / width 32 / depth 2, its MobileNetV1 at scale 0.125, 10 classes) are filled from the
+    seeded recipe on the stand-in and written with `model.save_weights(path)` (train.py:55): the positional `params`
+    object array.  The fixture keeps that array, the seeds, and the reference models' logits on a seeded input, so the
+    engine side can be checked to (i) restore every named weight from the positional list and (ii) compute the same
+    logits from the restored weights.  The on-disk format itself is [TLX-recalled] (oracle/tlx_cpu/nn.py)."""
+    import tempfile
+    out = {}
+    vit = import_reference("tlxcv/models/classification/vision_transformer.py", "ref_vit_small_instance")
+    mb = import_reference("tlxcv/models/classification/mobilenetv1.py", "ref_mobilenetv1_small_instance")
+    cases = (("vit", lambda: vit.VisionTransformer(img_size=32, patch_size=8, num_classes=10, embed_dim=32, depth=2, num_heads=2,
+                                                   mlp_ratio=2, qkv_bias=True, epsilon=1e-6), 21, 32),
+             ("mbv1", lambda: mb.MobileNetV1(scale=0.125, num_classes=10), 22, 64))
+    for tag, ctor, wseed, hw in cases:
+        model = ctor()
+        shapes = seeded.shapes_of(model)
+        model.load_dict(seeded.fill(shapes, wseed))
+        model.set_eval()
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, "model.npz")
+            model.save_weights(path)
+            fresh = ctor()
+            fresh.load_weights(path)
+            fresh.set_eval()
+            params = np.load(path, allow_pickle=True)["params"]
+        x = torch.from_numpy(seeded.image_batch(2, 30, hw=hw))
+        with torch.no_grad():
+            y, y2 = model(x), fresh(x)
+        assert torch.equal(y, y2), "stand-in save_weights -> load_weights must round-trip"
+        print(f"[tlx npz {tag}] {len(params)} arrays, {sum(int(np.prod(a.shape)) for a in params)} values, logits std {y.std().item():.3f}")
+        for i, a in enumerate(params):
+            out[f"{tag}_params_{i:03d}"] = np.asarray(a, dtype=np.float32)
+        out[f"{tag}_n"] = len(params)
+        out[f"{tag}_weight_seed"], out[f"{tag}_input_seed"], out[f"{tag}_hw"] = wseed, 30, hw
+        out[f"{tag}_logits"] = y.numpy().astype(np.float32)
+        out[f"{tag}_param_names"] = np.array(list(shapes.keys()))
+    np.savez_compressed(os.path.join(OUT, fname), pinned_by="reference-file-on-tlx_cpu (small instances of the reference's VisionTransformer / MobileNetV1; "
+                        "positional checkpoint written by the stand-in's save_weights, format [TLX-recalled])",
+                        restatement_max_abs_diff=np.float64(0.0), **out)
+
+
 def main(only=()):
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(os.cpu_count() or 1)
@@ -362,6 +404,7 @@ def main(only=()):
     job(gen_efficientnet, "efficientnet_b2", 1, 130, 16, 14, "efficientnet_b2_b1.npz")     # width / depth multipliers, odd extents under 'SAME' 
     job(gen_darknet, 1, 64, 5, 2, "darknet53_b1.npz")
     job(gen_yolov3, 1, 64, 6, 3, "yolov3_b1.npz")
+    job(gen_tlx_npz, "tlx_npz_small.npz")
     for fn, args, kw in jobs:
         fn(*args, **kw)
 

@@ -84,6 +84,43 @@ class Module(torch.nn.Module):
         self.register_parameter(name, parameter)
         return parameter
 
+    # --- checkpoint interchange [TLX-recalled; the real package cannot be consulted here]: `all_weights` lists the
+    # variables layer by layer in construction order, each layer's in the order its build() creates them (conv / linear:
+    # weight, bias; BatchNorm: beta, gamma, moving_mean, moving_var; LayerNorm: gamma, beta); save_weights('x.npz') writes
+    # that list, without names, as ONE object array under the key `params` (tlx.files.save_npz) and load_weights assigns
+    # it back by position (demo/image_classification/train.py:55, predict.py:19).
+    _BUILD_ORDER = {"BatchNorm2d": ("beta", "gamma", "moving_mean", "moving_var")}
+
+    @property
+    def all_weights(self):
+        self._adopt_lists()
+        out = []
+        for _, m in self.named_modules():
+            own = dict(m._parameters)
+            own.update(m._buffers)
+            for k in Module._BUILD_ORDER.get(type(m).__name__, list(own)):
+                if own.get(k) is not None and k not in ("attn_mask", "relative_position_bias", "relative_position_index"):
+                    out.append(own[k])
+        return out
+
+    def save_weights(self, file_path, format=None):
+        import numpy as np
+        assert (format or "npz") == "npz", "stand-in writes the positional npz only"
+        ws = self.all_weights
+        params = np.empty(len(ws), dtype=object)
+        for i, w in enumerate(ws):
+            params[i] = w.detach().numpy().astype(np.float32)
+        np.savez(file_path, params=params)
+
+    def load_weights(self, file_path, format=None, in_order=True, skip=False):
+        import numpy as np
+        params = list(np.load(file_path, allow_pickle=True)["params"])
+        ws = self.all_weights
+        assert len(params) == len(ws)
+        with torch.no_grad():
+            for w, a in zip(ws, params):
+                w.copy_(torch.as_tensor(a))
+
     def load_dict(self, named, strict=True):
         self._adopt_lists()
         sd = self.state_dict()

@@ -97,3 +97,80 @@ def test_save_and_load_weights_roundtrip(tmp_path):
     m2.load_weights(f)
     for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
         assert torch.equal(a, b), k
+
+
+# ---------------------------------------------------------------------------------------------
+# TensorLayerX `.npz` checkpoint interchange (positional `params` list)
+# ---------------------------------------------------------------------------------------------
+def _tlx_npz_case(tag, tmp_path):
+    """The positional checkpoint the reference's own model class wrote through the oracle stand-in's save_weights
+    (oracle/gen_golden.py: gen_tlx_npz), re-materialised as the file a user would hand to load_weights."""
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "tlx_npz_small.npz"))
+    n = int(g[f"{tag}_n"])
+    params = np.empty(n, dtype=object)
+    for i in range(n):
+        params[i] = g[f"{tag}_params_{i:03d}"]
+    path = str(tmp_path / f"{tag}_model.npz")
+    np.savez(path, params=params)
+    return g, path
+
+
+def _small_models():
+    from tlxcv_amd import models
+    return {"vit": lambda: models.VisionTransformer(img_size=32, patch_size=8, num_classes=10, embed_dim=32, depth=2, num_heads=2,
+                                                    mlp_ratio=2, qkv_bias=True, epsilon=1e-6),
+            "mbv1": lambda: models.MobileNetV1(scale=0.125, num_classes=10)}
+
+
+@pytest.mark.parametrize("tag", ["vit", "mbv1"])
+def test_positional_tlx_npz_restores_every_named_weight(tag, tmp_path):
+    from tlxcv_amd import seeded
+    g, path = _tlx_npz_case(tag, tmp_path)
+    m = _small_models()[tag]()
+    m.load_weights(path)                                            # demo/image_classification/predict.py:19
+    want = seeded.fill(seeded.shapes_of(m), int(g[f"{tag}_weight_seed"]))
+    assert list(want) == [str(k) for k in g[f"{tag}_param_names"]]      # same parameter tree as the reference's class
+    sd = m.state_dict()
+    for k, v in want.items():
+        assert np.array_equal(sd[k].numpy(), v), k
+    # and back: save_weights('x.npz') writes the same positional list, array for array
+    out = str(tmp_path / "again.npz")
+    m.save_weights(out)
+    a, b = np.load(out, allow_pickle=True)["params"], np.load(path, allow_pickle=True)["params"]
+    assert len(a) == len(b) and all(np.array_equal(x, y) for x, y in zip(a, b))
+    # the name-keyed form still loads, and derived buffers are never demanded of it
+    m.save_weights(str(tmp_path / "dict.npz"), format="npz_dict")
+    m2 = _small_models()[tag]()
+    m2.load_weights(str(tmp_path / "dict.npz"))
+    assert all(torch.equal(m2.state_dict()[k], sd[k]) for k in sd)
+
+
+def test_positional_tlx_npz_rejects_a_foreign_model(tmp_path):
+    _, path = _tlx_npz_case("vit", tmp_path)
+    with pytest.raises(ValueError):
+        _small_models()["mbv1"]().load_weights(path)
+
+
+def test_derived_tensors_follow_parameter_updates():
+    """a cached derived tensor must not survive load_state_dict / in-place parameter writes."""
+    from tlxcv_amd.tlx import nn
+    lin = nn.Linear(in_features=8, out_features=8)
+    calls = []
+    build = lambda: calls.append(1) or len(calls)      # noqa: E731
+    assert lin._cached("k", build) == 1 and lin._cached("k", build) == 1
+    with torch.no_grad():
+        lin.weights.add_(1.0)                          # in-place edit: version counter moves
+    assert lin._cached("k", build) == 2
+    lin.load_state_dict(lin.state_dict())              # torch's own loader
+    assert lin._cached("k", build) == 3
+    bn = nn.BatchNorm2d(num_features=8)
+    conv = nn.GroupConv2d(in_channels=8, out_channels=8, kernel_size=1, padding=0, b_init=None)
+    assert conv._cached("f", build, deps=(bn,)) == 4 and conv._cached("f", build, deps=(bn,)) == 4
+    with torch.no_grad():
+        bn.moving_var.mul_(2.0)                        # the BatchNorm folded into the conv changed
+    assert conv._cached("f", build, deps=(bn,)) == 5
+    e0 = conv._weights_epoch
+    conv.load_dict({"filters": torch.zeros(8, 8, 1, 1)}, strict=False)
+    assert conv._weights_epoch == e0 + 1               # what a captured hipGraph compares before replay

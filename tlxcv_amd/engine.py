@@ -43,6 +43,7 @@ def precision():
     return _precision
 
 
+
 def dt_code(dtype):
     if dtype == torch.float16:
         return F16
@@ -71,6 +72,22 @@ def need_gpu(t, what="tensor"):
             f"tlxcv_amd: {what} lives on {t.device}; this engine only runs on an MI355X (HIP) device "
             "and has no CPU path — move the model and inputs to 'cuda'.")
     return t
+
+
+def to_model_device(inputs, model):
+    """Task-boundary upload: host tensors (or the {"images": ...} dict of the detectors, darknet.py:300) handed to a
+    model that lives on the GPU are copied there — the reference scripts build their image on the host
+    (predict.py:22-29).  A data transfer, not a compute path: a model that is itself on the CPU still raises."""
+    p = next(model.parameters(), None)
+    if p is None or not p.is_cuda:
+        return inputs
+    if isinstance(inputs, torch.Tensor):
+        return inputs if inputs.is_cuda else inputs.to(p.device, non_blocking=True)
+    if isinstance(inputs, dict):
+        return {k: to_model_device(v, model) for k, v in inputs.items()}
+    if isinstance(inputs, (list, tuple)):
+        return type(inputs)(to_model_device(v, model) for v in inputs)
+    return inputs
 
 
 def _f32(t):
@@ -511,6 +528,37 @@ def affine_act(x, scale=None, shift=None, res=None, act=ACT_NONE, act_param=0.0,
               Cc if res is not None else 0, Cc, act, float(act_param), EPI_RES_AFTER_ACT if res_after_act else 0,
               _stream())
     return y
+
+
+def act_flat(x, act, act_param=0.0):
+    """Elementwise activation of a tensor of ANY shape: runs over the flat storage, so the channel count need not be a
+    multiple of the 16-byte vector width and the memory layout (contiguous / channels_last) is kept.  A buffer whose
+    element count is not a whole number of chunks (or that is not dense) takes one padded copy."""
+    need_gpu(x, "input")
+    if x.dtype != _precision:
+        x = x.to(_precision)
+    v = vec(x.dtype)
+    dense = x.is_contiguous() or (x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last))
+    if not dense:
+        x = x.contiguous()
+    n = x.numel()
+    if n == 0:
+        return x.clone()
+    if n % v == 0 and x.data_ptr() % 16 == 0:
+        y = torch.empty_like(x)          # preserve_format: same strides as the dense input
+        _lib.call("tlxmi_affine_act", _p(x), None, None, None, _p(y), dt_code(x.dtype), n // v, v, v, 0, v, act,
+                  float(act_param), 0, _stream())
+        return y
+    npad = (n + v - 1) // v * v
+    buf = torch.zeros(npad, dtype=x.dtype, device=x.device)
+    buf[:n] = x.reshape(-1) if x.is_contiguous() else x.permute(0, 2, 3, 1).reshape(-1)
+    out = torch.empty_like(buf)
+    _lib.call("tlxmi_affine_act", _p(buf), None, None, None, _p(out), dt_code(x.dtype), npad // v, v, v, 0, v, act,
+              float(act_param), 0, _stream())
+    if x.is_contiguous():
+        return out[:n].view(x.shape)
+    N, Cc, H, W = x.shape
+    return out[:n].view(N, H, W, Cc).permute(0, 3, 1, 2)
 
 
 def scale_channels(x, s):

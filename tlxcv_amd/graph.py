@@ -15,6 +15,12 @@ class GraphedForward:
         assert example.is_cuda, "hipGraph capture needs a device tensor"
         self.model = model
         self.static_in = example.clone()
+        self.warmup = warmup
+        self._capture()
+
+    def _capture(self):
+        model, warmup = self.model, self.warmup
+        self.epoch = getattr(model, "_weights_epoch", 0)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -27,7 +33,15 @@ class GraphedForward:
             self.static_out = model(self.static_in)
 
     def __call__(self, x=None):
+        if getattr(self.model, "_weights_epoch", 0) != self.epoch:
+            # weights were (re)loaded or moved since the capture: the graph still points at the old packed filters.
+            # (In-place edits of single parameters are not seen here — call recapture() after them.)
+            self._capture()
         if x is not None and x.data_ptr() != self.static_in.data_ptr():
             self.static_in.copy_(x)
         self.graph.replay()
         return self.static_out
+
+    def recapture(self):
+        """Capture again after the model's weights changed in a way the loaders do not see (in-place parameter edits)."""
+        self._capture()

@@ -89,7 +89,10 @@ class WindowAttention(nn.Module):
         hd = self.dim // self.num_heads
         if qkv.dtype == torch.float16 and hd in (32, 64, 96) and qkv.shape[1] <= 256 and os.environ.get("TLXMI_ATTN_COMB", "1") != "0":
             # relative position bias + shift mask summed and padded once per layer (:205-220 adds them per forward)
-            tab = self._cached(("rpb+mask", id(mask)), lambda: E.attention_table(self.bias_table(), mask, qkv.shape[1]))
+            # keyed by the mask's storage, in-place version and shape — not id(): a temporary mask can be collected and its
+            # id reused by another tensor
+            mkey = None if mask is None else (mask.data_ptr(), mask._version, tuple(mask.shape))
+            tab = self._cached(("rpb+mask", mkey), lambda: E.attention_table(self.bias_table(), mask, qkv.shape[1]))
             a = E.attention_comb(qkv, self.num_heads, self.scale, tab, 0 if mask is None else mask.shape[0])
         else:
             a = E.attention(qkv, self.num_heads, self.scale, self.bias_table(), mask)  # :202-226

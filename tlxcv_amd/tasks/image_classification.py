@@ -1,7 +1,7 @@
 """ImageClassification task wrapper — same surface as tlxcv/tasks/image_classification.py:6-23."""
 from typing import Any
 
-from .. import tlx
+from .. import engine as E, tlx
 
 
 class ImageClassification(tlx.nn.Module):
@@ -13,9 +13,9 @@ class ImageClassification(tlx.nn.Module):
         raise NotImplementedError("training losses are out of scope for the inference engine (SURVEY.md §8f)")
 
     def forward(self, inputs: Any) -> Any:
-        return self.backbone(inputs)
+        return self.backbone(E.to_model_device(inputs, self))
 
     def predict(self, inputs: Any) -> Any:
         self.set_eval()
-        outputs = self.backbone(inputs)
+        outputs = self.backbone(E.to_model_device(inputs, self))
         return tlx.argmax(outputs, axis=-1)

@@ -1,7 +1,7 @@
 """ObjectDetection task wrapper — same surface as tlxcv/tasks/object_detection.py:6-22."""
 from typing import Any
 
-from .. import tlx
+from .. import engine as E, tlx
 
 
 class ObjectDetection(tlx.nn.Module):
@@ -13,8 +13,8 @@ class ObjectDetection(tlx.nn.Module):
         raise NotImplementedError("training losses are out of scope for the inference engine (SURVEY.md §8f)")
 
     def forward(self, inputs: Any) -> Any:
-        return self.backbone(inputs)
+        return self.backbone(E.to_model_device(inputs, self))
 
     def predict(self, inputs: Any, **kwargs) -> Any:
         self.set_eval()
-        return self.backbone(inputs, **kwargs)
+        return self.backbone(E.to_model_device(inputs, self), **kwargs)

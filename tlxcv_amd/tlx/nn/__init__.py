@@ -47,6 +47,7 @@ class Module(torch.nn.Module):
         self.name = name
         self.is_train = True
         self._engine_cache = {}
+        self._weights_epoch = 0
 
     # -- TLX surface -------------------------------------------------------------------------
     def _adopt_lists(self):
@@ -83,6 +84,13 @@ class Module(torch.nn.Module):
             m.training = False
             if isinstance(m, Module):
                 m.is_train = False
+        # Lazy device placement: the reference scripts never place the model (demo/image_classification/predict.py:16-20
+        # goes load_weights -> set_eval -> predict); the engine only runs on the GPU, so a model still on the host moves
+        # there the moment it is switched to inference.
+        if torch.cuda.is_available():
+            p = next(self.parameters(), None)
+            if p is not None and not p.is_cuda:
+                self.to("cuda")
         return self
 
     def set_train(self):
@@ -102,15 +110,12 @@ class Module(torch.nn.Module):
 
     def _apply(self, fn, *a, **k):
         self._adopt_lists()
-        for m in self.modules():
-            if isinstance(m, Module):
-                m._engine_cache.clear()
+        self._invalidate()
         return super()._apply(fn, *a, **k)
 
     @property
     def all_weights(self):
-        self._adopt_lists()
-        return list(self.parameters()) + [b for b in self.buffers()]
+        return [t for _, t in self.tlx_weights()]
 
     @property
     def trainable_weights(self):
@@ -133,34 +138,81 @@ class Module(torch.nn.Module):
     def register_parameter(self, name=None, param=None):  # keyword form: vision_transformer.py:296
         return super().register_parameter(name, param)
 
-    def save_weights(self, file_path, format=None):
-        """npz_dict-style checkpoint: {dotted name: array} for parameters and buffers."""
+    # Buffers that are functions of the architecture, not weights: never stored positionally, never required by name.
+    _DERIVED = ("attn_mask", "relative_position_bias", "relative_position_index")
+
+    def tlx_weights(self):
+        """The model's weights in TensorLayerX's `all_weights` order [TLX-recalled: layers in construction order, each
+        layer's variables in the order its build() creates them — conv/linear: weight then bias; BatchNorm: beta, gamma,
+        moving_mean, moving_var; LayerNorm: gamma, beta — trainable and non-trainable interleaved].  This is the order of
+        the positional `.npz` checkpoint (`save_weights('model.npz')`, demo/image_classification/train.py:55).
+        Returns [(dotted name, tensor)]."""
         self._adopt_lists()
-        np.savez(file_path, **{k: v.detach().float().cpu().numpy() for k, v in self.state_dict().items()})
+        out = []
+        for prefix, m in self.named_modules():
+            own = dict(m._parameters)
+            own.update(m._buffers)
+            order = getattr(m, "_TLX_ORDER", None) or list(own)
+            for k in order:
+                t = own.get(k)
+                if t is None or k in Module._DERIVED:
+                    continue
+                out.append(((prefix + "." if prefix else "") + k, t))
+        return out
+
+    def save_weights(self, file_path, format=None):
+        """format 'npz' (the default for a .npz path, as in TensorLayerX): ONE object array under the key `params`, the
+        weights in tlx_weights() order, no names [TLX-recalled: tlx.files.save_npz].  format 'npz_dict': {dotted name:
+        array}.  Conv filters are stored OIHW and Linear weights (in_features, out_features), as the torch backend of
+        TensorLayerX keeps them [TLX-recalled]."""
+        self._adopt_lists()
+        fmt = format or "npz"
+        if fmt == "npz":
+            arrs = [t.detach().float().cpu().numpy() for _, t in self.tlx_weights()]
+            params = np.empty(len(arrs), dtype=object)
+            for i, a in enumerate(arrs):
+                params[i] = a
+            np.savez(file_path, params=params)
+        elif fmt == "npz_dict":
+            np.savez(file_path, **{k: v.detach().float().cpu().numpy() for k, v in self.state_dict().items()})
+        else:
+            raise NotImplementedError(f"save_weights: format {fmt!r} (npz and npz_dict are supported)")
 
     def load_weights(self, file_path, format=None, in_order=True, skip=False):
+        """Loads either checkpoint form (detected from the file): the positional `params` list TensorLayerX's
+        save_weights('x.npz') writes — assigned to tlx_weights() in order, every shape checked — or a name-keyed
+        npz_dict (in_order=False semantics; `skip` tolerates missing names).  predict.py:19."""
         self._adopt_lists()
-        data = np.load(file_path, allow_pickle=False)
-        sd = self.state_dict()
-        missing = [k for k in sd if k not in data.files]
-        if missing and not skip:
-            raise KeyError(f"load_weights: {len(missing)} entries missing from {file_path}, e.g. {missing[:3]}")
+        data = np.load(file_path, allow_pickle=True)
         with torch.no_grad():
-            for k, t in sd.items():
-                if k in data.files:
-                    a = torch.as_tensor(data[k])
+            if "params" in data.files and len(data.files) == 1:
+                params = list(data["params"])
+                mine = self.tlx_weights()
+                if len(params) != len(mine):
+                    raise ValueError(f"load_weights: {file_path} holds {len(params)} arrays, the model has {len(mine)} weights")
+                for (k, t), a in zip(mine, params):
+                    a = torch.as_tensor(np.asarray(a))
                     if tuple(a.shape) != tuple(t.shape):
-                        raise ValueError(f"load_weights: {k} has shape {tuple(a.shape)}, expected {tuple(t.shape)}")
+                        raise ValueError(f"load_weights: position of {k}: shape {tuple(a.shape)}, expected {tuple(t.shape)}")
                     t.copy_(a.to(t.dtype))
-        for m in self.modules():
-            if isinstance(m, Module):
-                m._engine_cache.clear()
+            else:
+                sd = self.state_dict()
+                missing = [k for k in sd if k not in data.files and k.rsplit(".", 1)[-1] not in Module._DERIVED]
+                if missing and not skip:
+                    raise KeyError(f"load_weights: {len(missing)} entries missing from {file_path}, e.g. {missing[:3]}")
+                for k, t in sd.items():
+                    if k in data.files:
+                        a = torch.as_tensor(data[k])
+                        if tuple(a.shape) != tuple(t.shape):
+                            raise ValueError(f"load_weights: {k} has shape {tuple(a.shape)}, expected {tuple(t.shape)}")
+                        t.copy_(a.to(t.dtype))
+        self._invalidate()
 
     def load_dict(self, named, strict=True):
         """Assign {dotted name: numpy/torch array}; used by tests and benches with seeded recipes."""
         self._adopt_lists()
         sd = self.state_dict()
-        derived = ("attn_mask", "relative_position_bias", "relative_position_index")   # computed buffers
+        derived = Module._DERIVED   # computed buffers
         unknown = [k for k in named if k not in sd]
         missing = [k for k in sd if k not in named and sd[k].is_floating_point()
                    and k.rsplit(".", 1)[-1] not in derived]
@@ -173,9 +225,12 @@ class Module(torch.nn.Module):
                     if tuple(a.shape) != tuple(sd[k].shape):
                         raise ValueError(f"load_dict: {k} shape {tuple(a.shape)} != {tuple(sd[k].shape)}")
                     sd[k].copy_(a.to(sd[k].dtype))
-        for m in self.modules():
-            if isinstance(m, Module):
-                m._engine_cache.clear()
+        self._invalidate()
+
+    def load_state_dict(self, *args, **kwargs):
+        r = super().load_state_dict(*args, **kwargs)
+        self._invalidate()
+        return r
 
     def _require_eval(self):
         if self.is_train:
@@ -183,12 +238,31 @@ class Module(torch.nn.Module):
                 f"{type(self).__name__}: training-mode forward is out of scope for the MI355X inference "
                 "engine — call model.set_eval() first (tasks/image_classification.py:21 does).")
 
-    def _cached(self, key, build):
+    def _invalidate(self):
+        """Weights of this sub-tree were (re)loaded or moved: drop every derived tensor and advance the epoch a captured
+        hipGraph (graph.GraphedForward) compares before each replay."""
+        for m in self.modules():
+            if isinstance(m, Module):
+                m._engine_cache.clear()
+                m._weights_epoch += 1
+
+    def _stamp(self):
+        """(storage address, in-place version) of every parameter / buffer this module owns: a derived tensor (packed
+        filter, folded BatchNorm, bias table) is rebuilt when any of them was reassigned or written in place —
+        load_state_dict, p.copy_(), p.data = ... — not only by this class's own loaders."""
+        return tuple((t.data_ptr(), t._version) for t in list(self._parameters.values()) + list(self._buffers.values())
+                     if t is not None)
+
+    def _cached(self, key, build, deps=()):
+        """Derived tensors of this layer, keyed by (key, precision) and validated against the parameter stamps of this
+        module and of `deps` (other modules whose weights went into the value, e.g. the BatchNorm folded into a conv)."""
         k = (key, E.precision())
-        v = self._engine_cache.get(k)
-        if v is None:
-            v = build()
-            self._engine_cache[k] = v
+        stamp = self._stamp() + tuple(s_ for d in deps for s_ in d._stamp())
+        hit = self._engine_cache.get(k)
+        if hit is not None and hit[0] == stamp:
+            return hit[1]
+        v = build()
+        self._engine_cache[k] = (stamp, v)
         return v
 
 
@@ -250,7 +324,15 @@ def as_nhwc(x, data_format="channels_first"):
     return E.nchw_to_nhwc(x, dt)
 
 
-def from_nhwc(y, data_format="channels_first"):
+def true_channels(x, data_format="channels_first"):
+    return x.shape[-1] if data_format == "channels_last" else x.shape[1]
+
+
+def from_nhwc(y, data_format="channels_first", channels=None):
+    """Physical NHWC -> the caller's logical layout.  `channels`: the true channel count when as_nhwc() had to pad the
+    channel axis to a whole number of 16-byte chunks (C = 3, 30, 291 ...): the padding is cropped off again."""
+    if channels is not None and y.shape[-1] != channels:
+        y = y[..., :channels]
     return y if data_format == "channels_last" else y.permute(0, 3, 1, 2)
 
 
@@ -266,14 +348,7 @@ class _Act(Module):
     PARAM = 0.0
 
     def forward(self, x):
-        E.need_gpu(x, "input")
-        if x.dtype != E.precision():
-            x = x.to(E.precision())
-        if x.dim() == 4:  # keep the physical layout, run over the flat buffer
-            v = x.permute(0, 2, 3, 1)
-            if v.is_contiguous():
-                return E.affine_act(v, act=self.ACT, act_param=self.PARAM).permute(0, 3, 1, 2)
-        return E.affine_act(x.contiguous(), act=self.ACT, act_param=self.PARAM)
+        return E.act_flat(x, self.ACT, self.PARAM)      # elementwise: any shape, any channel count, layout kept
 
 
 class ReLU(_Act):  # resnet.py:50,138,212
@@ -422,7 +497,7 @@ class GroupConv2d(Module):
         else:   # 1 < n_group < C: ResNeXt cardinality, resnext.py:83-91
             pk = self._cached("gpk", lambda: E.PackedGroupFilter(self.filters, self.n_group, dt))
         if bn is not None:
-            scale, shift = self._cached(("bn", id(bn)), lambda: bn.folded(self.biases))
+            scale, shift = self._cached(("bn", id(bn)), lambda: bn.folded(self.biases), deps=(bn,))
         else:
             scale, shift = None, (self._cached("bias", lambda: E._f32(self.biases)) if self.biases is not None else None)
         if self.n_group == 1:
@@ -464,7 +539,7 @@ class GroupConv2d(Module):
             return E.PackedFilter(w2, dt), pad2
         pk, pad2 = self._cached(("s2d", b, pad[0]), build)
         if bn is not None:
-            scale, shift = self._cached(("bn", id(bn)), lambda: bn.folded(self.biases))
+            scale, shift = self._cached(("bn", id(bn)), lambda: bn.folded(self.biases), deps=(bn,))
         else:
             scale, shift = None, (self._cached("bias", lambda: E._f32(self.biases)) if self.biases is not None else None)
         v = E.nchw_to_nhwc_s2d(x_nchw, b, dt)
@@ -501,6 +576,7 @@ class BatchNorm2d(Module):
             raise ValueError("BatchNorm2d: num_features must be given")
         self.num_features, self.epsilon, self.momentum = int(num_features), float(epsilon), momentum
         self.data_format, self.act = data_format, str_to_act(act)
+        self._TLX_ORDER = ("beta", "gamma", "moving_mean", "moving_var")
         n = (self.num_features,)
         self.gamma = Parameter(data=str_to_init(gamma_init)(shape=n))
         self.beta = Parameter(data=str_to_init(beta_init)(shape=n))
@@ -512,9 +588,17 @@ class BatchNorm2d(Module):
 
     def forward(self, x):
         self._require_eval()
-        scale, shift = self._cached("fold", self.folded)
         v = as_nhwc(x, self.data_format)
-        y = from_nhwc(E.affine_act(v, scale, shift), self.data_format)
+        cpad = v.shape[-1]
+
+        def padded():       # (scale, shift) over the padded channel axis: the kernel reads v.shape[-1] of each
+            sc, sh = self.folded()
+            if cpad == self.num_features:
+                return sc, sh
+            z = torch.zeros(cpad - self.num_features, dtype=sc.dtype, device=sc.device)
+            return torch.cat([sc, z]).contiguous(), torch.cat([sh, z]).contiguous()
+        scale, shift = self._cached(("fold", cpad), padded)
+        y = from_nhwc(E.affine_act(v, scale, shift), self.data_format, self.num_features)
         return self.act(y) if self.act is not None else y
 
 
@@ -576,7 +660,7 @@ class Linear(Module):
         if not E.linear_ln_supported(self.in_features, self.out_features, dt, x.numel() // x.shape[-1], x.device):
             return self.run(norm(x), act=act)
         prep = self._cached(("ln", id(norm)), lambda: E.LinearLN(self.weights.detach().t().contiguous(), self.biases,
-                                                                 norm.gamma, norm.beta, dt))
+                                                                 norm.gamma, norm.beta, dt), deps=(norm,))
         return E.linear_ln(x, prep, norm.epsilon, act)
 
     def forward(self, x):
@@ -602,7 +686,7 @@ class MaxPool2d(Module):
         return E.maxpool2d(x, self.kernel_size, self.stride, self.padding)
 
     def forward(self, x):
-        return from_nhwc(self.run_nhwc(as_nhwc(x, self.data_format)), self.data_format)
+        return from_nhwc(self.run_nhwc(as_nhwc(x, self.data_format)), self.data_format, true_channels(x, self.data_format))
 
 
 class AvgPool2d(Module):
@@ -625,7 +709,7 @@ class AvgPool2d(Module):
         return E.avgpool2d(v, self.kernel_size, self.stride, self.padding)
 
     def forward(self, x):
-        return from_nhwc(self.run_nhwc(as_nhwc(x, self.data_format)), self.data_format)
+        return from_nhwc(self.run_nhwc(as_nhwc(x, self.data_format)), self.data_format, true_channels(x, self.data_format))
 
 
 class AdaptiveAvgPool2d(Module):
@@ -644,7 +728,7 @@ class AdaptiveAvgPool2d(Module):
         return E.adaptive_avgpool2d(v, self.output_size)
 
     def forward(self, x):
-        return from_nhwc(self.run_nhwc(as_nhwc(x, self.data_format)), self.data_format)
+        return from_nhwc(self.run_nhwc(as_nhwc(x, self.data_format)), self.data_format, true_channels(x, self.data_format))
 
 
 class AdaptiveAvgPool1d(Module):
@@ -675,4 +759,4 @@ class UpSampling2d(Module):
         v = as_nhwc(x, self.data_format)
         N, H, W, Cc = v.shape
         out = torch.empty((N, 2 * H, 2 * W, Cc), dtype=v.dtype, device=v.device)
-        return from_nhwc(E.upsample2x_into(v, out, 0), self.data_format)
+        return from_nhwc(E.upsample2x_into(v, out, 0), self.data_format, true_channels(x, self.data_format))

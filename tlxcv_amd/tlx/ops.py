@@ -12,12 +12,12 @@ def softmax(logits, axis=-1):
 
 def sigmoid(x):
     _E.need_gpu(x)
-    return _E.affine_act(x.contiguous(), act=_E.ACT_SIGMOID)
+    return _E.act_flat(x, _E.ACT_SIGMOID)
 
 
 def relu(x):
     _E.need_gpu(x)
-    return _E.affine_act(x.contiguous(), act=_E.ACT_RELU)
+    return _E.act_flat(x, _E.ACT_RELU)
 
 
 def arange(start, limit=None, delta=1, dtype=None):

@@ -19,7 +19,7 @@ for s in "$@"; do
         smoke) step smoke 400 python -c "import __graft_entry__ as g; g.smoke()" ;;
         tests) step pytest 900 python -m pytest tests -m gpu -q -x --timeout=600 ;;
         testsall) step pytest 900 python -m pytest tests -m gpu -q --timeout=600 ;;
-        bench) step bench 600 python bench.py --steps 20 --warmup 5 ;;
+        bench) step bench 600 python bench.py ;;
         benchvit) step benchvit 600 python bench.py --workload vit_b16 --steps 10 --warmup 3 --no-cpu-baseline ;;
         benchswin) step benchswin 600 python bench.py --workload swin_b --steps 10 --warmup 3 --no-cpu-baseline ;;
         prof) cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
