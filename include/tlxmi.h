@@ -283,6 +283,30 @@ int tlxmi_attention(const tlxmi_attn_desc* d, const void* qkv, const float* bias
 int tlxmi_attention_comb(const tlxmi_attn_desc* d, const void* qkv, const float* comb, void* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * General multi-head attention on separate, strided Q / K / V — the core of tlx.nn.MultiheadAttention and of DETR's
+ * MultiHeadAttention.forward (tlxcv/models/detection/detr.py:1003-1062): query and key lengths may differ, layouts
+ * are given by element strides (sequence-first [L][B][D]: batch stride D, row stride B*D; batch-first: batch stride
+ * L*D, row stride D; a packed qkv matrix: three pointers into it with row stride 3*D), head h of a row is the hd
+ * values at offset h*hd.
+ *   out[b][i][h*hd + :] = sum_j softmax_j( (scale * q_i) . k_j + mask[..][i][j] ) v_j
+ *   mask_mode 0: none; 1: one fp32 [Lq][Lk] mask for every (batch, head); 2: [B*heads][Lq][Lk] (detr.py:1038-1039)
+ *   avg_weights: optional fp32 [B][Lq][Lk] output, the softmax weights averaged over the heads (detr.py:1054-1060);
+ *                NULL = not wanted.
+ * hd <= 128.  A coverage kernel (any lengths), not a tuned one: self attention over a packed qkv of <= 256 tokens
+ * belongs on tlxmi_attention.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct tlxmi_mha_desc {
+    int32_t dtype;
+    int32_t B, Lq, Lk, heads, hd;
+    float scale;
+    int32_t mask_mode;
+    int64_t q_batch_stride, q_row_stride, k_batch_stride, k_row_stride, v_batch_stride, v_row_stride,
+            out_batch_stride, out_row_stride;       /* in elements */
+} tlxmi_mha_desc;
+int tlxmi_mha(const tlxmi_mha_desc* d, const void* q, const void* k, const void* v, const float* mask,
+              void* out, float* avg_weights, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Swin window plumbing folded into index math (swin_transformer.py:85-116, 317-333):
  *   partition: x[B][H][W][C] --roll(-shift)--> windows [B*nW][ws*ws][C]
  *   reverse:   windows --> x (+roll(+shift)), optionally y = res + reverse(windows)

@@ -578,6 +578,54 @@ def darknet53(p, x, pre="", return_idx=(2, 3, 4)):
     return blocks
 
 
+def mobilenet_det(p, x, pre="", scale=1, feature_maps=(4, 6, 13), extra_block_filters=None):
+    """MobileNet.forward of the detection backbone, detection/backbones/mobilenet_v1.py:233-240; ConvBNLayer.forward
+    :41-49 (conv without bias, BatchNorm, relu — relu6 in the extra blocks :121-130); DepthwiseSeparable.forward :94-97;
+    cfgs :205-215; list children are named dwsl_<i> / extra_blocks_<i>."""
+    def cbl(name, x, stride, padding, groups=1, act=F.relu):
+        return act(bn(p, name + ".my_batch_norm", conv(p, name + "._conv", x, stride, padding, 1, groups)))
+    cfgs = [[32, 64, 1], [64, 128, 2], [128, 128, 1], [128, 256, 2], [256, 256, 1], [256, 512, 2],
+            *[[512, 512, 1]] * 5, [512, 1024, 2], [1024, 1024, 1]]
+    outs = []
+    y = cbl(pre + "conv1", x, 2, 1)
+    for i, (ci, co, s_) in enumerate(cfgs):
+        y = cbl(f"{pre}dwsl_{i}._depthwise_conv", y, s_, 1, groups=int(ci * scale))
+        y = cbl(f"{pre}dwsl_{i}._pointwise_conv", y, 1, 0)
+        if i + 1 in feature_maps:
+            outs.append(y)
+    for i, _ in enumerate(extra_block_filters or []):
+        y = cbl(f"{pre}extra_blocks_{i}.pointwise_conv", y, 1, 0, act=F.relu6)
+        y = cbl(f"{pre}extra_blocks_{i}.normal_conv", y, 2, 1, act=F.relu6)
+        if len(cfgs) + i + 1 in feature_maps:
+            outs.append(y)
+    return outs
+
+
+def detr_mha(p, pre, query, key, value, num_heads, attn_mask=None, need_weights=True):
+    """MultiHeadAttention.forward, detection/detr.py:1003-1062: sequence-first (L, B, D) inputs, packed in_proj applied
+    slice by slice (:1010-1020), q scaled before q k^T (:1022), + attn_mask (:1038-1039), softmax, @ v, out_proj,
+    weights averaged over the heads (:1054-1060)."""
+    D = query.shape[-1]
+    hd = D // num_heads
+    W, b = p[pre + "in_proj_weight"], p[pre + "in_proj_bias"]
+    T, B, S = query.shape[0], query.shape[1], key.shape[0]
+    WQ = torch.matmul(query, W[:D].t()) + b[:D]
+    WK = torch.matmul(key, W[D:2 * D].t()) + b[D:2 * D]
+    WV = torch.matmul(value, W[2 * D:].t()) + b[2 * D:]
+    WQ = (WQ * float(hd) ** -0.5).reshape(T, B * num_heads, hd).permute(1, 0, 2)
+    WK = WK.reshape(S, B * num_heads, hd).permute(1, 0, 2)
+    WV = WV.reshape(S, B * num_heads, hd).permute(1, 0, 2)
+    w = torch.matmul(WQ, WK.transpose(-1, -2))
+    if attn_mask is not None:
+        w = w + attn_mask
+    w = torch.softmax(w, dim=-1)
+    o = torch.matmul(w, WV).permute(1, 0, 2).reshape(T, B, D)
+    o = torch.matmul(o, p[pre + "out_proj_weight"].t()) + p[pre + "out_proj_bias"]
+    if need_weights:
+        return o, w.reshape(B, num_heads, T, S).mean(dim=1)
+    return o
+
+
 def yolov3_neck(p, feats, pre="neck."):
     """YOLOv3FPN.forward, yolov3.py:239-258; YoloDetBlock.forward :180-183."""
     X = feats[::-1]

@@ -273,6 +273,62 @@ def gen_darknet(batch, hw, wseed, xseed, fname):
         param_names=np.array(list(shapes.keys())), torch_version=torch.__version__)
 
 
+def gen_mobilenet_det(batch, hw, wseed, xseed, fname):
+    """The detection MobileNet backbone (backbones/mobilenet_v1.py), with the SSD-style extra blocks switched on so that
+    ExtraBlock / relu6 are covered: feature maps after blocks 4, 6, 13 and the first two extra blocks."""
+    ref = import_reference("tlxcv/models/detection/backbones/mobilenet_v1.py", "ref_mobilenet_det")
+    kw = dict(feature_maps=[4, 6, 13, 14, 15], with_extra_blocks=True, extra_block_filters=[[256, 512], [128, 256]])
+    model = ref.MobileNet(**kw)
+    shapes = seeded.shapes_of(model)
+    params = seeded.fill(shapes, wseed)
+    model.load_dict(params)
+    model.set_eval()
+    x = torch.from_numpy(seeded.image_batch(batch, xseed, hw=hw))
+    with torch.no_grad():
+        ref_out = model({"images": x})
+        re_out = OF.mobilenet_det({k: torch.from_numpy(v) for k, v in params.items()}, x, feature_maps=kw["feature_maps"],
+                                  extra_block_filters=kw["extra_block_filters"])
+    assert len(ref_out) == len(re_out) == 5
+    d = max(_check(f"mobilenet_det feature {i}", a, b) for i, (a, b) in enumerate(zip(ref_out, re_out)))
+    np.savez_compressed(
+        os.path.join(OUT, fname), arch="MobileNet(det)", weight_seed=wseed, input_seed=xseed, batch=batch, hw=hw,
+        **{f"feat{i}": o.numpy() for i, o in enumerate(ref_out)},
+        restatement_max_abs_diff=np.float64(d), pinned_by="reference-file-on-tlx_cpu",
+        param_names=np.array(list(shapes.keys())), torch_version=torch.__version__)
+
+
+def gen_detr_mha(fname):
+    """DETR's MultiHeadAttention (detection/detr.py:965-1062), the reference's own class loaded by path: a cross-attention
+    case (7 queries over 13 memory tokens, batch 2, with an additive mask, weights wanted) and a self-attention case
+    (197 tokens, the ViT length, no mask)."""
+    ref = import_reference("tlxcv/models/detection/detr.py", "ref_detr")
+    out = {}
+    rng = np.random.default_rng(40)
+    for tag, D, H, T, S, B, masked in (("cross", 64, 4, 7, 13, 2, True), ("self", 128, 4, 197, 197, 2, False)):
+        m = ref.MultiHeadAttention(D, H)
+        shapes = seeded.shapes_of(m)
+        params = seeded.fill(shapes, 41)
+        m.load_dict(params)
+        m.set_eval()
+        q = torch.from_numpy(rng.standard_normal((T, B, D)).astype(np.float32))
+        kv = q if tag == "self" else torch.from_numpy(rng.standard_normal((S, B, D)).astype(np.float32))
+        mask = None
+        if masked:
+            mask = torch.from_numpy(np.where(rng.random((T, S)) < 0.25, -1e9, 0.0).astype(np.float32))
+            mask[:, 0] = 0.0
+        with torch.no_grad():
+            o, w = m((q, kv, kv), attn_mask=mask)
+            o2, w2 = OF.detr_mha({k: torch.from_numpy(v) for k, v in params.items()}, "", q, kv, kv, H, mask)
+        d = max(_check(f"detr mha {tag} out", o.reshape(-1, D), o2.reshape(-1, D)), _check(f"detr mha {tag} weights", w.reshape(-1, S), w2.reshape(-1, S)))
+        out.update({f"{tag}_q": q.numpy(), f"{tag}_kv": kv.numpy(), f"{tag}_out": o.numpy(), f"{tag}_weights": w.numpy(),
+                    f"{tag}_dims": np.array([D, H, T, S, B]), f"{tag}_diff": np.float64(d)})
+        if mask is not None:
+            out[f"{tag}_mask"] = mask.numpy()
+    np.savez_compressed(os.path.join(OUT, fname), weight_seed=41, pinned_by="reference-file-on-tlx_cpu",
+                        restatement_max_abs_diff=np.float64(max(out["cross_diff"], out["self_diff"])),
+                        param_names=np.array(list(shapes.keys())), torch_version=torch.__version__, **out)
+
+
 def gen_yolov3(batch, hw, wseed, xseed, fname):
     """detection/yolov3.py loaded unmodified as a module of a synthetic parent package (its relative imports resolve
     against the reference tree; `decorator` / `torchvision` from oracle/shims).  YOLOv3.forward (yolov3.py:51-104) is
@@ -404,7 +460,9 @@ def main(only=()):
     job(gen_efficientnet, "efficientnet_b2", 1, 130, 16, 14, "efficientnet_b2_b1.npz")     # width / depth multipliers, odd extents under 'SAME' 
     job(gen_darknet, 1, 64, 5, 2, "darknet53_b1.npz")
     job(gen_yolov3, 1, 64, 6, 3, "yolov3_b1.npz")
+    job(gen_mobilenet_det, 1, 128, 23, 17, "mobilenet_det_b1.npz")
     job(gen_tlx_npz, "tlx_npz_small.npz")
+    job(gen_detr_mha, "detr_mha.npz")
     for fn, args, kw in jobs:
         fn(*args, **kw)
 

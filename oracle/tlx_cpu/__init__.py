@@ -113,6 +113,10 @@ def meshgrid(*args, indexing="ij"):
     return torch.meshgrid(*args, indexing=indexing)
 
 
+def reduce_mean(input_tensor, axis=None, keepdims=False):
+    return torch.mean(input_tensor) if axis is None else torch.mean(input_tensor, dim=axis, keepdim=keepdims)
+
+
 def argmax(x, axis=None, dtype="int64"):
     return torch.argmax(x, dim=axis)
 

@@ -64,6 +64,9 @@ class Module(torch.nn.Module):
     def register_parameter(self, name=None, param=None):
         return super().register_parameter(name, param)
 
+    def str_to_init(self, s):
+        return str_to_init(s)
+
     def _get_weights(self, var_name, shape, init=None, trainable=True, order=False):
         init = str_to_init(init)
         p = Parameter(data=init(shape=tuple(shape)))

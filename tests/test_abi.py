@@ -42,15 +42,17 @@ def test_descriptor_layout_matches_c(tmp_path):
     prog = tmp_path / "sz.c"
     prog.write_text(
         '#include <stdio.h>\n#include <stddef.h>\n#include "tlxmi.h"\n'
-        'int main(void){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(tlxmi_conv2d_desc), sizeof(tlxmi_dwconv2d_desc),'
+        'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(tlxmi_conv2d_desc), sizeof(tlxmi_dwconv2d_desc),'
         ' sizeof(tlxmi_attn_desc), offsetof(tlxmi_conv2d_desc, act_param), offsetof(tlxmi_conv2d_desc, flags),'
-        ' offsetof(tlxmi_attn_desc, scale));return 0;}\n')
+        ' offsetof(tlxmi_attn_desc, scale), sizeof(tlxmi_mha_desc), offsetof(tlxmi_mha_desc, q_batch_stride),'
+        ' offsetof(tlxmi_mha_desc, out_row_stride));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(REPO, "include"), str(prog), "-o", str(exe)])
     out = subprocess.check_output([str(exe)]).split()
     got = [int(x) for x in out]
     want = [ctypes.sizeof(_lib.ConvDesc), ctypes.sizeof(_lib.DwConvDesc), ctypes.sizeof(_lib.AttnDesc),
-            _lib.ConvDesc.act_param.offset, _lib.ConvDesc.flags.offset, _lib.AttnDesc.scale.offset]
+            _lib.ConvDesc.act_param.offset, _lib.ConvDesc.flags.offset, _lib.AttnDesc.scale.offset,
+            ctypes.sizeof(_lib.MhaDesc), _lib.MhaDesc.q_batch_stride.offset, _lib.MhaDesc.out_row_stride.offset]
     assert got == want
 
 

@@ -57,13 +57,13 @@ def test_predict_script_body_runs_on_the_engine(dev, tmp_path, fp32_mode):
         backbone.load_dict(params)
         w = str(tmp_path / "model.npz")
         model.save_weights(w)
-        model.load_weights(w)                                   # predict.py:19
-        model.to("cuda")
-        model.set_eval()                                        # :20
+        model.load_weights(w)                                   # predict.py:19  (positional TLX .npz)
+        model.set_eval()                                        # :20  (lazy device placement: no extra line)
+        assert next(model.parameters()).is_cuda
         image = load_image(f)                                   # :22
         transform = Compose([Resize((224, 224)), Normalize(mean=(125.31, 122.95, 113.86), std=(62.99, 62.09, 66.70)),
                              ToTensor(data_format=data_format_short)])
-        image = tlx.expand_dims(transform(image), 0)            # :27-29
+        image = tlx.expand_dims(transform(image), 0).cpu()      # :27-29; a HOST tensor, as a script on a CPU-default backend has
         class_id = tlx.convert_to_numpy(model.predict(image)).item()   # :31
         with torch.no_grad():
             ref = oracle({k: torch.from_numpy(v) for k, v in params.items()}, image.cpu())

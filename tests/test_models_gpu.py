@@ -231,6 +231,44 @@ def test_yolov3_neck_and_head(dev, mode):
         tlxcv_amd.set_precision("fp16")
 
 
+MBDET_KW = dict(feature_maps=[4, 6, 13, 14, 15], with_extra_blocks=True, extra_block_filters=[[256, 512], [128, 256]])
+
+
+@pytest.mark.parametrize("mode", ["fp32", "fp16"])
+def test_detection_mobilenet_backbone_feature_maps(dev, mode):
+    """detection/backbones/mobilenet_v1.py:233-240 (fixture from the reference's own file): the three YOLO feature maps
+    plus two SSD-style extra blocks (relu6)."""
+    import tlxcv_amd
+    tlxcv_amd.set_precision(mode)
+    try:
+        g = np.load(os.path.join(GOLDEN, "mobilenet_det_b1.npz"))
+        m = build("MobileNet", int(g["weight_seed"]), dev, **MBDET_KW)
+        x = torch.from_numpy(seeded.image_batch(1, int(g["input_seed"]), hw=int(g["hw"]))).to(dev)
+        feats = m({"images": x})
+        assert len(feats) == 5 and m._out_channels == [256, 512, 1024, 512, 256]
+        for i, f in enumerate(feats):
+            _close(f, g[f"feat{i}"], mode)
+    finally:
+        tlxcv_amd.set_precision("fp16")
+
+
+def test_yolov3_on_the_mobilenet_backbone_runs_to_the_head_maps(dev, fp32_mode):
+    """YOLOv3(backbone="MobileNet") (yolov3.py:6,36): the neck's in_channels [256, 512, 1024] are this backbone's
+    feature maps; checked against the oracle restatement end to end."""
+    from oracle import functional as OF
+    m = build("YOLOv3", 31, dev, backbone="MobileNet")
+    params = seeded.fill(seeded.shapes_of(m), 31)
+    x = torch.from_numpy(seeded.image_batch(1, 32, hw=96))
+    p = {k: torch.from_numpy(v) for k, v in params.items()}
+    with torch.no_grad():
+        body = OF.mobilenet_det(p, x, "backbone.")
+        neck = OF.yolov3_neck(p, body, "neck.")
+        head = [OF.conv(p, f"yolo_head.yolo_outputs_{i}", f) for i, f in enumerate(neck)]
+    out = m({"images": x.to(dev)})
+    for got, ref in zip(out["yolo_head_outs"], head):
+        assert np.abs(got.cpu().numpy() - ref.numpy()).max() <= 1e-4 * max(1.0, float(ref.abs().max()))
+
+
 def test_swin_block_api_and_shift_mask(dev, fp32_mode):
     """One shifted block through the layer-level API vs the oracle restatement (exercises roll + mask)."""
     from oracle import functional as OF
@@ -244,3 +282,28 @@ def test_swin_block_api_and_shift_mask(dev, fp32_mode):
         ref = OF.swin_block({"b." + k: torch.from_numpy(v) for k, v in params.items()}, "b", x, 14, 14, 2, 7, 3)
     got = blk(x.to(dev))
     torch.testing.assert_close(got.cpu(), ref, atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("tag", ["vit", "mbv1"])
+def test_positional_tlx_npz_checkpoint_gives_the_reference_logits(dev, fp32_mode, tag, tmp_path):
+    """the positional `.npz` the reference's own class wrote (through the stand-in's save_weights)
+    loads into the engine model by position and the engine computes the reference's logits from it."""
+    from tlxcv_amd import models
+    g = np.load(os.path.join(GOLDEN, "tlx_npz_small.npz"))
+    n = int(g[f"{tag}_n"])
+    params = np.empty(n, dtype=object)
+    for i in range(n):
+        params[i] = g[f"{tag}_params_{i:03d}"]
+    path = str(tmp_path / "model.npz")
+    np.savez(path, params=params)
+    m = {"vit": lambda: models.VisionTransformer(img_size=32, patch_size=8, num_classes=10, embed_dim=32, depth=2, num_heads=2,
+                                                 mlp_ratio=2, qkv_bias=True, epsilon=1e-6),
+         "mbv1": lambda: models.MobileNetV1(scale=0.125, num_classes=10)}[tag]()
+    m.load_weights(path)                     # predict.py:19
+    m.set_eval()                             # :20 (moves the model to the GPU)
+    x = torch.from_numpy(seeded.image_batch(2, int(g[f"{tag}_input_seed"]), hw=int(g[f"{tag}_hw"])))
+    from tlxcv_amd.tasks import ImageClassification
+    task = ImageClassification(m)
+    y = task(x)                              # host tensor in: uploaded at the task boundary
+    assert np.abs(y.cpu().numpy() - g[f"{tag}_logits"]).max() <= 1e-4
+    assert (task.predict(x).cpu().numpy() == g[f"{tag}_logits"].argmax(-1)).all()

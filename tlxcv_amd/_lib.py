@@ -33,6 +33,13 @@ class AttnDesc(C.Structure):
         ("scale", C.c_float), ("nW", C.c_int32)]
 
 
+class MhaDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("dtype", "B", "Lq", "Lk", "heads", "hd")] + [
+        ("scale", C.c_float), ("mask_mode", C.c_int32)] + [(n, C.c_int64) for n in (
+            "q_batch_stride", "q_row_stride", "k_batch_stride", "k_row_stride", "v_batch_stride", "v_row_stride",
+            "out_batch_stride", "out_row_stride")]
+
+
 _vp, _i, _f, _u, _l = C.c_void_p, C.c_int, C.c_float, C.c_uint32, C.c_int64
 
 # name -> argtypes; every function returns int status unless listed in _SPECIAL
@@ -62,6 +69,7 @@ PROTOTYPES = {
     "tlxmi_linear_ln": [_i, _l, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
     "tlxmi_attention": [C.POINTER(AttnDesc), _vp, _vp, _vp, _vp, _vp],
     "tlxmi_attention_comb": [C.POINTER(AttnDesc), _vp, _vp, _vp, _vp],
+    "tlxmi_mha": [C.POINTER(MhaDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "tlxmi_window_partition": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "tlxmi_window_reverse": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "tlxmi_patch_merge_gather": [_vp, _vp, _i, _i, _i, _i, _i, _vp],

@@ -173,6 +173,91 @@ template <typename T> static int launch_rows(const AttnArgs& a, hipStream_t st) 
 
 int launch_attn_mfma(const AttnArgs& a, hipStream_t st);  // attention_mfma.hip
 
+// General multi-head attention: separate, strided Q / K / V (sequence-first or batch-first, packed or not), query and
+// key lengths may differ (cross attention), optional additive mask, optional head-averaged weights.
+// Reference: MultiHeadAttention.forward, detection/detr.py:1003-1062 (q scaled by hd^-0.5 before q k^T :1023, + attn_mask
+// :1038-1039, softmax :1041, @ v :1044, weights averaged over the heads :1054-1060); tlx.nn.MultiheadAttention.
+// A coverage kernel (one wave per query row, keys in tiles of 64 with the usual running max / sum; with WEIGHTS the
+// wave walks all heads of its row and re-derives the probabilities in a second pass so it can add p / heads into
+// avgw[b][row][:] without atomics), not a tuned one: self attention of <= 256 tokens is routed to tlxmi_attention.
+struct MhaArgs {
+    const void *q, *k, *v;
+    void* out;
+    const float* mask;
+    float* avgw;
+    int B, Lq, Lk, heads, hd;
+    long q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs;   // element strides: batch, row
+    long mask_bs;                                          // 0: one [Lq][Lk] mask; Lq*Lk: one per (batch, head)
+    float scale;
+};
+
+template <typename T, bool WEIGHTS>
+__global__ __launch_bounds__(256) void mha_rows_kernel(const MhaArgs a) {
+    __shared__ float ps[4][64];
+    __shared__ float qs[4][128];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int row = blockIdx.y * 4 + wv;
+    if (row >= a.Lq) return;       // wave-uniform; no block-wide barrier below
+    const int b = WEIGHTS ? (int)blockIdx.x : (int)blockIdx.x / a.heads;
+    const int h0 = WEIGHTS ? 0 : (int)blockIdx.x - b * a.heads, h1 = WEIGHTS ? a.heads : h0 + 1;
+    const int hd = a.hd, Lk = a.Lk;
+    float* wrow = WEIGHTS ? a.avgw + ((long)b * a.Lq + row) * Lk : nullptr;
+    const float invh = 1.f / (float)a.heads;
+    for (int h = h0; h < h1; ++h) {
+        const T* qb = reinterpret_cast<const T*>(a.q) + b * a.q_bs + row * a.q_rs + (long)h * hd;
+        const T* kb = reinterpret_cast<const T*>(a.k) + b * a.k_bs + (long)h * hd;
+        const T* vb = reinterpret_cast<const T*>(a.v) + b * a.v_bs + (long)h * hd;
+        const float* mask = a.mask ? a.mask + ((long)b * a.heads + h) * a.mask_bs + (long)row * Lk : nullptr;
+        for (int d = lane; d < hd; d += 64) qs[wv][d] = (float)qb[d] * a.scale;     // q scaled first (detr.py:1023)
+        __builtin_amdgcn_wave_barrier();
+        float m = -INFINITY, l = 0.f, o0 = 0.f, o1 = 0.f;   // running max / sum; output dims lane, lane + 64
+        for (int j0 = 0; j0 < Lk; j0 += 64) {
+            const int j = j0 + lane;
+            float s = -INFINITY;
+            if (j < Lk) {
+                float acc = 0.f;
+                const T* kr = kb + j * a.k_rs;
+                for (int d = 0; d < hd; ++d) acc = fmaf(qs[wv][d], (float)kr[d], acc);
+                if (mask) acc += mask[j];
+                s = acc;
+            }
+            const float mn = fmaxf(m, wave_max(s));
+            // a row whose every key so far is masked with -inf keeps m = mn = -inf: exp(-inf - -inf) must not poison it
+            const float p = (j < Lk && mn > -INFINITY) ? expf(s - mn) : 0.f;
+            const float corr = mn > -INFINITY ? expf(m - mn) : 1.f;     // 0 on the first live tile (m = -inf)
+            l = l * corr + wave_sum(p);
+            ps[wv][lane] = p;
+            __builtin_amdgcn_wave_barrier();
+            o0 *= corr;
+            o1 *= corr;
+            const int nj = Lk - j0 < 64 ? Lk - j0 : 64;
+            for (int jj = 0; jj < nj; ++jj) {
+                const float pj = ps[wv][jj];
+                const T* vr = vb + (long)(j0 + jj) * a.v_rs;
+                if (lane < hd) o0 = fmaf(pj, (float)vr[lane], o0);
+                if (lane + 64 < hd) o1 = fmaf(pj, (float)vr[lane + 64], o1);
+            }
+            __builtin_amdgcn_wave_barrier();
+            m = mn;
+        }
+        T* out = reinterpret_cast<T*>(a.out) + b * a.o_bs + row * a.o_rs + (long)h * hd;
+        const float inv = 1.f / l;
+        if (lane < hd) out[lane] = (T)(o0 * inv);
+        if (lane + 64 < hd) out[lane + 64] = (T)(o1 * inv);
+        if constexpr (WEIGHTS) {
+            for (int j = lane; j < Lk; j += 64) {
+                float acc = 0.f;
+                const T* kr = kb + j * a.k_rs;
+                for (int d = 0; d < hd; ++d) acc = fmaf(qs[wv][d], (float)kr[d], acc);
+                if (mask) acc += mask[j];
+                const float pw = expf(acc - m) * inv * invh;
+                wrow[j] = h == 0 ? pw : wrow[j] + pw;          // this wave owns the row: plain accumulate
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 }  // namespace tlxmi
 
 using namespace tlxmi;
@@ -195,6 +280,37 @@ extern "C" int tlxmi_attention(const tlxmi_attn_desc* d, const void* qkv, const 
     if (d->dtype == TLXMI_F32) return launch_rows<float>(a, st);
     if ((d->hd == 64 || d->hd == 32 || d->hd == 96) && aligned16(qkv) && aligned16(out)) return launch_attn_mfma(a, st);
     return launch_rows<half_t>(a, st);
+}
+
+extern "C" int tlxmi_mha(const tlxmi_mha_desc* d, const void* q, const void* k, const void* v, const float* mask,
+                         void* out, float* avg_weights, void* stream) {
+    TLXMI_REQUIRE(d && q && k && v && out, TLXMI_ERR_BAD_ARG, "mha: null argument");
+    TLXMI_REQUIRE(d->dtype == TLXMI_F16 || d->dtype == TLXMI_F32, TLXMI_ERR_BAD_ARG, "mha: bad dtype");
+    TLXMI_REQUIRE(d->B > 0 && d->Lq > 0 && d->Lk > 0 && d->heads > 0 && d->hd > 0, TLXMI_ERR_BAD_ARG, "mha: bad extent");
+    TLXMI_REQUIRE(d->hd <= 128 && (long long)d->B * d->heads < (1ll << 31) && d->Lq <= 65535 * 4, TLXMI_ERR_UNSUPPORTED,
+                  "mha: hd=%d (<= 128), Lq=%d", d->hd, d->Lq);
+    TLXMI_REQUIRE(d->mask_mode >= 0 && d->mask_mode <= 2 && (d->mask_mode == 0) == (mask == nullptr), TLXMI_ERR_BAD_ARG,
+                  "mha: mask_mode %d does not match the mask pointer", d->mask_mode);
+    const long need = (long)d->heads * d->hd;
+    TLXMI_REQUIRE(d->q_row_stride >= need || d->B == 1 || d->q_batch_stride >= need, TLXMI_ERR_BAD_ARG, "mha: q strides");
+    MhaArgs a;
+    a.q = q; a.k = k; a.v = v; a.out = out; a.mask = mask; a.avgw = avg_weights;
+    a.B = d->B; a.Lq = d->Lq; a.Lk = d->Lk; a.heads = d->heads; a.hd = d->hd; a.scale = d->scale;
+    a.q_bs = d->q_batch_stride; a.q_rs = d->q_row_stride; a.k_bs = d->k_batch_stride; a.k_rs = d->k_row_stride;
+    a.v_bs = d->v_batch_stride; a.v_rs = d->v_row_stride; a.o_bs = d->out_batch_stride; a.o_rs = d->out_row_stride;
+    a.mask_bs = d->mask_mode == 2 ? (long)d->Lq * d->Lk : 0;
+    hipStream_t st = as_stream(stream);
+    const dim3 blk(256);
+    if (avg_weights) {
+        const dim3 g(d->B, (d->Lq + 3) / 4);
+        if (d->dtype == TLXMI_F32) hipLaunchKernelGGL((mha_rows_kernel<float, true>), g, blk, 0, st, a);
+        else hipLaunchKernelGGL((mha_rows_kernel<half_t, true>), g, blk, 0, st, a);
+    } else {
+        const dim3 g(d->B * d->heads, (d->Lq + 3) / 4);
+        if (d->dtype == TLXMI_F32) hipLaunchKernelGGL((mha_rows_kernel<float, false>), g, blk, 0, st, a);
+        else hipLaunchKernelGGL((mha_rows_kernel<half_t, false>), g, blk, 0, st, a);
+    }
+    return check_launch("mha");
 }
 
 // tlxmi_attention with the relative-position bias and the shift mask handed over pre-summed and padded:

@@ -626,6 +626,38 @@ def attention(qkv, heads, scale, bias=None, mask=None):
     return out
 
 
+def mha(q, k, v, heads, scale, mask=None, need_weights=False, batch_first=False):
+    """General multi-head attention core (tlxmi_mha): q (Lq, B, D), k / v (Lk, B, D) sequence-first — or (B, L, D) with
+    batch_first — any row / batch strides as long as the last axis is dense; mask: additive fp32 (Lq, Lk) or
+    (B*heads, Lq, Lk).  Returns (out in q's layout, head-averaged weights (B, Lq, Lk) fp32 or None)."""
+    for t in (q, k, v):
+        need_gpu(t, "mha operand")
+        if t.stride(-1) != 1:
+            raise RuntimeError("mha: the feature axis must be dense")
+    if not (q.dtype == k.dtype == v.dtype):
+        raise RuntimeError("mha: q / k / v dtypes differ")
+    bd, ld = (0, 1) if batch_first else (1, 0)
+    B, Lq, Lk, D = q.shape[bd], q.shape[ld], k.shape[ld], q.shape[-1]
+    hd = D // heads
+    out = torch.empty(q.shape, dtype=q.dtype, device=q.device)
+    avg = torch.empty((B, Lq, Lk), dtype=torch.float32, device=q.device) if need_weights else None
+    mode = 0
+    if mask is not None:
+        mask = mask.to(device=q.device, dtype=torch.float32).contiguous()
+        if tuple(mask.shape) == (Lq, Lk):
+            mode = 1
+        elif tuple(mask.shape) == (B * heads, Lq, Lk):
+            mode = 2
+        else:
+            raise RuntimeError(f"mha: attn_mask shape {tuple(mask.shape)}; expected ({Lq}, {Lk}) or ({B * heads}, {Lq}, {Lk})")
+    d = _lib.MhaDesc(dtype=dt_code(q.dtype), B=B, Lq=Lq, Lk=Lk, heads=heads, hd=hd, scale=float(scale), mask_mode=mode,
+                     q_batch_stride=q.stride(bd), q_row_stride=q.stride(ld), k_batch_stride=k.stride(bd),
+                     k_row_stride=k.stride(ld), v_batch_stride=v.stride(bd), v_row_stride=v.stride(ld),
+                     out_batch_stride=out.stride(bd), out_row_stride=out.stride(ld))
+    _lib.call("tlxmi_mha", C.byref(d), _p(q), _p(k), _p(v), _p(mask), _p(out), _p(avg), _stream())
+    return out, avg
+
+
 def attention_table(bias, mask, N):
     """bias (heads, N, N) + mask (nW, N, N) or None -> the pre-summed, padded table of tlxmi_attention_comb:
     (max(nW,1), heads, NP, NP) fp32, NP = 32 * ceil(N / 32).  Built once per layer (the reference adds the two on

@@ -12,13 +12,14 @@ from ... import engine as E
 from ...tlx import nn
 from ...tlx.nn import as_nhwc, from_nhwc
 from .backbones.darknet import ConvBNLayer, DarkNet
+from .backbones.mobilenet_v1 import MobileNet
 
 __all__ = ["YOLOv3", "YOLOv3FPN", "YOLOv3Head", "YoloDetBlock"]
 
 
 def create(obj, **kwds):
     if isinstance(obj, str):
-        return {"DarkNet": DarkNet}[obj](**kwds)
+        return {"DarkNet": DarkNet, "MobileNet": MobileNet}[obj](**kwds)      # the reference evals the name (yolov3.py:16-20)
     return obj
 
 

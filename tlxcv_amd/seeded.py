@@ -49,6 +49,7 @@ def fill(shapes, seed):
       *.moving_mean              N(0, 0.05)
       *.moving_var               U(0.8, 1.2)
       pos_embed / cls_token / relative_position_bias_table   N(0, 0.02) clipped at 2 sigma
+      *_weight (attention projections, out x in)   N(0, sqrt(1/fan_in));   *_bias   N(0, 0.02)
     """
     rng = np.random.default_rng(seed)
     out = {}
@@ -72,6 +73,10 @@ def fill(shapes, seed):
             a = rng.uniform(0.8, 1.2, shape).astype(np.float32)
         elif leaf in ("pos_embed", "cls_token", "relative_position_bias_table"):
             a = np.clip(rng.standard_normal(shape, dtype=np.float32), -2, 2) * np.float32(0.02)
+        elif leaf.endswith("_weight") and len(shape) == 2:      # attention projections stored (out, in): detr.py:975-995
+            a = rng.standard_normal(shape, dtype=np.float32) * np.float32(np.sqrt(1.0 / shape[1]))
+        elif leaf.endswith("_bias"):
+            a = rng.standard_normal(shape, dtype=np.float32) * np.float32(0.02)
         else:
             raise KeyError(f"seeded.fill: no rule for parameter {name!r}")
         out[name] = np.ascontiguousarray(a, dtype=np.float32)

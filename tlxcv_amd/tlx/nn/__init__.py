@@ -27,6 +27,7 @@ __all__ = [
     "Module", "Sequential", "ModuleList", "Parameter", "GroupConv2d", "Conv2d", "BatchNorm2d", "BatchNorm",
     "LayerNorm", "Linear", "MaxPool2d", "AdaptiveAvgPool2d", "AdaptiveAvgPool1d", "Dropout", "ReLU", "ReLU6",
     "LeakyReLU", "Hardswish", "HardSigmoid", "Sigmoid", "Softmax", "GELU", "Flatten", "UpSampling2d", "Identity",
+    "MultiheadAttention",
 ]
 
 
@@ -760,3 +761,71 @@ class UpSampling2d(Module):
         N, H, W, Cc = v.shape
         out = torch.empty((N, 2 * H, 2 * W, Cc), dtype=v.dtype, device=v.device)
         return from_nhwc(E.upsample2x_into(v, out, 0), self.data_format, true_channels(x, self.data_format))
+
+
+class MultiheadAttention(Module):
+    """tlx.nn.MultiheadAttention(embed_dim, num_heads, dropout, kdim, vdim, bias, batch_first, need_weights) — named by
+    BASELINE.json's north_star; the reference's own consumer of the same computation is DETR's MultiHeadAttention
+    (tlxcv/models/detection/detr.py:965-1062), whose arithmetic this follows: q / k / v projections with bias, q scaled by
+    head_dim^-0.5 before q k^T, additive attn_mask, softmax, @ v, output projection, weights averaged over the heads.
+    Parameter names and shapes [TLX-recalled]: q_weight (E, E), k_weight (E, kdim), v_weight (E, vdim), out_weight (E, E)
+    stored (out, in) as torch's functional form takes them, q_bias / k_bias / v_bias / out_bias.
+    forward(q, k=None, v=None, attn_mask=None, key_padding_mask=None) -> (attn_output, attn_weights or None); inputs are
+    (L, B, E) unless batch_first.  The three projections and the output projection are GEMM launches, the core is
+    tlxmi_mha — or, for self attention of <= 256 tokens without mask / weights in fp16, the fused tlxmi_attention."""
+
+    def __init__(self, embed_dim, num_heads, dropout=0.0, kdim=None, vdim=None, bias=True, batch_first=False,
+                 need_weights=True, name=None):
+        super().__init__(name=name)
+        self.embed_dim, self.num_heads = int(embed_dim), int(num_heads)
+        self.kdim = int(kdim) if kdim is not None else self.embed_dim
+        self.vdim = int(vdim) if vdim is not None else self.embed_dim
+        if self.embed_dim % self.num_heads:
+            raise ValueError("embed_dim must be divisible by num_heads")
+        self.head_dim = self.embed_dim // self.num_heads
+        self.dropout, self.batch_first, self.need_weights, self.bias = dropout, batch_first, need_weights, bias
+        init = xavier_uniform()
+        E_ = self.embed_dim
+        self.q_weight = Parameter(data=init(shape=(E_, E_)))
+        self.k_weight = Parameter(data=init(shape=(E_, self.kdim)))
+        self.v_weight = Parameter(data=init(shape=(E_, self.vdim)))
+        self.out_weight = Parameter(data=init(shape=(E_, E_)))
+        if bias:
+            for n in ("q_bias", "k_bias", "v_bias", "out_bias"):
+                setattr(self, n, Parameter(data=Constant(0.0)(shape=(E_,))))
+        else:
+            self.q_bias = self.k_bias = self.v_bias = self.out_bias = None
+
+    def _proj(self, x, wname, bname, res=None):
+        dt = E.precision()
+        w = getattr(self, wname)
+        pk = self._cached(("pk", wname), lambda: E.PackedFilter(w.detach().contiguous(), dt))
+        b = getattr(self, bname)
+        bb = self._cached(("b", bname), lambda: E._f32(b)) if b is not None else None
+        return E.linear(x if x.dtype == dt else x.to(dt), pk, bb)
+
+    def forward(self, q, k=None, v=None, attn_mask=None, key_padding_mask=None):
+        self._require_eval() if self.dropout else None
+        E.need_gpu(q, "query")
+        k = q if k is None else k
+        v = k if v is None else v
+        if key_padding_mask is not None:
+            raise NotImplementedError("MultiheadAttention: key_padding_mask (fold it into attn_mask as -inf columns)")
+        dt = E.precision()
+        hd, H = self.head_dim, self.num_heads
+        self_attn = (k is q) and (v is q)
+        L = q.shape[1] if self.batch_first else q.shape[0]
+        if self_attn and attn_mask is None and not self.need_weights and dt == torch.float16 and L <= 256 and hd in (32, 64, 96):
+            # fused path: one packed qkv GEMM on batch-first rows + the MFMA attention kernel
+            xb = (q if self.batch_first else q.transpose(0, 1)).to(dt).contiguous()          # (B, L, E)
+            pk = self._cached("pk_qkv", lambda: E.PackedFilter(
+                torch.cat([self.q_weight, self.k_weight, self.v_weight], 0).detach().contiguous(), dt))
+            bb = self._cached("b_qkv", lambda: E._f32(torch.cat([self.q_bias, self.k_bias, self.v_bias]))) if self.bias else None
+            a = E.attention(E.linear(xb, pk, bb), H, hd ** -0.5)
+            o = self._proj(a, "out_weight", "out_bias")
+            return (o if self.batch_first else o.transpose(0, 1)), None
+        Q = self._proj(q, "q_weight", "q_bias")
+        K = self._proj(k, "k_weight", "k_bias")
+        V = self._proj(v, "v_weight", "v_bias")
+        a, w = E.mha(Q, K, V, H, hd ** -0.5, attn_mask, self.need_weights, self.batch_first)
+        return self._proj(a, "out_weight", "out_bias"), w
