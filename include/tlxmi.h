@@ -17,6 +17,11 @@
  *     lives at ((n*H + h)*W + w)*ld + c.  A token matrix [rows][features] is the H=W=1 case.
  *   - dtype: TLXMI_F16 = IEEE binary16 storage, fp32 accumulate; TLXMI_F32 = fp32 storage, exact
  *     fp32 MFMA/FMA accumulate (the parity mode: 1e-4 vs the CPU oracle).
+ *   - one process drives ONE device (one rank per GPU): the library binds to the device that is current at its first
+ *     launch and returns TLXMI_ERR_UNSUPPORTED for launches under another current device.
+ *   - buffer offsets are 32-bit: a single tensor handed to conv2d / linear / the GEMM family must stay under 2 GiB
+ *     (256 images of ResNet-50's largest map are 411 MB); larger ones return TLXMI_ERR_UNSUPPORTED — split the batch.
+ *   - the product library reads no environment variable; tuning knobs exist only in the -DTLXMI_TUNING flavour.
  */
 #ifndef TLXMI_H
 #define TLXMI_H
@@ -59,6 +64,9 @@ typedef enum tlxmi_act {
 /* epilogue flag bits */
 #define TLXMI_EPI_RES_AFTER_ACT 1u /* y = act(a*scale+shift) + res   (darknet.py:155-159)      */
                                    /* default: y = act(a*scale+shift+res) (resnet.py:154-155)  */
+#define TLXMI_EPI_MAXPOOL_3S2P1 4u /* y = maxpool(k 3, stride 2, pad 1) of the conv + epilogue result, written as
+                                     [N][Ho/2][Wo/2][y_ld]; the conv map itself is never stored (resnet.py:287-290).
+                                     fp16 stem geometry only: ask tlxmi_conv2d_maxpool_supported() first */
 #define TLXMI_EPI_RES_BCAST_N 2u   /* res has no batch axis (pos_embed, vision_transformer.py:323) */
 
 /* ------------------------------------------------------------------------------------------
@@ -133,6 +141,10 @@ typedef struct tlxmi_conv2d_desc {
 int tlxmi_conv2d(const tlxmi_conv2d_desc* d, const void* x, const void* w_packed,
                  const float* scale /* [Cout] or NULL=1 */, const float* shift /* [Cout] or NULL=0 */,
                  const void* res /* or NULL */, void* y, void* stream);
+/* 1 when tlxmi_conv2d takes this descriptor with TLXMI_EPI_MAXPOOL_3S2P1 set (a stride-1 4x4 conv on 16 fp16 channels
+ * — the 7x7/2 ResNet stem after the 2x2 space-to-depth fold — with 112-pixel output rows), else 0: the caller then
+ * runs tlxmi_conv2d and tlxmi_maxpool2d as two launches. */
+int tlxmi_conv2d_maxpool_supported(const tlxmi_conv2d_desc* d);
 
 /* ------------------------------------------------------------------------------------------
  * Grouped convolution, 1 < groups < C: nn.GroupConv2d(n_group=cardinality) of the ResNeXt bottleneck,
@@ -158,6 +170,8 @@ int tlxmi_group_conv2d(const tlxmi_conv2d_desc* d, int groups, const void* x, co
  * sums are added in slice order (deterministic), then y = act((sum)*scale + shift (+res)) as tlxmi_conv2d.
  * w_packed: tlxmi_pack_filter of the [Cout][K] weight (1x1).
  * ---------------------------------------------------------------------------------------- */
+/* (the per-slice partial sums are stored in `dtype`: with TLXMI_F16 each slice — at least four 128-byte K tiles — is
+ * accumulated in fp32 and rounded to fp16 once before the slice-order sum, itself in fp32) */
 int tlxmi_linear_splitk(int dtype, int64_t rows, int K, int Cout, int x_ld, const void* x, const void* w_packed,
                         int splits, void* partials, const float* scale, const float* shift, const void* res,
                         int res_ld, int act, float act_param, uint32_t flags, void* y, int y_ld, void* stream);

@@ -98,3 +98,16 @@ def test_host_dispatch_survives_without_a_device():
                 rc = lib.tlxmi_conv2d(ctypes.byref(d), ctypes.c_void_p(1 << 20), ctypes.c_void_p(1 << 22), None, None,
                                       res, ctypes.c_void_p(1 << 26), None)
                 assert rc in (0, -4), (rc, lib.tlxmi_last_error())
+
+
+def test_product_library_reads_no_environment_knob():
+    """the A/B knobs (TLXMI_TILE / HALO / TAIL / PP128 / STORE / DEBUG ...) exist only in the tuning flavour
+    (libtlxmi_tune.so, -DTLXMI_TUNING).  The product library must not even import getenv."""
+    from tlxcv_amd import _lib
+    out = subprocess.check_output(["nm", "-D", "--undefined-only", _lib.LIB_PATH]).decode()
+    assert "getenv" not in out
+    if os.path.exists(_lib.TUNE_LIB_PATH):
+        assert "getenv" in subprocess.check_output(["nm", "-D", "--undefined-only", _lib.TUNE_LIB_PATH]).decode()
+        with _lib.tuning(TLXMI_TILE="3") as lib:
+            assert os.environ["TLXMI_TILE"] == "3" and lib.tlxmi_version() == 100 and _lib.load() is lib
+        assert "TLXMI_TILE" not in os.environ and _lib.load() is not lib

@@ -10,6 +10,7 @@ import torch
 
 from oracle import functional as OF
 from tlxcv_amd import engine as E
+from tlxcv_amd._lib import tuning      # the tuning flavour of the library: honours TLXMI_TILE / TLXMI_HALO per call
 from util import rnd, q16, nchw_to_engine, engine_to_nchw, tol
 
 pytestmark = pytest.mark.gpu
@@ -170,13 +171,9 @@ HALO_CASES = [
 @pytest.mark.parametrize("halo", ["1", "0"], ids=["halo", "igemm"])
 @pytest.mark.parametrize("cfg", HALO_CASES, ids=lambda c: "x".join(map(str, c)))
 def test_thin_input_stride1(dev, cfg, halo):
-    import os
     N, Cin, Cout, k, pad, H, W, res, act = cfg
-    os.environ["TLXMI_HALO"] = halo
-    try:
+    with tuning(TLXMI_HALO=halo):
         run_case(dev, torch.float16, N, Cin, Cout, k, 1, pad, H, W, act=act, act_param=0.1, with_res=res, seed=11)
-    finally:
-        os.environ.pop("TLXMI_HALO", None)
 
 
 @pytest.mark.parametrize("cfg", [(128, 64, 64, 3, 1, 56, 56, True), (64, 16, 64, 4, 0, 115, 115, False)],
@@ -185,7 +182,6 @@ def test_thin_input_full_size_matches_the_implicit_gemm(dev, cfg):
     """BASELINE-sized property check: at full image count (dozens of tiles per workgroup, every ring wrap and
     image boundary of conv_halo.hip) the row-ring kernel and the implicit GEMM — each checked against the oracle
     at small sizes above — agree to fp16 rounding of one accumulation order vs the other."""
-    import os
     N, Cin, Cout, k, pad, H, W, res = cfg
     g = torch.Generator().manual_seed(3)
     x = (torch.randn((N, H, W, Cin), generator=g) * 0.5).half().to(dev)
@@ -197,11 +193,8 @@ def test_thin_input_full_size_matches_the_implicit_gemm(dev, cfg):
     r = torch.randn((N, Ho, Wo, Cout), generator=g).half().to(dev) if res else None
     outs = []
     for halo in ("1", "0"):
-        os.environ["TLXMI_HALO"] = halo
-        try:
+        with tuning(TLXMI_HALO=halo):
             outs.append(E.conv2d(x, pk, 1, pad, 1, sc, sh, r, E.ACT_RELU).float().cpu())
-        finally:
-            os.environ.pop("TLXMI_HALO", None)
     torch.testing.assert_close(outs[0], outs[1], atol=4e-3, rtol=4e-3)
 
 
@@ -281,13 +274,9 @@ PPCONV_CASES = [
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["fp32", "fp16"])
 @pytest.mark.parametrize("cfg", PPCONV_CASES, ids=lambda c: "x".join(map(str, c)))
 def test_conv3x3_on_the_antiphase_gemm(dev, dtype, cfg, tile):
-    import os
     N, Cin, Cout, k, stride, pad, H, W, res, act = cfg
-    os.environ["TLXMI_TILE"] = tile
-    try:
+    with tuning(TLXMI_TILE=tile):
         run_case(dev, dtype, N, Cin, Cout, k, stride, pad, H, W, act=act, act_param=0.1, with_res=res, seed=23)
-    finally:
-        os.environ.pop("TLXMI_TILE", None)
 
 
 # 128 output channels: only the 256 x 128 tile (candidate 10) takes these (resnet.py:111-121, 28 x 28 stage)
@@ -296,24 +285,16 @@ def test_conv3x3_on_the_antiphase_gemm(dev, dtype, cfg, tile):
                                  (3, 64, 136, 3, 1, 1, 11, 17, True, 3), (1, 256, 128, 3, 1, 1, 16, 16, True, 0)],
                          ids=lambda c: "x".join(map(str, c)))
 def test_conv3x3_with_128_output_channels_on_the_antiphase_gemm(dev, dtype, cfg):
-    import os
     N, Cin, Cout, k, stride, pad, H, W, res, act = cfg
-    os.environ["TLXMI_TILE"] = "10"
-    try:
+    with tuning(TLXMI_TILE="10"):
         run_case(dev, dtype, N, Cin, Cout, k, stride, pad, H, W, act=act, act_param=0.1, with_res=res, seed=29)
-    finally:
-        os.environ.pop("TLXMI_TILE", None)
 
 
 def test_linear_on_the_256x128_antiphase_tile(dev):
     """The 1x1 / Linear path of the same tile shape (reachable through TLXMI_TILE=10 only)."""
-    import os
-    os.environ["TLXMI_TILE"] = "10"
-    try:
+    with tuning(TLXMI_TILE="10"):
         run_case(dev, torch.float16, 2, 512, 128, 1, 1, 0, 28, 28, act=1, with_res=False, seed=31)
         run_case(dev, torch.float32, 1, 256, 392, 1, 1, 0, 19, 19, act=0, with_res=True, seed=32)
-    finally:
-        os.environ.pop("TLXMI_TILE", None)
 
 
 def test_conv3x3_image_axis_tail_split(dev):
@@ -375,3 +356,37 @@ def test_space_to_depth_stem_with_same_padding(dev, dtype, k, H, W):
         torch.testing.assert_close(engine_to_nchw(got), want, **tol(dtype))
     finally:
         tlxcv_amd.set_precision("fp16")
+
+
+@pytest.mark.parametrize("N,act", [(1, E.ACT_RELU), (3, E.ACT_RELU), (5, E.ACT_LEAKY), (9, E.ACT_NONE)])
+def test_stem_with_the_max_pool_in_its_epilogue(dev, N, act):
+    """resnet.py:287-290 conv1 -> bn1 -> relu -> maxpool(3, 2, 1) as ONE launch (TLXMI_EPI_MAXPOOL_3S2P1): must equal the
+    two-launch path bit for bit (the conv result is rounded to fp16 once in both, a maximum is exact), and the oracle.
+    The batch sizes make workgroup ranges start at an image's first tile, inside an image (recomputed warm-up tile) and
+    span image seams; activations without a lower bound of 0 check that the pool's padding is 'skip', not zero."""
+    from tlxcv_amd.tlx import nn
+    rng = np.random.default_rng(N)
+    conv = nn.GroupConv2d(in_channels=3, out_channels=64, kernel_size=7, stride=2, padding=3, b_init=None,
+                          data_format="channels_first")
+    bn = nn.BatchNorm2d(num_features=64, data_format="channels_first")
+    with torch.no_grad():
+        conv.filters.copy_(q16(rnd(rng, (64, 3, 7, 7), (2.0 / 147) ** 0.5)))
+        bn.gamma.copy_(torch.from_numpy(rng.uniform(0.5, 1.5, 64).astype(np.float32)))
+        bn.beta.copy_(rnd(rng, (64,), 0.3) - 0.5)           # mostly negative maps: a zero-padded pool would differ
+        bn.moving_mean.copy_(rnd(rng, (64,), 0.1))
+        bn.moving_var.copy_(torch.from_numpy(rng.uniform(0.5, 1.5, 64).astype(np.float32)))
+    conv, bn = conv.to(dev).set_eval(), bn.to(dev).set_eval()
+    pool = nn.MaxPool2d(3, 2, 1, data_format="channels_first")
+    x = q16(rnd(rng, (N, 3, 224, 224)))
+    fused = conv.run_stem(x.to(dev), 2, bn, act, 0.1, maxpool=pool)
+    two = pool.run_nhwc(conv.run_stem(x.to(dev), 2, bn, act, 0.1))
+    torch.cuda.synchronize()
+    assert fused.shape == two.shape == (N, 56, 56, 64)
+    assert torch.equal(fused, two)
+    scale, shift = bn.folded(None)
+    want = torch.nn.functional.max_pool2d(
+        OF.conv_bn_act(x, conv.filters.cpu(), scale.cpu(), shift.cpu(), None, act, 0.1, 2, 3), 3, 2, 1)
+    torch.testing.assert_close(engine_to_nchw(fused), want, **tol(torch.float16))
+    # geometries without the fused kernel fall back to two launches inside run_stem (nothing else changes for the caller)
+    small = conv.run_stem(x[:1, :, :64, :64].contiguous().to(dev), 2, bn, act, 0.1, maxpool=pool)
+    assert small.shape == (1, 16, 16, 64)

@@ -22,13 +22,20 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture
 def force_tile():
+    """set_tile(t): the following launches run on the TUNING flavour of the library (libtlxmi_tune.so, which reads
+    TLXMI_TILE per call) with tile candidate t forced; set_tile(None): back to the product library and its own choice."""
+    from tlxcv_amd._lib import tuning
+    state = {"ctx": None}
+
     def set_tile(t):
-        if t is None:
-            os.environ.pop("TLXMI_TILE", None)
-        else:
-            os.environ["TLXMI_TILE"] = str(t)
+        if state["ctx"] is not None:
+            state["ctx"].__exit__(None, None, None)
+            state["ctx"] = None
+        if t is not None:
+            state["ctx"] = tuning(TLXMI_TILE=str(t))
+            state["ctx"].__enter__()
     yield set_tile
-    os.environ.pop("TLXMI_TILE", None)
+    set_tile(None)
 
 
 def run_linear(dev, dtype, M, K, Cout, bias=True, scale=False, res=False, act=E.ACT_NONE, seed=0):

@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("TLXMI_LIB") or os.path.join(_HERE, "libtlxmi.so")   #
 F16, F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_RELU6, ACT_LEAKY, ACT_HARDSWISH, ACT_HARDSIGMOID, ACT_GELU, ACT_SIGMOID, ACT_SILU = range(9)
 EPI_RES_AFTER_ACT = 1
+EPI_MAXPOOL_3S2P1 = 4
 
 
 class ConvDesc(C.Structure):
@@ -84,23 +85,19 @@ _SPECIAL = {
     "tlxmi_packed_filter_bytes": ([_i, _i, _i, _i, _i], C.c_size_t),
     "tlxmi_packed_group_filter_bytes": ([_i, _i, _i, _i, _i, _i], C.c_size_t),
     "tlxmi_group_conv_chunks": ([_i, _i, _i, _i], C.c_int),
+    "tlxmi_conv2d_maxpool_supported": ([C.POINTER(ConvDesc)], C.c_int),
 }
 ALL_SYMBOLS = sorted(list(PROTOTYPES) + list(_SPECIAL))
 
-_lib = None
+TUNE_LIB_PATH = os.path.join(_HERE, "libtlxmi_tune.so")   # `make -C tlxcv_amd/csrc tune` (-DTLXMI_TUNING)
+
+_lib = None        # the library call() goes through: the product build, or the tuning flavour inside `with tuning():`
+_product = None
+_tune = None
 
 
-def load():
-    """Load libtlxmi.so (built by __graft_entry__.build() / `make -C tlxcv_amd/csrc`)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise RuntimeError(
-            f"tlxcv_amd: {LIB_PATH} is missing — the HIP engine has not been built "
-            "(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C tlxcv_amd/csrc`). "
-            "There is no CPU fallback.")
-    lib = C.CDLL(LIB_PATH)
+def _open(path):
+    lib = C.CDLL(path)
     for name, argtypes in PROTOTYPES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
@@ -109,8 +106,56 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = restype
-    _lib = lib
     return lib
+
+
+def load():
+    """Load libtlxmi.so (built by __graft_entry__.build() / `make -C tlxcv_amd/csrc`)."""
+    global _lib, _product
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"tlxcv_amd: {LIB_PATH} is missing — the HIP engine has not been built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C tlxcv_amd/csrc`). "
+            "There is no CPU fallback.")
+    _product = _open(LIB_PATH)
+    _lib = _product
+    return _lib
+
+
+class tuning:
+    """`with _lib.tuning(TLXMI_TILE="7"): ...` — run the enclosed calls on the TUNING flavour of the library
+    (libtlxmi_tune.so: the same sources built with -DTLXMI_TUNING), which reads the A/B knobs (TLXMI_TILE, TLXMI_HALO,
+    TLXMI_TAIL, TLXMI_PP128, TLXMI_STORE, TLXMI_DWSTRIP, TLXMI_PANEL_KB, TLXMI_DEBUG) from the environment on every call.
+    The product library never does: outside this context no environment variable changes a kernel choice or a result.
+    Used by tools/ab_*.py and by the tests that force a tile candidate the dispatcher would not pick at test sizes."""
+
+    def __init__(self, **env):
+        self.env = {k: str(v) for k, v in env.items()}
+
+    def __enter__(self):
+        global _lib, _tune
+        load()
+        if _tune is None:
+            if not os.path.exists(TUNE_LIB_PATH):
+                raise RuntimeError(f"tlxcv_amd: {TUNE_LIB_PATH} is missing — build it with `make -C tlxcv_amd/csrc tune`")
+            _tune = _open(TUNE_LIB_PATH)
+        self.saved = {k: os.environ.get(k) for k in self.env}
+        os.environ.update(self.env)
+        self.prev = _lib
+        _lib = _tune
+        return _tune
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self.prev
+        for k, v in self.saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        return False
 
 
 def call(name, *args):

@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdarg.h>
 #include <math.h>
+#include <stdlib.h>
 #include "../../include/tlxmi.h"
 
 namespace tlxmi {
@@ -22,6 +23,21 @@ int check_launch(const char* what);
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 inline size_t elt_size(int dtype) { return dtype == TLXMI_F16 ? 2 : 4; }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---- tuning knobs ------------------------------------------------------------------------------
+// The product library (libtlxmi.so) reads NO environment variable: every A/B knob below is its compiled-in default and
+// the kernels carry no ablation branch.  The tuning flavour (libtlxmi_tune.so, `make tune`, -DTLXMI_TUNING) reads them
+// per call — tools/ab_*.py and the tests that force a tile candidate load that flavour (tlxcv_amd._lib.tuning()).
+#ifdef TLXMI_TUNING
+inline long tune_int(const char* name, long dflt) {
+    const char* e = getenv(name);
+    return (e && *e) ? atol(e) : dflt;
+}
+#define TLXMI_DBG(args, bit) (((args).debug & (bit)) != 0)
+#else
+constexpr long tune_int(const char*, long dflt) { return dflt; }
+#define TLXMI_DBG(args, bit) (false)
+#endif
 
 // ---- device-side vector types -------------------------------------------------------------
 typedef _Float16 half_t;

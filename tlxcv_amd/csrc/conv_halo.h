@@ -26,10 +26,13 @@ struct HaloArgs {
     int nring;                // rows of the LDS ring (power of two)
     unsigned x_bytes, w_bytes, y_bytes, res_bytes;
     int debug;                // tuning builds only
+    int pool;                 // 1: y receives maxpool(3, 2, 1) of the conv + epilogue result (conv_halo.hip, POOL variant)
 };
 
 int conv_halo_tile_pixels(int R, int S, int PB);   // 0: no instantiation
 bool conv_halo_act_ok(int act);
 int launch_conv_halo(const HaloArgs& a, hipStream_t st, int cus);
+bool conv_halo_pool_ok(int R, int S, int PB, int Ho, int Wo);
+bool conv_halo_pool_act_ok(int act);   // geometry of the fused max-pool epilogue
 
 }  // namespace tlxmi

@@ -23,6 +23,16 @@
 // XOR-swizzled: physical 16-byte slot = slot ^ (line & 7), applied on the DMA source side and on the
 // fragment reads; any 16 consecutive pixels of 128 B read conflict-free whatever the first pixel.
 // Algorithmic bytes: input once + output once (+ residual); FLOPs 2*M*Cout*R*S*C.
+//
+// POOL variant (TLXMI_EPI_MAXPOOL_3S2P1: the ResNet stem, resnet.py:287-290 conv1 -> bn1 -> relu -> maxpool(3, 2, 1)):
+// the 112 x 112 x 64 conv map (411 MB at batch 256) is never written.  A tile is exactly two conv rows (PI = 7: a
+// pixel half of a tile = 16 * PI = Wo = 112 pixels = one row), so tile j of an image holds conv rows 2j, 2j+1.  The
+// epilogue of a tile takes the horizontal 3-tap / stride-2 maximum in registers (the left / right neighbours of an even
+// pixel come by DPP row rotates; the pixel left of a 16-pixel sub-tile is lane 15 of the previous sub-tile) and leaves
+// two half-resolution rows (56 pixels x 64 channels, 7 KB each) in a 3-tile LDS ring; the epilogue phase after that
+// — the other wave group, one barrier later — combines rows 2j-1, 2j, 2j+1 (the first from tile j-1's ring slot) and
+// stores pooled row j with full-line 16-byte stores.  A workgroup whose range starts inside an image first recomputes
+// the tile before it (no store) to obtain row 2j-1.  Padding of the pool is "skip", which equals -inf padding.
 #include "common.h"
 #include "conv_halo.h"
 #include <stdlib.h>
@@ -46,8 +56,24 @@ static __device__ __forceinline__ void ch_store16_nt(__amdgpu_buffer_rsrc_t rsrc
 // R x S taps, PB = bytes per input pixel (C * 2); S * PB must be a multiple of 64 (one MFMA K slice)
 // PI = MFMA pixel sub-tiles per wave: a tile is TP = 32 * PI consecutive pixels (8 where the filter registers
 // leave room)
-template <int R, int S, int PB, int PI, bool RES>
+template <int CTRL> static __device__ __forceinline__ unsigned ch_dpp(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+}
+// packed fp16 maximum as ONE instruction (the builtin maximum canonicalises both operands first: three instructions)
+static __device__ __forceinline__ unsigned ch_pkmax(unsigned a, unsigned b) {
+    unsigned r;
+    asm("v_pk_max_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+static __device__ __forceinline__ u32x4 ch_pkmax4(u32x4 a, u32x4 b) {
+    return u32x4{ch_pkmax(a[0], b[0]), ch_pkmax(a[1], b[1]), ch_pkmax(a[2], b[2]), ch_pkmax(a[3], b[3])};
+}
+
+// PACT: the activation of the POOL epilogue, compiled in (a runtime switch per sub-tile doubled its instruction count)
+template <int R, int S, int PB, int PI, bool RES, bool POOL = false, int PACT = TLXMI_ACT_NONE>
 __global__ __launch_bounds__(512) void conv_halo_kernel(const HaloArgs a) {
+    static_assert(!POOL || !RES, "the pooled epilogue takes no residual");
+    static_assert(PACT == TLXMI_ACT_NONE || PACT == TLXMI_ACT_RELU, "POOL epilogue: ReLU or none");
     constexpr int TP = 32 * PI;          // pixels of a tile (2 pixel halves x PI sub-tiles of 16)
     constexpr int KR = S * PB / 64;      // K slices per filter row
     constexpr int NKK = R * KR;          // K slices in all
@@ -68,7 +94,10 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const HaloArgs a) {
     // one channel tile (a.nt) per launch: the filters are loaded once, before the tile loop.  Workgroup b takes
     // the contiguous tile range [b*T/G, (b+1)*T/G) in (image, first pixel) order: consecutive tiles of an image.
     const int ntiles = a.N * a.tpi;
-    const int t_lo = (int)(((long)blockIdx.x * ntiles) / gridDim.x), t_hi = (int)(((long)(blockIdx.x + 1) * ntiles) / gridDim.x);
+    const int s_lo = (int)(((long)blockIdx.x * ntiles) / gridDim.x), t_hi = (int)(((long)(blockIdx.x + 1) * ntiles) / gridDim.x);
+    // POOL: pooled row j needs conv row 2j-1 of the tile before; a range that starts inside an image recomputes it
+    const int warm = (POOL && s_lo < t_hi && s_lo - (s_lo / a.tpi) * a.tpi != 0) ? 1 : 0;
+    const int t_lo = s_lo - warm;
     const int n_mine = t_hi - t_lo;
     const float inv_wo = 1.0f / (float)a.Wo;
 
@@ -175,11 +204,46 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const HaloArgs a) {
     f32x4 acc[2][PI];
 
     // phase p: group p & 1 computes tile p; the other group finishes tile p-1 and stages the rows of tile p+2
-    for (int p = 0; p <= n_mine; ++p) {
+    // half-resolution rows of the POOL epilogue: [3 tile slots][2 rows][Wo/2 pixels][128 B], 16-byte chunk c of pixel
+    // x' at slot c ^ (x' & 7) (the four even pixels a ds_write_b128 lane group stores would share banks otherwise)
+    char* const hb = smem + a.nring * row_bytes + 512;
+    constexpr int HROW = 16 * PI / 2 * 128;       // bytes of one half-resolution row (POOL: PI = 7 -> 56 pixels)
+    Tile tpp = tprev;                             // tile p-2 (POOL)
+    auto pooled_row = [&](int p) {
+        if constexpr (POOL) {
+                if (p >= 2) {
+                    // pooled row of tile p-2 = max(half-res rows 2j-1 [tile p-3's second row], 2j, 2j+1); two 16-byte
+                    // chunks per thread of the group (448 chunks = 56 pixels x 8); every lane issues both stores
+                    // (out-of-range offset when it has nothing to store) so that the counted wait below stays exact
+                    const Tile tj = tpp;
+                    const int L = t_lo + p - 2;                       // global tile index
+                    const int jrow = L - tj.n * a.tpi;                // tile inside its image = pooled row
+                    const bool st_ok = L >= s_lo;                     // (the warm-up tile stores nothing)
+                    const char* r0 = hb + (((p - 2) % 3) * 2) * HROW;
+                    const char* rp = hb + (((p + 0) % 3) * 2 + 1) * HROW;   // slot (p-3) % 3, second row
+                    const int t4 = t & 255;
+#pragma unroll
+                    for (int rd = 0; rd < 2; ++rd) {
+                        const int c = t4 + 256 * rd;
+                        const int xh = c >> 3, ch = c & 7;
+                        const bool in = c < (16 * PI / 2) * 8;
+                        const int off = xh * 128 + ((ch ^ (xh & 7)) << 4);
+                        u32x4 m = u32x4{0u, 0u, 0u, 0u};
+                        if (in) {
+                            m = ch_pkmax4(*reinterpret_cast<const u32x4*>(r0 + off), *reinterpret_cast<const u32x4*>(r0 + HROW + off));
+                            if (jrow > 0) m = ch_pkmax4(m, *reinterpret_cast<const u32x4*>(rp + off));
+                        }
+                        const int opix = (tj.n * a.tpi + jrow) * (16 * PI / 2) + xh;     // pooled pixel index (N, Ho/2, Wo/2)
+                        ch_store16_nt(ysrd, m, (in && st_ok && ch * 8 < a.Cout && !TLXMI_DBG(a, 2)) ? (opix * a.y_ld + a.nt * 64 + ch * 8) * 2 : OOB);
+                    }
+                }
+        }
+    };
+    for (int p = 0; p <= n_mine + (POOL ? 1 : 0); ++p) {
         const Tile nx2 = tile_at(p + 2);
         if (grp == (p & 1)) {
             prefetch(nx2, false);
-            if (p < n_mine) {
+            if (p < n_mine && !TLXMI_DBG(a, 32)) {
                 const Tile cur = tcur;
                 // ring slot (for filter row 0) and byte inside the row of this lane's pixel of each sub-tile
                 int sq[PI], bx[PI];
@@ -245,9 +309,58 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const HaloArgs a) {
                 };
                 steps(steps, IntTag<0>{});
             }
+            if constexpr (POOL) {
+                if TLXMI_DBG(a, 4) {
+                    pooled_row(p);
+                    if TLXMI_DBG(a, 8) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // my row DMAs of the phase before have landed
+                } else if TLXMI_DBG(a, 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
         } else {
             // rows of tile p+2 first (its DMAs are the oldest operations of this phase), then the epilogue
-            if (!(a.debug & 1)) prefetch(nx2, true); else prefetch(nx2, false);
+            if (!TLXMI_DBG(a, 1)) prefetch(nx2, true); else prefetch(nx2, false);
+            if constexpr (POOL) {
+                if (p >= 1 && p <= n_mine && !TLXMI_DBG(a, 16)) {
+                    // tile p-1: scale / shift / activation, fp16, horizontal 3-tap stride-2 maximum -> ring slot (p-1) % 3
+                    const float* tb = reinterpret_cast<const float*>(smem + a.nring * row_bytes) + cg * 32 + 8 * fg;
+                    const f32x4 s0 = *reinterpret_cast<const f32x4*>(tb), s1 = *reinterpret_cast<const f32x4*>(tb + 4);
+                    const f32x4 h0 = *reinterpret_cast<const f32x4*>(tb + 64), h1 = *reinterpret_cast<const f32x4*>(tb + 68);
+                    char* const hrow = hb + (((p - 1) % 3) * 2 + pg) * HROW;     // this wave's conv row (pg) of the tile
+                    u32x4 prev = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+                    for (int pi = 0; pi < PI; ++pi) {
+                        float v[8];
+#pragma unroll
+                        for (int bb = 0; bb < 4; ++bb) {
+                            v[bb] = acc[0][pi][bb] * s0[bb] + h0[bb];
+                            v[4 + bb] = acc[1][pi][bb] * s1[bb] + h1[bb];
+                        }
+                        half8v hv;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) hv[e] = (half_t)v[e];
+                        u32x4 cur4 = __builtin_bit_cast(u32x4, hv);
+                        if constexpr (PACT == TLXMI_ACT_RELU) {      // on the rounded pairs: max(fp16(v), 0) == fp16(max(v, 0))
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) cur4[q] = ch_pkmax(cur4[q], 0u);
+                        }
+                        u32x4 hm;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            // row_ror:1 — lane l takes lane l-1 of its 16-lane row, lane 0 takes lane 15: feed lane 15 the
+                            // previous sub-tile's value, so that lane 0 receives pixel x-1 across the sub-tile seam
+                            const unsigned left = ch_dpp<0x121>(frow == 15 ? prev[q] : cur4[q]);
+                            const unsigned right = ch_dpp<0x12F>(cur4[q]);      // row_ror:15 — lane l takes lane l+1
+                            const unsigned m = ch_pkmax(cur4[q], right);
+                            hm[q] = (pi == 0 && frow == 0) ? m : ch_pkmax(m, left);   // x = 0: the left tap is padding
+                        }
+                        prev = cur4;
+                        if ((frow & 1) == 0) {
+                            const int xh = pi * 8 + (frow >> 1);
+                            *reinterpret_cast<u32x4*>(hrow + xh * 128 + (((cg * 4 + fg) ^ (xh & 7)) << 4)) = hm;
+                        }
+                    }
+                }
+                if (!TLXMI_DBG(a, 4)) pooled_row(p);
+            } else
             if (p >= 1) {
                 const Tile cur = tprev;
                 // residual loads (four sub-tiles at a time) before the stores of those sub-tiles: a load behind a
@@ -307,18 +420,26 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const HaloArgs a) {
                     half8v hv;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) hv[e] = (half_t)v[e];
-                    ch_store16_nt(ysrd, __builtin_bit_cast(u32x4, hv), (ok && !(a.debug & 2)) ? (mg * a.y_ld + ch0) * 2 : OOB);
+                    ch_store16_nt(ysrd, __builtin_bit_cast(u32x4, hv), (ok && !TLXMI_DBG(a, 2)) ? (mg * a.y_ld + ch0) * 2 : OOB);
                 }
             }
             // the rows of tile p+2 have landed; the PI stores just issued (and nothing else) may stay in flight
-            if (p >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PI) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (POOL) {
+                if TLXMI_DBG(a, 8) { if (p == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }   // relaxed: waited for at the end of this group's next (compute) phase
+                else if (p >= 2 && !TLXMI_DBG(a, 4)) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                if (p >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PI) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
         }
         q2_iy = base_iy_ld; q2_slot = base_slot_ld;
         // after the barrier: nobody reads the rows only tile p needed, tile p+2's rows are visible to every wave
+        if constexpr (POOL) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the half-resolution rows are in LDS
         __builtin_amdgcn_s_barrier();
         q0_iy = q1_iy; q0_slot = q1_slot;
         q1_iy = q2_iy; q1_slot = q2_slot;
+        tpp = tprev;
         tprev = tcur; tcur = tnx1; tnx1 = nx2;
     }
 }
@@ -329,9 +450,9 @@ bool conv_halo_act_ok(int act) {
            act == TLXMI_ACT_HARDSWISH;
 }
 
-template <int R, int S, int PB, int PI, bool RES> static int launch_halo_r(const HaloArgs& a, hipStream_t st, int cus) {
-    const void* fn = reinterpret_cast<const void*>(&conv_halo_kernel<R, S, PB, PI, RES>);
-    const size_t lds = (size_t)a.nring * a.PWp * PB + 512;   // ring + scale / shift table
+template <int R, int S, int PB, int PI, bool RES, bool POOL = false, int PACT = TLXMI_ACT_NONE> static int launch_halo_r(const HaloArgs& a, hipStream_t st, int cus) {
+    const void* fn = reinterpret_cast<const void*>(&conv_halo_kernel<R, S, PB, PI, RES, POOL, PACT>);
+    const size_t lds = (size_t)a.nring * a.PWp * PB + 512 + (POOL ? 3 * 2 * (16 * PI / 2) * 128 : 0);   // ring + scale / shift table (+ half-resolution rows)
     static bool raised = false;
     if (!raised) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -342,7 +463,7 @@ template <int R, int S, int PB, int PI, bool RES> static int launch_halo_r(const
     int grid = cus & ~7;
     if (grid < 8) grid = 8;
     if (grid > tiles) grid = tiles;
-    static const int dbg = [] { const char* e = getenv("TLXMI_DEBUG"); return e ? atoi(e) : 0; }();
+    const int dbg = (int)tune_int("TLXMI_DEBUG", 0);   // ablation bits: tuning flavour only
     for (int nt = 0; nt < a.ntn; ++nt) {     // one launch per tile of 64 output channels
         HaloArgs b = a;
         b.debug = dbg;
@@ -365,7 +486,20 @@ int conv_halo_tile_pixels(int R, int S, int PB) {
     return 0;
 }
 
+// The fused max-pool epilogue: a pixel half of a tile must be exactly one conv row (16 * PI = Wo) and tiles pair rows
+bool conv_halo_pool_act_ok(int act) { return act == TLXMI_ACT_RELU || act == TLXMI_ACT_NONE; }
+bool conv_halo_pool_ok(int R, int S, int PB, int Ho, int Wo) {
+    return R == 4 && S == 4 && PB == 32 && Wo == 112 && Ho % 2 == 0 && Ho >= 2;
+}
+
 int launch_conv_halo(const HaloArgs& a, hipStream_t st, int cus) {
+    if (a.pool) {
+        if (!conv_halo_pool_ok(a.R, a.S, a.PB, a.Ho, a.Wo) || a.res)
+            return fail(TLXMI_ERR_UNSUPPORTED, "conv_halo: no fused max-pool instantiation for this geometry");
+        if (a.act == TLXMI_ACT_RELU) return launch_halo_r<4, 4, 32, 7, false, true, TLXMI_ACT_RELU>(a, st, cus);
+        if (a.act == TLXMI_ACT_NONE) return launch_halo_r<4, 4, 32, 7, false, true, TLXMI_ACT_NONE>(a, st, cus);
+        return fail(TLXMI_ERR_UNSUPPORTED, "conv_halo: the fused max-pool epilogue is compiled for ReLU / no activation");
+    }
     if (a.R == 3 && a.S == 3 && a.PB == 128) return launch_halo_t<3, 3, 128, 4>(a, st, cus);
     if (a.R == 3 && a.S == 3 && a.PB == 64) return launch_halo_t<3, 3, 64, 8>(a, st, cus);
     if (a.R == 4 && a.S == 4 && a.PB == 32) return launch_halo_t<4, 4, 32, 8>(a, st, cus);

@@ -528,7 +528,7 @@ template <typename T, int BM, int BN, int WGM, int STAGES> static int launch(con
     b.mtiles = (a.M + BM - 1) / BM;
     b.ntiles = (a.Cout + BN - 1) / BN;
     {
-        static const long budget = [] { const char* e = getenv("TLXMI_PANEL_KB"); return (e ? atol(e) : (1l << 20)) * 1024; }();   // default: no panels (N fastest); measured neutral
+        const long budget = tune_int("TLXMI_PANEL_KB", 1l << 20) * 1024;   // default: no panels (N fastest); measured neutral
         long gn = budget / ((long)BN * a.Kp_bytes);
         b.gn = (int)(gn < 1 ? 1 : (gn > b.ntiles ? b.ntiles : gn));
     }
@@ -576,14 +576,38 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
     // latency/HBM-bound and want many small resident blocks; MFMA-bound layers want the 128x128 tile.
     // Thin inputs (<= 128 bytes per pixel), stride 1, few output channels: the gather of every tap through LDS is
     // the bound; conv_halo.hip loads the input rows once and keeps the filters in registers.
+    const bool pool = (a.flags & TLXMI_EPI_MAXPOOL_3S2P1) != 0;
     if constexpr (sizeof(T) == 2) {
         const int PB = a.C * 2;
-        int forced_h = -1;
-        { const char* e = getenv("TLXMI_HALO"); if (e && *e) forced_h = atoi(e); }   // 0: off (A/B runs)
+        if (pool) {
+            // conv -> epilogue -> maxpool(3, 2, 1) in one launch (the ResNet stem, resnet.py:287-290): conv_halo's POOL
+            // variant only; y is [N][Ho/2][Wo/2][y_ld]
+            if (!(a.nchunk == 1 && !a.overhang && a.sh == 1 && a.sw == 1 && a.dh == 1 && a.dw == 1 && conv_halo_pool_ok(a.R, a.S, PB, a.Ho, a.Wo) &&
+                  conv_halo_pool_act_ok(a.act) && !a.strided_n && a.vec_io && !a.res && a.Cout % 8 == 0 && a.Cout <= 128 && a.y_bytes != 0))
+                return fail(TLXMI_ERR_UNSUPPORTED, "conv2d: TLXMI_EPI_MAXPOOL_3S2P1 needs the fp16 4x4 / 16-channel stem geometry (Wo = 112, even Ho, no residual)");
+            HaloArgs h;
+            h.x = a.x; h.w = a.w; h.y = a.y; h.scale = a.scale; h.shift = a.shift; h.res = nullptr;
+            h.N = a.N; h.H = a.H; h.W = a.W; h.Cout = a.Cout; h.R = a.R; h.S = a.S; h.ph = a.ph; h.pw = a.pw;
+            h.Ho = a.Ho; h.Wo = a.Wo; h.HoWo = a.HoWo; h.x_ld = a.x_ld; h.y_ld = a.y_ld; h.res_ld = 0;
+            h.PB = PB; h.Kp_bytes = a.Kp_bytes; h.act = a.act; h.act_param = a.act_param; h.flags = a.flags;
+            h.tpi = a.Ho / 2;                      // a tile = two conv rows
+            h.ntn = (a.Cout + 63) / 64; h.nt = 0;
+            h.PW = a.Wo + a.S - 1;
+            const int ppp = 1024 / PB;
+            h.PWp = (h.PW + ppp - 1) / ppp * ppp;
+            h.nring = 16;                          // 2 rows + 3 halo rows per tile, three tiles resident
+            h.x_bytes = a.x_bytes; h.w_bytes = a.w_bytes;
+            h.y_bytes = (unsigned)((long long)a.N * (a.Ho / 2) * (a.Wo / 2) * a.y_ld * 2);
+            h.res_bytes = 0u;
+            h.pool = 1;
+            return launch_conv_halo(h, st, num_cus());
+        }
+        const int forced_h = (int)tune_int("TLXMI_HALO", -1);   // tuning flavour: 0 = off (A/B runs)
         if (forced_h != 0 && a.nchunk == 1 && !a.overhang && a.sh == 1 && a.sw == 1 && a.dh == 1 && a.dw == 1 && (a.R > 1 || a.S > 1) && conv_halo_tile_pixels(a.R, a.S, PB) > 0 &&
             conv_halo_act_ok(a.act) && !a.strided_n && a.vec_io && a.Cout % 8 == 0 && a.Cout <= 128 && a.y_bytes != 0 &&
             a.HoWo >= 1024 && (!a.res || (long long)a.M * a.res_ld * 2 < (1ll << 31))) {
             HaloArgs h;
+            h.pool = 0;
             h.x = a.x; h.w = a.w; h.y = a.y; h.scale = a.scale; h.shift = a.shift; h.res = a.res;
             h.N = a.N; h.H = a.H; h.W = a.W; h.Cout = a.Cout; h.R = a.R; h.S = a.S; h.ph = a.ph; h.pw = a.pw;
             h.Ho = a.Ho; h.Wo = a.Wo; h.HoWo = a.HoWo; h.x_ld = a.x_ld; h.y_ld = a.y_ld; h.res_ld = a.res_ld;
@@ -604,6 +628,7 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
             if ((long)h.nring * h.PWp * PB + 512 <= 160 * 1024) return launch_conv_halo(h, st, num_cus());
         }
     }
+    if (pool) return fail(TLXMI_ERR_UNSUPPORTED, "conv2d: TLXMI_EPI_MAXPOOL_3S2P1 is an fp16-only fusion");
     struct Cand { int bm, bn; float eff; };
     const double flops = 2.0 * a.M * (double)a.Cout * a.kchunks * (16 / (int)sizeof(T));
     const double obytes = (double)a.M * a.Cout * sizeof(T) * (a.res ? 2.0 : 1.0);
@@ -635,8 +660,7 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
     if (!gemm256_ok) cands[5].eff = cands[6].eff = cands[8].eff = 0.f;
     if (!gemm256_ok && !pp_conv_ok) cands[7].eff = 0.f;
     // 128 x 256 tiles for plain GEMM rows too (few row tiles: 7 x 7 stage, 2048 -> 512); TLXMI_PP128=0: convs only (A/B)
-    int pp128_gemm = 1;
-    { const char* e = getenv("TLXMI_PP128"); if (e && *e) pp128_gemm = atoi(e); }
+    const int pp128_gemm = (int)tune_int("TLXMI_PP128", 1);
     if (!pp_conv_ok && !(gemm256_ok && pp128_gemm)) cands[9].eff = 0.f;
     if (!pp_conv128_ok) cands[10].eff = 0.f;      // (1x1 layers: reachable through TLXMI_TILE=10 only)
     cands[5].eff = 0.f;   // superseded by candidate 7 (same tile, antiphase wave groups); kept for A/B runs (TLXMI_TILE=5)
@@ -660,8 +684,7 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
     const int cus = num_cus();
     const long full_rounds = t256 / cus;
     // TLXMI_TAIL (A/B): 0 no split, 1 small tiles only (4 * left <= CUs), default: 128 x 256 tiles (2 * left <= CUs)
-    int tail_mode = 2;
-    { const char* e = getenv("TLXMI_TAIL"); if (e && *e) tail_mode = atoi(e); }
+    const int tail_mode = (int)tune_int("TLXMI_TAIL", 2);
     const bool tail_split = gemm256_ok && allow_split && tail_mode != 0 && full_rounds >= 1 && (t256 % cus) != 0 &&
                             (tail_mode == 1 ? 4 : 2) * (t256 % cus) <= cus;
     int best = 0;
@@ -693,8 +716,7 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
     }
     // tuning / test aid: TLXMI_TILE=<candidate> forces a tile shape (read on every call, so one process can
     // compare candidates: tools/ab_tiles.py, tests/test_gemm_gpu.py)
-    int forced = -1;
-    { const char* e = getenv("TLXMI_TILE"); if (e && *e) forced = atoi(e); }
+    const int forced = (int)tune_int("TLXMI_TILE", -1);
     if (forced >= 0 && forced < NC && !(cands[forced].bn == 128 && a.Cout <= 64) &&
         (forced < 5 || (forced <= 9 && gemm256_ok) || ((forced == 7 || forced == 9) && pp_conv_ok) ||
          (forced == 10 && (pp_conv128_ok || gemm128_ok)))) best = forced;
@@ -858,7 +880,7 @@ static int conv2d_impl(const tlxmi_conv2d_desc* d, int nchunk, const void* x, co
     a.x_bytes = (unsigned)x_bytes;
     {
         // non-temporal stores by default (measured: -3..-28 % per layer); TLXMI_STORE=0/16/2 overrides for tuning
-        static const int pol = [] { const char* e = getenv("TLXMI_STORE"); return e ? atoi(e) : 2; }();
+        const int pol = (int)tune_int("TLXMI_STORE", 2);
         const long long yb = M * (long long)d->y_ld * es;
         a.y_bytes = yb < (1ll << 31) ? (unsigned)yb : 0u;
         a.store_policy = (a.y_bytes && !d->y_nstride) ? pol : 0;
@@ -899,6 +921,12 @@ extern "C" int tlxmi_conv2d(const tlxmi_conv2d_desc* d, const void* x, const voi
                             const float* scale, const float* shift, const void* res, void* y,
                             void* stream) {
     return conv2d_impl(d, 1, x, w_packed, scale, shift, res, y, stream);
+}
+
+extern "C" int tlxmi_conv2d_maxpool_supported(const tlxmi_conv2d_desc* d) {
+    if (!d || d->dtype != TLXMI_F16) return 0;
+    return d->stride_h == 1 && d->stride_w == 1 && d->dil_h == 1 && d->dil_w == 1 && conv_halo_pool_ok(d->R, d->S, d->C * 2, d->Ho, d->Wo) &&
+           conv_halo_pool_act_ok(d->act) && d->Cout % 8 == 0 && d->Cout <= 128 && d->y_nstride == 0 && d->y_ld % 8 == 0;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -21,9 +21,21 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+// One process drives ONE device (the deployment model: one rank per GPU).  The per-kernel caches of this library —
+// raised dynamic-LDS limits (hipFuncSetAttribute), the CU count persistent grids are sized by — are process-wide, so a
+// second device in the same process is refused instead of silently running with the first device's settings.
+static int g_bound_device = -1;
+
 int check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(TLXMI_ERR_LAUNCH, "%s: HIP launch failed: %s", what, hipGetErrorString(e));
+    int dev = -1;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        if (g_bound_device < 0) g_bound_device = dev;
+        else if (dev != g_bound_device)
+            return fail(TLXMI_ERR_UNSUPPORTED, "%s: this process already runs libtlxmi on device %d; device %d needs its own process "
+                        "(one rank per GPU)", what, g_bound_device, dev);
+    }
     return TLXMI_OK;
 }
 

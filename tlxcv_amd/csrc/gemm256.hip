@@ -251,7 +251,7 @@ template <typename T, int BN, int WGN, int NSLOT> static int launch_v(const Gemm
     a.mtiles = (a.M + 255) / 256;
     a.ntiles = (a.Cout + BN - 1) / BN;
     {
-        static const long budget = [] { const char* e = getenv("TLXMI_PANEL_KB"); return (e ? atol(e) : (1l << 20)) * 1024; }();   // default: no panels (N fastest); measured neutral
+        const long budget = tune_int("TLXMI_PANEL_KB", 1l << 20) * 1024;   // default: no panels (N fastest); measured neutral
         long gn = budget / ((long)BN * a.Kp_bytes);
         a.gn = (int)(gn < 1 ? 1 : (gn > a.ntiles ? a.ntiles : gn));
     }

@@ -327,7 +327,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
 #undef TLXMI_PP_MMA
 #undef TLXMI_PP_SYNC
 
-    if (a.debug & 1) {   // ablation: no epilogue
+    if TLXMI_DBG(a, 1) {   // ablation: no epilogue
 #pragma unroll
         for (int i = 0; i < 2 * HN; ++i)
 #pragma unroll
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
 // Preconditions as launch_gemm256 (checked by conv_igemm.hip's dispatcher); a.ksteps = packed pitch / 128.
 template <typename T, int HM, int HN, bool CONV> static int launch_pp_t(const Gemm256Args& a0, hipStream_t st, bool& raised) {
     Gemm256Args a = a0;
-    { static const int dbg = [] { const char* e = getenv("TLXMI_DEBUG"); return e ? atoi(e) : 0; }(); a.debug = dbg; }
+    a.debug = (int)tune_int("TLXMI_DEBUG", 0);     // ablation bits: tuning flavour only (TLXMI_DBG is `false` in the product)
     a.mtiles = (a.M + 128 * HM - 1) / (128 * HM);
     a.ntiles = (a.Cout + 128 * HN - 1) / (128 * HN);
     a.gn = a.ntiles;

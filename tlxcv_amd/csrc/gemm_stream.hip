@@ -200,8 +200,8 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
         asm volatile("" : "+v"(px));   // offsets are recomputed here, not kept live across the K loop
         const int col = 128 * G + 32 * wc + 8 * fg;
         const int ch0 = bn0 + col;
-        const bool chok = live && ch0 < a.Cout && !(a.debug & 2);      // Cout is a multiple of 8 on this path
-        if (a.debug & 1) {   // ablation: stores without the arithmetic
+        const bool chok = live && ch0 < a.Cout && !TLXMI_DBG(a, 2);      // Cout is a multiple of 8 on this path
+        if TLXMI_DBG(a, 1) {   // ablation: stores without the arithmetic
 #pragma unroll
             for (int pi = 0; pi < 4 * (ES / 2); ++pi) gs_store16_nt(ysrd, __builtin_bit_cast(u32x4, acc[2 * G][4 * H + (pi & 3)]), OOB);
             return;
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
                 half8v hv;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) hv[e] = (half_t)v[e];
-                if (a.debug & 4) gs_store16_wb(ysrd, __builtin_bit_cast(u32x4, hv), yo);
+                if TLXMI_DBG(a, 4) gs_store16_wb(ysrd, __builtin_bit_cast(u32x4, hv), yo);
                 else gs_store16_nt(ysrd, __builtin_bit_cast(u32x4, hv), yo);
             } else {
                 f32x4 f0, f1;
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
 // with a residual: fp16, a.scale == nullptr, residual added before the activation, a.ksteps >= 11.
 template <typename T, int ACT, bool RES, bool ROWAFF = false> static int launch_gs(const Gemm256Args& a0, hipStream_t st, int cus) {
     Gemm256Args a = a0;
-    { static const int dbg = [] { const char* e = getenv("TLXMI_DEBUG"); return e ? atoi(e) : 0; }(); a.debug = dbg; }
+    a.debug = (int)tune_int("TLXMI_DEBUG", 0);     // ablation bits: tuning flavour only (TLXMI_DBG is `false` in the product)
     a.mtiles = (a.M + 255) / 256;
     a.ntiles = (a.Cout + 255) / 256;
     a.gn = a.ntiles;

@@ -903,7 +903,7 @@ extern "C" int tlxmi_dwconv2d(const tlxmi_dwconv2d_desc* d, const void* x, const
                   "dwconv2d: output extent %dx%d outside [%dx%d, %dx%d]", d->Ho, d->Wo, Ho, Wo, Ho_max, Wo_max);
     TLXMI_REQUIRE(d->act >= TLXMI_ACT_NONE && d->act <= TLXMI_ACT_SILU, TLXMI_ERR_BAD_ARG, "dwconv2d: bad act");
     // register-tiled strips for the shapes the models use (3x3 / 5x5, stride 1 / 2, no dilation); TLXMI_DWSTRIP=0: off (A/B)
-    static const int strip_on = [] { const char* e = getenv("TLXMI_DWSTRIP"); return e ? atoi(e) : 1; }();
+    const int strip_on = (int)tune_int("TLXMI_DWSTRIP", 1);
     if (strip_on && d->dil_h == 1 && d->dil_w == 1 && (d->S == 3 || d->S == 5) && (d->stride_w == 1 || d->stride_w == 2) && d->Wo >= 4) {
         constexpr int TW = 4;
         const int per_row = ((d->Wo + TW - 1) / TW) * (d->C / VECN(d->dtype));

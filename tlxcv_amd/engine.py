@@ -6,7 +6,6 @@ hands `tensor.data_ptr()` and the current HIP stream to libtlxmi.so.  Activation
 parity dtype.  There is deliberately no CPU branch: a CPU tensor raises.
 """
 import ctypes as C
-import os
 
 import torch
 
@@ -17,6 +16,22 @@ from ._lib import (ACT_GELU, ACT_HARDSIGMOID, ACT_HARDSWISH, ACT_LEAKY, ACT_NONE
 EPI_RES_BCAST_N = 2
 
 _precision = torch.float16
+
+# Host-side A/B switches (tools/ only; no environment variable is read on the product path).
+_options = {"splitk": True,       # classifier heads: K slices side by side (tlxmi_linear_splitk)
+            "lnfuse": False,      # LayerNorm folded into the next Linear (tlxmi_linear_ln): measured neutral, off
+            "attn_comb": True}    # Swin attention with the pre-summed bias + mask table (tlxmi_attention_comb)
+
+
+def set_option(name, value):
+    if name not in _options:
+        raise KeyError(f"unknown option {name!r}; have {sorted(_options)}")
+    _options[name] = bool(value)
+
+
+def option(name):
+    return _options[name]
+
 
 # Optional per-launch probe (bench.py): when a list is installed, every implicit-GEMM launch appends
 # (start_event, end_event, algorithmic_bytes, flops) recorded on the launch stream.
@@ -234,8 +249,10 @@ def _pair(v):
 
 def conv2d(x, pk, stride=1, padding=0, dilation=1, scale=None, shift=None, res=None, act=ACT_NONE,
            act_param=0.0, res_after_act=False, out=None, out_ld=None, y_nstride=0, res_nstride=0,
-           res_bcast=False, res_ld=None, out_hw=None, overhang=False):
-    """x (N,H,W,C>=Cin_pad...) NHWC -> y (N,Ho,Wo,Cout).  `out` may be a wider/pre-offset buffer."""
+           res_bcast=False, res_ld=None, out_hw=None, overhang=False, maxpool3s2=False):
+    """x (N,H,W,C>=Cin_pad...) NHWC -> y (N,Ho,Wo,Cout).  `out` may be a wider/pre-offset buffer.
+    maxpool3s2: fold nn.MaxPool2d(3, 2, 1) into the conv's epilogue (TLXMI_EPI_MAXPOOL_3S2P1) -> (N,Ho/2,Wo/2,Cout);
+    returns None — nothing launched — when the library has no fused kernel for this geometry."""
     need_gpu(x, "input")
     N, H, W, ld = x.shape
     if x.dtype != pk.dtype:
@@ -251,8 +268,10 @@ def conv2d(x, pk, stride=1, padding=0, dilation=1, scale=None, shift=None, res=N
         raise RuntimeError(f"conv2d: empty output {Ho}x{Wo} for input {H}x{W}")
     if out_hw is not None:      # crop (asymmetric padding of a space-to-depth stem), or one-sided end padding ('SAME' at stride 2)
         Ho, Wo = (int(out_hw[0]), int(out_hw[1])) if overhang else (min(Ho, out_hw[0]), min(Wo, out_hw[1]))
+    if maxpool3s2 and (out is not None or res is not None):
+        return None
     if out is None:
-        out = torch.empty((N, Ho, Wo, pk.Cout), dtype=x.dtype, device=x.device)
+        out = None if maxpool3s2 else torch.empty((N, Ho, Wo, pk.Cout), dtype=x.dtype, device=x.device)
         out_ld = pk.Cout
     elif out_ld is None:
         out_ld = out.shape[-1]
@@ -260,15 +279,20 @@ def conv2d(x, pk, stride=1, padding=0, dilation=1, scale=None, shift=None, res=N
                       stride_h=sh, stride_w=sw, pad_h=ph, pad_w=pw, dil_h=dh, dil_w=dw, Ho=Ho, Wo=Wo,
                       x_ld=ld, y_ld=out_ld, res_ld=(res_ld if res_ld is not None else (res.shape[-1] if res is not None else 0)),
                       y_nstride=y_nstride, res_nstride=res_nstride, act=act, act_param=float(act_param),
-                      flags=(EPI_RES_AFTER_ACT if res_after_act else 0) | (EPI_RES_BCAST_N if res_bcast else 0))
+                      flags=(EPI_RES_AFTER_ACT if res_after_act else 0) | (EPI_RES_BCAST_N if res_bcast else 0)
+                      | (_lib.EPI_MAXPOOL_3S2P1 if maxpool3s2 else 0))
     if res is not None and res.dtype != x.dtype:
         raise RuntimeError("conv2d: residual dtype mismatch")
+    if maxpool3s2:
+        if not _lib.load().tlxmi_conv2d_maxpool_supported(C.byref(d)):
+            return None
+        out = torch.empty((N, Ho // 2, Wo // 2, pk.Cout), dtype=x.dtype, device=x.device)
     if _probe is None:
         _lib.call("tlxmi_conv2d", C.byref(d), _p(x), _p(pk.buf), _p(scale), _p(shift), _p(res), _p(out), _stream())
         return out
     es = x.element_size()
     M = N * Ho * Wo
-    alg_bytes = (N * H * W * pk.Cin + M * pk.Cout * (2 if res is not None else 1)
+    alg_bytes = (N * H * W * pk.Cin + (M // 4 if maxpool3s2 else M) * pk.Cout * (2 if res is not None else 1)
                  + pk.Cout * pk.Cin * pk.R * pk.S) * es
     flops = 2 * M * pk.Cout * pk.Cin * pk.R * pk.S
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -337,6 +361,8 @@ def linear(x, pk, bias=None, res=None, act=ACT_NONE, out=None):
     o4 = None
     if out is not None:
         o4 = out.view(rows, 1, 1, pk.Cout)
+    if x.dtype != pk.dtype:
+        raise RuntimeError(f"linear: input dtype {x.dtype} != packed filter dtype {pk.dtype}")
     splits = _linear_splits(rows, shp[-1], pk, x) if (out is None and _probe is None and pk.R == 1 and pk.S == 1) else 0
     if splits:
         # few rows, large filter (classifier heads): K slices side by side + a deterministic reduction (tlxmi_linear_splitk)
@@ -350,8 +376,8 @@ def linear(x, pk, bias=None, res=None, act=ACT_NONE, out=None):
 
 
 def _linear_splits(rows, K, pk, x):
-    """Number of K slices for a Linear with few rows (0: run it as one GEMM).  TLXMI_SPLITK=0 turns the path off (A/B)."""
-    if os.environ.get("TLXMI_SPLITK", "1") == "0" or rows > 512 or pk.Cin != K or pk.Cin_pad != K:
+    """Number of K slices for a Linear with few rows (0: run it as one GEMM).  set_option("splitk", False) turns the path off (A/B)."""
+    if not _options["splitk"] or rows > 512 or pk.Cin != K or pk.Cin_pad != K:
         return 0
     es = x.element_size()
     if K * es < 8192 or pk.Cout * K * es < 8000000 or (pk.Cout * es) % 16:      # a filter of >= 8 MB with K >= 4096 (fp16)
@@ -374,12 +400,12 @@ def _linear_splits(rows, K, pk, x):
 
 
 def linear_ln_supported(K, Cout, dtype, rows=None, device=None):
-    """Whether a layer takes the fused LayerNorm + Linear path (tlxmi_linear_ln).  OFF unless TLXMI_LNFUSE=1:
+    """Whether a layer takes the fused LayerNorm + Linear path (tlxmi_linear_ln).  OFF unless set_option("lnfuse", True):
     measured on ViT-B/16 (same box, hipGraph replay) the fused qkv is -1 % end to end and fused qkv + fc1 -1..+1 %
     — the statistics pass (28 us) plus the row-affine epilogue cost what the LayerNorm pass (46 us) saved.  fp16
     only: the fp32 parity mode keeps the reference's order of operations.  With `rows` given, also requires the
     one-workgroup-per-CU launch to fill its last round (the fused call has no tail split)."""
-    if os.environ.get("TLXMI_LNFUSE", "0") != "1":
+    if not _options["lnfuse"]:
         return False
     if not (dtype == torch.float16 and Cout % 8 == 0 and Cout >= 256 and K % 8 == 0 and K * 2 >= 256):
         return False

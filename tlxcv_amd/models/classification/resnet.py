@@ -141,10 +141,10 @@ class ResNet(nn.Module):
         if (self.data_format == 'channels_first' and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
                 and not x.permute(0, 2, 3, 1).is_contiguous()):
             # NCHW image: 2x2 space-to-depth fold + 4x4/1 conv == the 7x7/2 pad-3 stem (resnet.py:199-207, 287-289)
-            v = self.conv1.run_stem(x, 2, self.bn1, E.ACT_RELU)
+            # the max-pool (:290) rides in the stem's epilogue where the library has the fused kernel (224 x 224 inputs)
+            v = self.conv1.run_stem(x, 2, self.bn1, E.ACT_RELU, maxpool=self.maxpool)
         else:
-            v = self.conv1.run_nhwc(as_nhwc(x, self.data_format), self.bn1, E.ACT_RELU)
-        v = self.maxpool.run_nhwc(v)                           # :290
+            v = self.maxpool.run_nhwc(self.conv1.run_nhwc(as_nhwc(x, self.data_format), self.bn1, E.ACT_RELU))   # :287-290
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
             for blk in layer:
                 v = blk.forward_nhwc(v)

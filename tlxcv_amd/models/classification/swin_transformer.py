@@ -14,7 +14,6 @@ bias (+ shift mask) -> softmax -> @v -> proj -> window_reverse -> roll back -> r
   * PatchMerging's strided 2x2 gather + concat is one copy kernel, then LayerNorm and the GEMM.
 Quirks kept on purpose: the -100.0 (not -inf) mask, and the PatchMerging reduction bias (:369-370).
 """
-import os
 
 import numpy as np
 import torch
@@ -87,7 +86,7 @@ class WindowAttention(nn.Module):
     def run(self, xw, mask=None):
         qkv = self.qkv.run(xw)                                                     # (B_, N, 3C)
         hd = self.dim // self.num_heads
-        if qkv.dtype == torch.float16 and hd in (32, 64, 96) and qkv.shape[1] <= 256 and os.environ.get("TLXMI_ATTN_COMB", "1") != "0":
+        if qkv.dtype == torch.float16 and hd in (32, 64, 96) and qkv.shape[1] <= 256 and E.option("attn_comb"):
             # relative position bias + shift mask summed and padded once per layer (:205-220 adds them per forward)
             # keyed by the mask's storage, in-place version and shape — not id(): a temporary mask can be collected and its
             # id reused by another tensor

@@ -113,7 +113,7 @@ class Block(nn.Module):
 
     def run_inplace(self, x):
         """x (B, N, C) engine dtype, updated in place: x += attn(norm1(x)); x += mlp(norm2(x))."""
-        self.attn.run(x, res=x, norm=self.norm1)       # norm1 -> qkv: folded into the GEMM only with TLXMI_LNFUSE=1
+        self.attn.run(x, res=x, norm=self.norm1)       # norm1 -> qkv: folded into the GEMM only with engine.set_option('lnfuse', True)
         self.mlp.run(self.norm2(x), res=x)             # (engine.linear_ln_supported: measured neutral to -1 %)
         return x
 

@@ -513,10 +513,12 @@ class GroupConv2d(Module):
             raise NotImplementedError("depthwise conv with fused residual")
         return E.dwconv2d(x, pk, self.stride, padding, self.dilation, scale, shift, act, act_param, out_hw=kw.get("out_hw"))
 
-    def run_stem(self, x_nchw, b, bn=None, act=E.ACT_NONE, act_param=0.0, **kw):
+    def run_stem(self, x_nchw, b, bn=None, act=E.ACT_NONE, act_param=0.0, maxpool=None, **kw):
         """Few-channel first conv (RGB stem / patch embedding) on a b x b space-to-depth input: the 3-channel
         image would leave 5 of every 8 fp16 K-lanes zero; folding b x b pixels into channels makes K dense
-        (7x7/2 stem: 448 -> 256; 16x16/16 patch embed: 2048 -> 768).  Same arithmetic, re-indexed once."""
+        (7x7/2 stem: 448 -> 256; 16x16/16 patch embed: 2048 -> 768).  Same arithmetic, re-indexed once.
+        maxpool: the nn.MaxPool2d that follows (resnet.py:290) — taken in the conv's epilogue when it is the 3/2/1 pool
+        and the library has the fused kernel for this geometry, otherwise run as its own launch."""
         self._require_eval()
         E.need_gpu(x_nchw, "input")
         if self.data_format != "channels_first" or self.n_group != 1 or self.dilation != (1, 1):
@@ -544,8 +546,14 @@ class GroupConv2d(Module):
         else:
             scale, shift = None, (self._cached("bias", lambda: E._f32(self.biases)) if self.biases is not None else None)
         v = E.nchw_to_nhwc_s2d(x_nchw, b, dt)
-        return E.conv2d(v, pk, (sh // b, sw // b), pad2, 1, scale, shift, act=act, act_param=act_param,
-                        out_hw=(Ho, Wo), **kw)
+        if maxpool is not None and (maxpool.kernel_size, maxpool.stride, maxpool.padding) == ((3, 3), (2, 2), (1, 1)) and not kw:
+            y = E.conv2d(v, pk, (sh // b, sw // b), pad2, 1, scale, shift, act=act, act_param=act_param, out_hw=(Ho, Wo),
+                         maxpool3s2=True)
+            if y is not None:
+                return y
+        y = E.conv2d(v, pk, (sh // b, sw // b), pad2, 1, scale, shift, act=act, act_param=act_param,
+                     out_hw=(Ho, Wo), **kw)
+        return maxpool.run_nhwc(y) if maxpool is not None else y
 
     def forward(self, x):
         y = self.run_nhwc(as_nhwc(x, self.data_format))

@@ -8,7 +8,9 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 import tlxcv_amd  # noqa: E402,F401
-from tlxcv_amd import seeded, models, engine as E  # noqa: E402
+from tlxcv_amd import seeded, models, engine as E, _lib  # noqa: E402
+
+_lib.tuning().__enter__()      # the whole run goes through libtlxmi_tune.so, the flavour that reads the knobs per call
 
 var, va, vb = sys.argv[1:4]
 ctor = sys.argv[4] if len(sys.argv) > 4 else "resnet50"
