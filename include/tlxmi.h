@@ -147,6 +147,27 @@ int tlxmi_conv2d(const tlxmi_conv2d_desc* d, const void* x, const void* w_packed
 int tlxmi_conv2d_maxpool_supported(const tlxmi_conv2d_desc* d);
 
 /* ------------------------------------------------------------------------------------------
+ * The seam between two ResNet bottleneck blocks in one launch (resnet.py:142-156 of block b, :143-145 of block b + 1):
+ *     y  = relu( (t2 . W3^T) * scale3 + shift3 + skip )      conv3 + bn3 + residual add + relu of block b
+ *     t1 = relu( (y  . W1^T) * scale1 + shift1 )             conv1 + bn1 + relu of block b + 1
+ * t2: [rows][t2_ld] (K1 channels), skip / y: [rows][..] (N1 channels), t1: [rows][t1_ld] (N2 channels); w3_packed /
+ * w1_packed: tlxmi_pack_filter images of the two 1x1 filters ([N1][K1] and [N2][N1]).  The wide map y is written once
+ * and never re-read by the second convolution.  fp16 only, ReLU only (`act`), channel triples with a compiled kernel:
+ * ask tlxmi_bottleneck_seam_supported(dtype, K1, N1, N2) first; otherwise two tlxmi_conv2d launches do the same.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct tlxmi_seam_desc {
+    int32_t dtype;
+    int64_t rows;                        /* pixels: N * H * W */
+    int32_t K1, N1, N2;
+    int32_t t2_ld, skip_ld, y_ld, t1_ld; /* elements between rows */
+    int32_t act;                         /* TLXMI_ACT_RELU */
+} tlxmi_seam_desc;
+int tlxmi_bottleneck_seam_supported(int dtype, int K1, int N1, int N2);
+int tlxmi_bottleneck_seam(const tlxmi_seam_desc* d, const void* t2, const void* w3_packed, const float* scale3,
+                          const float* shift3, const void* skip, void* y, const void* w1_packed, const float* scale1,
+                          const float* shift1, void* t1, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Grouped convolution, 1 < groups < C: nn.GroupConv2d(n_group=cardinality) of the ResNeXt bottleneck,
  * resnext.py:30-40 (constructed at :83-91 with groups = 32 / 64), + BatchNorm(act='relu') :46-52.
  * d->C / d->Cout are the TOTAL input / output channels (both divisible by groups), x_ld / y_ld the pixel

@@ -1,0 +1,71 @@
+"""The fused bottleneck seam (tlxmi_bottleneck_seam, block_seam.hip): conv3 + bn3 + skip + relu of block b and conv1 + bn1 +
+relu of block b + 1 (resnet.py:142-156) as one launch — against the oracle and against the two-launch path, for every
+compiled channel triple, with row counts that leave partial waves and partial workgroups."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import functional as OF
+from tlxcv_amd import engine as E
+from util import rnd, q16
+
+pytestmark = pytest.mark.gpu
+
+# (K1, N1, N2, N, H, W): ResNet-50 layer1 / seam into layer2 / layer2 / seam into layer3 / layer3, small extents
+CASES = [(64, 256, 64, 1, 9, 9), (64, 256, 64, 3, 14, 14), (64, 256, 128, 2, 7, 5), (128, 512, 128, 1, 11, 13),
+         (128, 512, 256, 2, 6, 6)]
+
+
+def _make(K1, N1, N2, N, H, W, seed):
+    rng = np.random.default_rng(seed)
+    t2 = q16(torch.relu(rnd(rng, (N, K1, H, W))))
+    skip = q16(torch.relu(rnd(rng, (N, N1, H, W))))
+    w3 = q16(rnd(rng, (N1, K1, 1, 1), (2.0 / K1) ** 0.5))
+    w1 = q16(rnd(rng, (N2, N1, 1, 1), (2.0 / N1) ** 0.5))
+    s3 = torch.from_numpy(rng.uniform(0.2, 0.6, N1).astype(np.float32))
+    h3 = rnd(rng, (N1,), 0.2)
+    s1 = torch.from_numpy(rng.uniform(0.5, 1.5, N2).astype(np.float32))
+    h1 = rnd(rng, (N2,), 0.2)
+    return t2, skip, w3, w1, s3, h3, s1, h1
+
+
+@pytest.mark.parametrize("cfg", CASES, ids=lambda c: "x".join(map(str, c)))
+def test_seam_matches_the_oracle_and_the_two_launch_path(dev, fp16_mode, cfg):
+    K1, N1, N2, N, H, W = cfg
+    assert E.bottleneck_seam_supported(K1, N1, N2, torch.float16)
+    t2, skip, w3, w1, s3, h3, s1, h1 = _make(*cfg, seed=K1 + N2 + H)
+    y_ref = OF.conv_bn_act(t2, w3, s3, h3, skip, E.ACT_RELU)                       # fp32 oracle on the fp16-rounded inputs
+    t1_ref = OF.conv_bn_act(q16(y_ref), w1, s1, h1, None, E.ACT_RELU)              # the reduce conv sees y as stored (fp16)
+    nh = lambda a: a.permute(0, 2, 3, 1).contiguous().half().to(dev)               # noqa: E731
+    pk3, pk1 = E.PackedFilter(w3.to(dev), torch.float16), E.PackedFilter(w1.to(dev), torch.float16)
+    s3d, h3d, s1d, h1d = (v.to(dev) for v in (s3, h3, s1, h1))
+    y, t1 = E.bottleneck_seam(nh(t2), pk3, s3d, h3d, nh(skip), pk1, s1d, h1d)
+    y2 = E.conv2d(nh(t2), pk3, 1, 0, 1, s3d, h3d, nh(skip), E.ACT_RELU)
+    t12 = E.conv2d(y2, pk1, 1, 0, 1, s1d, h1d, None, E.ACT_RELU)
+    torch.cuda.synchronize()
+    assert y.shape == (N, H, W, N1) and t1.shape == (N, H, W, N2)
+    torch.testing.assert_close(y.float().cpu().permute(0, 3, 1, 2), y_ref, atol=2e-3, rtol=2e-3)
+    torch.testing.assert_close(t1.float().cpu().permute(0, 3, 1, 2), t1_ref, atol=4e-3, rtol=4e-3)
+    # against the same engine run as two launches: same fp32 accumulation of fp16 products, possibly another order
+    torch.testing.assert_close(y.float(), y2.float(), atol=2e-3, rtol=2e-3)
+    torch.testing.assert_close(t1.float(), t12.float(), atol=4e-3, rtol=4e-3)
+
+
+def test_seam_at_full_size_is_consistent_with_two_launches(dev, fp16_mode):
+    """BASELINE-sized: 64 images at 56 x 56 (200704 pixels): the fused launch and the two convolutions agree everywhere."""
+    cfg = (64, 256, 64, 64, 56, 56)
+    t2, skip, w3, w1, s3, h3, s1, h1 = _make(*cfg, seed=99)
+    nh = lambda a: a.permute(0, 2, 3, 1).contiguous().half().to(dev)               # noqa: E731
+    pk3, pk1 = E.PackedFilter(w3.to(dev), torch.float16), E.PackedFilter(w1.to(dev), torch.float16)
+    s3d, h3d, s1d, h1d = (v.to(dev) for v in (s3, h3, s1, h1))
+    a, b = nh(t2), nh(skip)
+    y, t1 = E.bottleneck_seam(a, pk3, s3d, h3d, b, pk1, s1d, h1d)
+    y2 = E.conv2d(a, pk3, 1, 0, 1, s3d, h3d, b, E.ACT_RELU)
+    t12 = E.conv2d(y2, pk1, 1, 0, 1, s1d, h1d, None, E.ACT_RELU)
+    torch.cuda.synchronize()
+    assert (y.float() - y2.float()).abs().max().item() <= 4e-3 and (t1.float() - t12.float()).abs().max().item() <= 8e-3
+
+
+def test_unsupported_triples_are_reported_not_run(dev):
+    assert not E.bottleneck_seam_supported(96, 384, 96, torch.float16)
+    assert not E.bottleneck_seam_supported(64, 256, 64, torch.float32)

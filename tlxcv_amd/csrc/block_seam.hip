@@ -1,0 +1,338 @@
+// The seam between two ResNet bottleneck blocks as ONE launch (fp16):
+//
+//     y  = relu( bn3(conv3(t2)) + skip )                  the "expand" 1x1 conv of block b      (resnet.py:151-155)
+//     t1 = relu( bn1'(conv1'(y)) )                        the "reduce" 1x1 conv of block b + 1  (resnet.py:143-145)
+//
+// Layer by layer the wide map y (256 x 56 x 56 x 256 channels = 411 MB at batch 256) crosses HBM three times per block:
+// written by the expand conv, read back by the next block's reduce conv, read again as that block's skip.  Here the
+// reduce conv consumes y while it is still in registers, so y is written once and read once: per seam at 56 x 56 the
+// traffic drops from 1439 MB to 1028 MB (t2 103 + skip 411 + y 411 + t1 103).
+//
+// Both convs are 1x1, so a pixel's t1 depends on that pixel's y only: a wave owns 32 pixels (two MFMA column blocks of
+// 16) and needs no other wave.  D[channel][pixel] orientation (weights are the A operand), 64 output channels of the
+// expand conv per step:
+//   GEMM1  acc1[ci][pw] (4 sub-tiles of 16 channels) = W3[64c .. 64c+63][:] . t2[pixels][:]
+//          sub-tile ci, MFMA row i  <->  channel 64c + 16*(i >> 2) + 4*ci + (i & 3), so that the lane of pixel p and lane
+//          group g ends up with the 16 CONSECUTIVE channels 64c + 16g .. + 15 of its pixel (32 contiguous bytes of y);
+//   epilogue: * scale3 + shift3 + skip, ReLU, -> fp16: stored to y AND — packed 8 + 8 — exactly the B-operand fragments
+//          of the next product's two k-steps (k-step s of lane group g = channels 64c + 16g + 8s .. + 7): the accumulator
+//          tile is the next MFMA's operand, no LDS, no shuffle;
+//   GEMM2  acc2[t][pw] += W1'[:][64c .. 64c+63] . y-chunk   (all N2 output channels, accumulated over the steps)
+// and after the last step acc2 * scale1 + shift1, ReLU -> t1.
+// The activation streams (t2, skip in; y, t1 out) are 16-byte-per-lane accesses whose four lane groups cover whole
+// 128-byte lines; the filters are staged through LDS per step (below).
+// Bound: HBM.  Algorithmic bytes per pixel: (K1 + 2*N1 + N2) * 2.
+#include "common.h"
+#include "block_seam.h"
+
+namespace tlxmi {
+
+static __device__ __forceinline__ __amdgpu_buffer_rsrc_t bs_srd(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+static __device__ __forceinline__ u32x4 bs_load16(__amdgpu_buffer_rsrc_t rsrc, int voff) {
+    return __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
+}
+static __device__ __forceinline__ void bs_store16_nt(__amdgpu_buffer_rsrc_t rsrc, u32x4 v, int voff) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff, 0, 2);
+}
+static __device__ __forceinline__ void bs_store16(__amdgpu_buffer_rsrc_t rsrc, u32x4 v, int voff) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff, 0, 0);
+}
+static __device__ __forceinline__ f32x4 bs_mma(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8v, a), __builtin_bit_cast(half8v, b), c, 0, 0, 0);
+}
+
+// Weight staging.  Every wave needs every filter element, so the filters go through LDS once per workgroup instead of
+// once per wave (as A fragments straight from L2 the fragment-shaped reads — 16 rows x 64 bytes per instruction — ran at
+// ~4.8 TB/s chip-wide and bound the kernel: 333 us against 280 us for the two separate convolutions at 56 x 56).  A
+// step's filters are (K1/64 + N2/64) panels of [64 rows][128 bytes]: W3 rows 64c .. 64c+63 cut into 64-channel column
+// blocks, and the columns 64c .. 64c+63 of W1' cut into 64-row blocks.  All 512 threads load one 16-byte chunk of every
+// panel of step c + 1 (plain loads: no LDS-DMA in this kernel, so hipcc's counted waits stay exact) while step c is
+// computed, and write them into the other buffer before the step's single barrier.  16-byte chunk k of panel row r sits
+// at slot k ^ f(r): with the lane -> row map of the A fragments (row = 16*(i >> 2) + 4*ci + (i & 3), i = lane & 15)
+//     f1(r) = ((r >> 1) & 1) | (((r >> 4) & 3) << 1)          W3 panels,  chunk = 4*(k-step & 1) + lane group
+//     f2(r) = (((r >> 1) & 1) << 2) | ((r >> 5) & 1)          W1' panels, chunk = 2*lane group + k-step
+// make every ds_read_b128 lane group (4 x 16 lanes: {0-3,12-15,20-27} ...) hit 16 distinct 16-byte bank slots.
+static __device__ __forceinline__ int bs_f1(int r) { return ((r >> 1) & 1) | (((r >> 4) & 3) << 1); }
+static __device__ __forceinline__ int bs_f2(int r) { return (((r >> 1) & 1) << 2) | ((r >> 5) & 1); }
+
+// K1: input channels of the expand conv (t2), N2: output channels of the reduce conv (t1); N1 (channels of y) is a
+// runtime multiple of 64.  PW: MFMA pixel blocks (16 pixels) per wave; 8 waves per workgroup.
+template <int K1, int N2, int PW, int NW>
+__global__ __launch_bounds__(64 * NW) void seam_kernel(const SeamArgs a) {
+    constexpr int NT = 64 * NW;          // threads
+    constexpr int IPT = 512 / NT;        // 16-byte chunks of a panel each thread stages
+    constexpr int KS = K1 / 32;          // k-steps of GEMM1
+    constexpr int CB = K1 / 64;          // W3 panels of a step
+    constexpr int Q2 = N2 / 64;          // W1' panels of a step
+    constexpr int NP = CB + Q2;
+    constexpr int T2 = N2 / 16;          // MFMA row tiles of GEMM2
+    constexpr int PANEL = 64 * 128;
+    constexpr int OOB = (int)0x80000000;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const wbuf = smem;                                                   // two step buffers of NP panels
+    float* const tab3 = reinterpret_cast<float*>(smem + 2 * NP * PANEL);       // scale3[N1], shift3[N1]
+    float* const tab1 = tab3 + 2 * a.N1;                                       // scale1[N2], shift1[N2]
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int fr = lane & 15, g = lane >> 4;
+
+    const __amdgpu_buffer_rsrc_t xsrd = bs_srd(a.x, a.x_bytes), w3srd = bs_srd(a.w3, a.w3_bytes), w1srd = bs_srd(a.w1, a.w1_bytes);
+    const __amdgpu_buffer_rsrc_t rsrd = bs_srd(a.res, a.res_bytes), ysrd = bs_srd(a.y, a.y_bytes), zsrd = bs_srd(a.z, a.z_bytes);
+
+    // staging: chunk k of this thread in every panel = (row, physical slot) of index k*NT + t; the logical chunks it fetches
+    auto stage_load = [&](int c, u32x4 (&st)[NP][IPT]) {
+#pragma unroll
+        for (int k = 0; k < IPT; ++k) {
+            const int idx = k * NT + t, srow = idx >> 3, sslot = idx & 7;
+            const int sl1 = sslot ^ bs_f1(srow), sl2 = sslot ^ bs_f2(srow);
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) st[cb][k] = bs_load16(w3srd, ((64 * c + srow) * K1 + 64 * cb + 8 * sl1) * 2);
+#pragma unroll
+            for (int q = 0; q < Q2; ++q) st[CB + q][k] = bs_load16(w1srd, ((64 * q + srow) * a.N1 + 64 * c + 8 * sl2) * 2);
+        }
+    };
+    auto stage_write = [&](int buf, const u32x4 (&st)[NP][IPT]) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j)
+#pragma unroll
+            for (int k = 0; k < IPT; ++k) *reinterpret_cast<u32x4*>(wbuf + (buf * NP + j) * PANEL + (k * NT + t) * 16) = st[j][k];
+    };
+
+    // this wave's pixels: block pw covers pixels m0 + 16*pw + fr (waves past the end still stage filters and keep the barriers)
+    const int m0 = ((int)blockIdx.x * NW + wid) * (16 * PW);
+    int pix[PW];
+    bool pok[PW];
+#pragma unroll
+    for (int pw = 0; pw < PW; ++pw) {
+        pix[pw] = m0 + 16 * pw + fr;
+        pok[pw] = pix[pw] < a.M;
+    }
+
+    // t2 fragments (B operand of GEMM1): lane (pixel fr, group g) holds channels 32*ks + 8g .. + 7
+    u32x4 xf[KS][PW];
+#pragma unroll
+    for (int pw = 0; pw < PW; ++pw)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            xf[ks][pw] = bs_load16(xsrd, pok[pw] ? (pix[pw] * a.x_ld + 32 * ks + 8 * g) * 2 : OOB);
+    auto skip_load = [&](int c, u32x4 (&sk)[PW][2]) {
+#pragma unroll
+        for (int pw = 0; pw < PW; ++pw)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                sk[pw][h] = bs_load16(rsrd, pok[pw] ? (pix[pw] * a.res_ld + 64 * c + 16 * g + 8 * h) * 2 : OOB);
+    };
+    u32x4 sk[PW][2];
+    skip_load(0, sk);
+    {
+        u32x4 st[NP][IPT];
+        stage_load(0, st);
+        for (int i = t; i < a.N1; i += NT) {
+            tab3[i] = a.scale3 ? a.scale3[i] : 1.f;
+            tab3[a.N1 + i] = a.shift3 ? a.shift3[i] : 0.f;
+        }
+        for (int i = t; i < N2; i += NT) {
+            tab1[i] = a.scale1 ? a.scale1[i] : 1.f;
+            tab1[N2 + i] = a.shift1 ? a.shift1[i] : 0.f;
+        }
+        stage_write(0, st);
+    }
+    __syncthreads();
+
+    // A-fragment addresses inside a panel: row arow + 4*ci; W3: chunk 4*h + g (h = k-step & 1); W1': chunk 2*g + s
+    const int arow = 16 * (fr >> 2) + (fr & 3);
+    int a1off[4], a2off[4];
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci) {
+        const int r = arow + 4 * ci;
+        a1off[ci] = r * 128 + ((g ^ bs_f1(r)) << 4);          // k-step parity h: XOR 64 (chunk bit 2; f1 < 8 keeps it separate)
+        a2off[ci] = r * 128 + (((2 * g) ^ bs_f2(r)) << 4);    // k-step s: XOR 16 (chunk bit 0)
+    }
+
+    f32x4 acc2[T2][PW];
+#pragma unroll
+    for (int tt = 0; tt < T2; ++tt)
+#pragma unroll
+        for (int pw = 0; pw < PW; ++pw) acc2[tt][pw] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nch = a.N1 >> 6;
+#pragma unroll 1
+    for (int c = 0; c < nch; ++c) {
+        const char* const wb = wbuf + (c & 1) * NP * PANEL;
+        const bool more = c + 1 < nch;
+        u32x4 st[NP][IPT], skn[PW][2];
+        if (more) {                                   // next step's filters and skip: in flight under this step's MFMAs
+            stage_load(c + 1, st);
+            skip_load(c + 1, skn);
+        }
+
+        // ---- GEMM1: 64 channels of the expand conv
+        f32x4 acc1[4][PW];
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci) {
+#pragma unroll
+            for (int pw = 0; pw < PW; ++pw) acc1[ci][pw] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const u32x4 af = *reinterpret_cast<const u32x4*>(wb + (ks >> 1) * PANEL + (a1off[ci] ^ ((ks & 1) << 6)));
+#pragma unroll
+                for (int pw = 0; pw < PW; ++pw) acc1[ci][pw] = bs_mma(af, xf[ks][pw], acc1[ci][pw]);
+            }
+        }
+
+        // ---- epilogue 1: folded BatchNorm, + skip, ReLU; y out; the rounded values are GEMM2's B fragments
+        u32x4 yf[PW][2];
+        {
+            const float* sc = tab3 + 64 * c + 16 * g;
+            const float* sh = sc + a.N1;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 s0 = *reinterpret_cast<const f32x4*>(sc + 8 * h), s1 = *reinterpret_cast<const f32x4*>(sc + 8 * h + 4);
+                const f32x4 h0 = *reinterpret_cast<const f32x4*>(sh + 8 * h), h1 = *reinterpret_cast<const f32x4*>(sh + 8 * h + 4);
+#pragma unroll
+                for (int pw = 0; pw < PW; ++pw) {
+                    const half8v rv = __builtin_bit_cast(half8v, sk[pw][h]);
+                    half8v o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v0 = acc1[2 * h][pw][e] * s0[e] + h0[e] + (float)rv[e];
+                        const float v1 = acc1[2 * h + 1][pw][e] * s1[e] + h1[e] + (float)rv[4 + e];
+                        o[e] = (half_t)fmaxf(v0, 0.f);
+                        o[4 + e] = (half_t)fmaxf(v1, 0.f);
+                    }
+                    yf[pw][h] = __builtin_bit_cast(u32x4, o);
+                    if (a.y_nt) bs_store16_nt(ysrd, yf[pw][h], pok[pw] ? (pix[pw] * a.y_ld + 64 * c + 16 * g + 8 * h) * 2 : OOB);
+                    else bs_store16(ysrd, yf[pw][h], pok[pw] ? (pix[pw] * a.y_ld + 64 * c + 16 * g + 8 * h) * 2 : OOB);
+                }
+            }
+        }
+
+        // ---- GEMM2: this step's 64 channels are two k-steps of the reduce conv
+#pragma unroll
+        for (int tt = 0; tt < T2; ++tt) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const u32x4 af = *reinterpret_cast<const u32x4*>(wb + (CB + (tt >> 2)) * PANEL + (a2off[tt & 3] ^ (s << 4)));
+#pragma unroll
+                for (int pw = 0; pw < PW; ++pw) acc2[tt][pw] = bs_mma(af, yf[pw][s], acc2[tt][pw]);
+            }
+        }
+
+        if (more) {
+            stage_write((c + 1) & 1, st);
+#pragma unroll
+            for (int pw = 0; pw < PW; ++pw) { sk[pw][0] = skn[pw][0]; sk[pw][1] = skn[pw][1]; }
+        }
+        __syncthreads();      // every wave is done with this step's buffer; the next step's is written
+    }
+
+    // ---- epilogue 2: t1 = relu(acc2 * scale1 + shift1); the lane holds 16 consecutive channels per block of 64
+#pragma unroll
+    for (int q = 0; q < N2 / 64; ++q) {
+        const float* sc = tab1 + 64 * q + 16 * g;
+        const float* sh = sc + N2;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const f32x4 s0 = *reinterpret_cast<const f32x4*>(sc + 8 * h), s1 = *reinterpret_cast<const f32x4*>(sc + 8 * h + 4);
+            const f32x4 h0 = *reinterpret_cast<const f32x4*>(sh + 8 * h), h1 = *reinterpret_cast<const f32x4*>(sh + 8 * h + 4);
+#pragma unroll
+            for (int pw = 0; pw < PW; ++pw) {
+                half8v o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = (half_t)fmaxf(acc2[4 * q + 2 * h][pw][e] * s0[e] + h0[e], 0.f);
+                    o[4 + e] = (half_t)fmaxf(acc2[4 * q + 2 * h + 1][pw][e] * s1[e] + h1[e], 0.f);
+                }
+                if (a.z_nt) bs_store16_nt(zsrd, __builtin_bit_cast(u32x4, o), pok[pw] ? (pix[pw] * a.z_ld + 64 * q + 16 * g + 8 * h) * 2 : OOB);
+                else bs_store16(zsrd, __builtin_bit_cast(u32x4, o), pok[pw] ? (pix[pw] * a.z_ld + 64 * q + 16 * g + 8 * h) * 2 : OOB);
+            }
+        }
+    }
+}
+
+template <int K1, int N2, int PW, int NW> static int launch_seam_t(const SeamArgs& a, hipStream_t st) {
+    constexpr int NP = K1 / 64 + N2 / 64;
+    const size_t lds = (size_t)2 * NP * 64 * 128 + (size_t)(2 * a.N1 + 2 * N2) * sizeof(float);
+    if (lds > 160 * 1024) return fail(TLXMI_ERR_UNSUPPORTED, "block_seam: %zu bytes of LDS", lds);
+    const void* fn = reinterpret_cast<const void*>(&seam_kernel<K1, N2, PW, NW>);
+    if (lds > 64 * 1024) {
+        static bool raised = false;
+        if (!raised) {
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return fail(TLXMI_ERR_LAUNCH, "block_seam: cannot raise LDS limit: %s", hipGetErrorString(e));
+            raised = true;
+        }
+    }
+    const long grid = ((long)a.M + NW * 16 * PW - 1) / (NW * 16 * PW);
+    if (grid >= (1l << 31)) return fail(TLXMI_ERR_UNSUPPORTED, "block_seam: too many rows");
+    SeamArgs b = a;
+    void* args[] = {&b};
+    hipError_t e = hipLaunchKernel(fn, dim3((unsigned)grid), dim3(64 * NW), args, lds, st);
+    if (e != hipSuccess) return fail(TLXMI_ERR_LAUNCH, "block_seam: HIP launch failed: %s", hipGetErrorString(e));
+    return TLXMI_OK;
+}
+
+bool block_seam_shape_ok(int K1, int N1, int N2) {
+    if (N1 % 64 || N1 < 64 || N1 > 2048) return false;
+    return (K1 == 64 && (N2 == 64 || N2 == 128)) || (K1 == 128 && (N2 == 128 || N2 == 256));
+}
+
+int launch_block_seam(const SeamArgs& a0, int K1, int N2, hipStream_t st) {
+    const int vv = (int)tune_int("TLXMI_SEAM", 0);     // tuning flavour: bit 0 = the other workgroup shape, bit 1 / 2 = flip the t1 / y store policy (A/B)
+    const int v = vv & 1;
+    SeamArgs b = a0;
+    b.z_nt = (vv & 2) ? 1 : 0;        // t1 is small and read back at once by the next conv: a plain store keeps it in the Infinity Cache (-124 us per ResNet-50 forward vs nt)
+    b.y_nt = (vv & 4) ? 1 : 0;
+    const SeamArgs& a = b;
+    if (K1 == 64 && N2 == 64) return v ? launch_seam_t<64, 64, 2, 8>(a, st) : launch_seam_t<64, 64, 2, 4>(a, st);
+    if (K1 == 64 && N2 == 128) return v ? launch_seam_t<64, 128, 2, 8>(a, st) : launch_seam_t<64, 128, 2, 4>(a, st);
+    // (measured, batch 256: 56 x 56 seams 226 / 268 us with 4 waves vs 233 / 288 with 8; 28 x 28 seams 153 / 194 us with 8 waves
+    //  vs 185 / 266 with 4 — the 128-channel filters are 256 - 384 KB per pass and want more pixels per staging)
+    if (K1 == 128 && N2 == 128) return v ? launch_seam_t<128, 128, 2, 4>(a, st) : launch_seam_t<128, 128, 2, 8>(a, st);
+    if (K1 == 128 && N2 == 256) return v ? launch_seam_t<128, 256, 1, 4>(a, st) : launch_seam_t<128, 256, 1, 8>(a, st);
+    return fail(TLXMI_ERR_UNSUPPORTED, "block_seam: no instantiation for %d -> N1 -> %d channels", K1, N2);
+}
+
+}  // namespace tlxmi
+
+using namespace tlxmi;
+
+extern "C" int tlxmi_bottleneck_seam_supported(int dtype, int K1, int N1, int N2) {
+    return dtype == TLXMI_F16 && block_seam_shape_ok(K1, N1, N2) ? 1 : 0;
+}
+
+extern "C" int tlxmi_bottleneck_seam(const tlxmi_seam_desc* d, const void* t2, const void* w3_packed, const float* scale3,
+                                     const float* shift3, const void* skip, void* y, const void* w1_packed, const float* scale1,
+                                     const float* shift1, void* t1, void* stream) {
+    TLXMI_REQUIRE(d && t2 && w3_packed && skip && y && w1_packed && t1, TLXMI_ERR_BAD_ARG, "bottleneck_seam: null argument");
+    TLXMI_REQUIRE(d->dtype == TLXMI_F16, TLXMI_ERR_UNSUPPORTED, "bottleneck_seam: fp16 only (the fp32 parity mode runs the two convolutions)");
+    TLXMI_REQUIRE(d->rows > 0 && d->K1 > 0 && d->N1 > 0 && d->N2 > 0, TLXMI_ERR_BAD_ARG, "bottleneck_seam: bad extent");
+    if (!block_seam_shape_ok(d->K1, d->N1, d->N2))
+        return fail(TLXMI_ERR_UNSUPPORTED, "bottleneck_seam: no kernel for %d -> %d -> %d channels", d->K1, d->N1, d->N2);
+    TLXMI_REQUIRE(d->t2_ld >= d->K1 && d->skip_ld >= d->N1 && d->y_ld >= d->N1 && d->t1_ld >= d->N2, TLXMI_ERR_BAD_ARG, "bottleneck_seam: row stride below the channel count");
+    TLXMI_REQUIRE(d->t2_ld % 8 == 0 && d->skip_ld % 8 == 0 && d->y_ld % 8 == 0 && d->t1_ld % 8 == 0 && aligned16(t2) && aligned16(skip) && aligned16(y) &&
+                      aligned16(t1) && aligned16(w3_packed) && aligned16(w1_packed),
+                  TLXMI_ERR_ALIGNMENT, "bottleneck_seam: rows must be whole 16-byte chunks");
+    TLXMI_REQUIRE(d->act == TLXMI_ACT_RELU, TLXMI_ERR_UNSUPPORTED, "bottleneck_seam: ReLU after both convolutions only");
+    const long long rows = d->rows;
+    const long long big = (1ll << 31);
+    TLXMI_REQUIRE(rows * d->t2_ld * 2 < big && rows * d->skip_ld * 2 < big && rows * d->y_ld * 2 < big && rows * d->t1_ld * 2 < big && rows < big,
+                  TLXMI_ERR_UNSUPPORTED, "bottleneck_seam: a tensor exceeds the 2 GiB the 32-bit buffer offsets address");
+    SeamArgs a;
+    a.x = (const char*)t2; a.w3 = (const char*)w3_packed; a.res = (const char*)skip; a.w1 = (const char*)w1_packed;
+    a.y = (char*)y; a.z = (char*)t1;
+    a.scale3 = scale3; a.shift3 = shift3; a.scale1 = scale1; a.shift1 = shift1;
+    a.M = (int)rows; a.N1 = d->N1;
+    a.x_ld = d->t2_ld; a.res_ld = d->skip_ld; a.y_ld = d->y_ld; a.z_ld = d->t1_ld;
+    a.x_bytes = (unsigned)(rows * d->t2_ld * 2); a.res_bytes = (unsigned)(rows * d->skip_ld * 2);
+    a.y_bytes = (unsigned)(rows * d->y_ld * 2); a.z_bytes = (unsigned)(rows * d->t1_ld * 2);
+    // packed filters (tlxmi_pack_filter, 1x1): [Cout rounded up to 128][K] row-major; K1 and N1 are multiples of 64
+    a.w3_bytes = (unsigned)(((size_t)(d->N1 + 127) / 128 * 128) * (size_t)d->K1 * 2);
+    a.w1_bytes = (unsigned)(((size_t)(d->N2 + 127) / 128 * 128) * (size_t)d->N1 * 2);
+    const int rc = launch_block_seam(a, d->K1, d->N2, as_stream(stream));
+    if (rc != TLXMI_OK) return rc;
+    return check_launch("bottleneck_seam");
+}

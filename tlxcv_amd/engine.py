@@ -303,6 +303,37 @@ def conv2d(x, pk, stride=1, padding=0, dilation=1, scale=None, shift=None, res=N
     return out
 
 
+def bottleneck_seam_supported(K1, N1, N2, dtype):
+    return bool(_lib.load().tlxmi_bottleneck_seam_supported(dt_code(dtype), int(K1), int(N1), int(N2)))
+
+
+def bottleneck_seam(t2, pk3, scale3, shift3, skip, pk1, scale1, shift1):
+    """One launch for the seam between two bottleneck blocks (tlxmi_bottleneck_seam): y = relu(conv3(t2) * scale3 + shift3 +
+    skip); t1 = relu(conv1'(y) * scale1 + shift1).  t2 (N,H,W,K1), skip (N,H,W,N1) -> (y (N,H,W,N1), t1 (N,H,W,N2))."""
+    need_gpu(t2, "input")
+    N, H, W, ld = t2.shape
+    if skip.shape[:3] != t2.shape[:3] or skip.dtype != t2.dtype or not skip.is_contiguous() or not t2.is_contiguous():
+        raise RuntimeError("bottleneck_seam: t2 / skip must be dense NHWC maps of one dtype and extent")
+    y = torch.empty((N, H, W, pk3.Cout), dtype=t2.dtype, device=t2.device)
+    t1 = torch.empty((N, H, W, pk1.Cout), dtype=t2.dtype, device=t2.device)
+    rows = N * H * W
+    d = _lib.SeamDesc(dtype=dt_code(t2.dtype), rows=rows, K1=pk3.Cin, N1=pk3.Cout, N2=pk1.Cout, t2_ld=ld, skip_ld=skip.shape[-1],
+                      y_ld=pk3.Cout, t1_ld=pk1.Cout, act=ACT_RELU)
+    args = (C.byref(d), _p(t2), _p(pk3.buf), _p(scale3), _p(shift3), _p(skip), _p(y), _p(pk1.buf), _p(scale1), _p(shift1), _p(t1), _stream())
+    if _probe is None:
+        _lib.call("tlxmi_bottleneck_seam", *args)
+        return y, t1
+    es = t2.element_size()
+    alg_bytes = (rows * (pk3.Cin + 2 * pk3.Cout + pk1.Cout) + pk3.Cout * pk3.Cin + pk1.Cout * pk1.Cin) * es
+    flops = 2 * rows * (pk3.Cout * pk3.Cin + pk1.Cout * pk1.Cin)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    _lib.call("tlxmi_bottleneck_seam", *args)
+    e1.record()
+    _probe.append((e0, e1, alg_bytes, flops, (N, H, W, pk3.Cin, pk3.Cout, pk1.Cout, "seam", True)))
+    return y, t1
+
+
 def group_conv2d(x, pk, stride=1, padding=0, dilation=1, scale=None, shift=None, res=None, act=ACT_NONE,
                  act_param=0.0, res_after_act=False):
     """Grouped convolution (+ folded BatchNorm / bias, activation, residual): x (N,H,W,Cin) NHWC with exactly the

@@ -8,6 +8,8 @@ conv+BN(+ReLU)(+residual) is ONE implicit-GEMM launch with the folded BatchNorm,
 connection and the activation in its epilogue, tensors stay NHWC from the stem to the pool, and
 the classifier is the same GEMM kernel with the bias as epilogue shift.
 """
+import torch
+
 from ... import engine as E
 from ...tlx import nn
 from ...tlx import FlattenReshape
@@ -88,6 +90,49 @@ class BottleneckBlock(nn.Module):
     def forward(self, x):
         return from_nhwc(self.forward_nhwc(as_nhwc(x, self.data_format)), self.data_format)
 
+    # -- the same block cut at the seams the engine fuses: run_head() = conv1 -> conv2 (+ projection shortcut) gives what
+    #    conv3 needs; the caller then runs conv3 + skip + relu either alone (finish) or in ONE launch together with the
+    #    next block's conv1 (E.bottleneck_seam): the wide map between two blocks is written once and not re-read.
+    def run_head(self, v, t1=None):
+        """v: the block's input; t1: relu(bn1(conv1(v))) if the previous seam launch already computed it."""
+        out = t1 if t1 is not None else self.conv1.run_nhwc(v, self.bn1, E.ACT_RELU)
+        out = self.conv2.run_nhwc(out, self.bn2, E.ACT_RELU)
+        identity = v if self.downsample is None else self.downsample[0].run_nhwc(v, self.downsample[1])
+        return out, identity
+
+    def finish(self, out, identity):
+        return self.conv3.run_nhwc(out, self.bn3, E.ACT_RELU, res=identity)
+
+    def seam_with(self, nxt, out, identity):
+        """(block output, nxt's conv1 output) in one launch, or None when there is no fused kernel for these layers."""
+        c3, c1 = self.conv3, nxt.conv1
+        dt = E.precision()
+        if (dt != torch.float16 or c3.n_group != 1 or c1.n_group != 1 or c1.kernel_size != (1, 1) or c1.stride != (1, 1)
+                or c1.padding != (0, 0) or c3.biases is not None or c1.biases is not None
+                or not E.bottleneck_seam_supported(c3.in_channels, c3.out_channels, c1.out_channels, dt)):
+            return None
+        pk3 = c3._cached("pk", lambda: E.PackedFilter(c3.filters, dt))
+        pk1 = c1._cached("pk", lambda: E.PackedFilter(c1.filters, dt))
+        s3, h3 = c3._cached(("bn", id(self.bn3)), lambda: self.bn3.folded(None), deps=(self.bn3,))
+        s1, h1 = c1._cached(("bn", id(nxt.bn1)), lambda: nxt.bn1.folded(None), deps=(nxt.bn1,))
+        return E.bottleneck_seam(out, pk3, s3, h3, identity, pk1, s1, h1)
+
+
+def run_bottleneck_chain(blocks, v):
+    """A run of BottleneckBlocks (all stages of a ResNet in order) with every block-to-block seam fused where the library has the
+    kernel (fp16; resnet.py:142-156 per block).  Falls back block by block to conv3 + skip as its own launch."""
+    t1 = None
+    for i, blk in enumerate(blocks):
+        out, identity = blk.run_head(v, t1)
+        t1 = None
+        nxt = blocks[i + 1] if i + 1 < len(blocks) else None
+        fused = blk.seam_with(nxt, out, identity) if isinstance(nxt, BottleneckBlock) else None
+        if fused is not None:
+            v, t1 = fused
+        else:
+            v = blk.finish(out, identity)
+    return v
+
 
 class ResNet(nn.Module):
     """resnet.py:159-300."""
@@ -145,8 +190,11 @@ class ResNet(nn.Module):
             v = self.conv1.run_stem(x, 2, self.bn1, E.ACT_RELU, maxpool=self.maxpool)
         else:
             v = self.maxpool.run_nhwc(self.conv1.run_nhwc(as_nhwc(x, self.data_format), self.bn1, E.ACT_RELU))   # :287-290
-        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
-            for blk in layer:
+        blocks = [blk for layer in (self.layer1, self.layer2, self.layer3, self.layer4) for blk in layer]
+        if all(isinstance(b, BottleneckBlock) for b in blocks):
+            v = run_bottleneck_chain(blocks, v)                # seams between blocks fused (fp16)
+        else:
+            for blk in blocks:
                 v = blk.forward_nhwc(v)
         if self.with_pool:
             v = E.global_avgpool(v)                            # (N, C)   :295-296

@@ -1,0 +1,43 @@
+"""Interleaved A/B per ResNet-50 stage, batch 256: the bottleneck seam as one launch vs conv3 + skip and conv1 as two."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import tlxcv_amd
+from tlxcv_amd import _lib
+_lib.tuning().__enter__()
+from tlxcv_amd import engine as E
+
+dev = torch.device("cuda:0")
+tlxcv_amd.set_precision("fp16")
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+for K1, N1, N2, hw in ((64, 256, 64, 56), (64, 256, 128, 56), (128, 512, 128, 28), (128, 512, 256, 28)):
+    g = torch.Generator().manual_seed(1)
+    t2 = torch.randn((B, hw, hw, K1), generator=g).half().to(dev)
+    skip = torch.randn((B, hw, hw, N1), generator=g).half().to(dev)
+    pk3 = E.PackedFilter((torch.randn((N1, K1, 1, 1), generator=g) * (2 / K1) ** 0.5).to(dev), torch.float16)
+    pk1 = E.PackedFilter((torch.randn((N2, N1, 1, 1), generator=g) * (2 / N1) ** 0.5).to(dev), torch.float16)
+    s3, h3, s1, h1 = (torch.rand(n, generator=g).to(dev) for n in (N1, N1, N2, N2))
+
+    def run(f):
+        if f:
+            return E.bottleneck_seam(t2, pk3, s3, h3, skip, pk1, s1, h1)
+        y = E.conv2d(t2, pk3, 1, 0, 1, s3, h3, skip, E.ACT_RELU)
+        return y, E.conv2d(y, pk1, 1, 0, 1, s1, h1, None, E.ACT_RELU)
+    for f in (0, 1):
+        run(f)
+    torch.cuda.synchronize()
+    res = {0: [], 1: []}
+    for r in range(8):
+        for f in (0, 1):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                run(f)
+            e1.record()
+            torch.cuda.synchronize()
+            res[f].append(e0.elapsed_time(e1) / 5 * 1e3)
+    m = B * hw * hw
+    fb = m * (K1 + 2 * N1 + N2) * 2
+    v0, v1 = sorted(res[0]), sorted(res[1])
+    print(f"{K1:4d} -> {N1:4d} -> {N2:4d} @ {hw}x{hw}: two launches {v0[len(v0)//2]:7.1f} us   fused {v1[len(v1)//2]:7.1f} us "
+          f"({fb / v1[len(v1)//2] / 1e6:.2f} TB/s of {fb / 1e6:.0f} MB)")
