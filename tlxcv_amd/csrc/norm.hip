@@ -34,7 +34,10 @@ __device__ __forceinline__ long win_row(const WinMap& wm, long r) {
     return (b * nW + wh * nWw + ww) * (long)(wm.ws * wm.ws) + (h - wh * wm.ws) * wm.ws + (w - ww * wm.ws);
 }
 
-template <typename T, int NCH, int RW, int LPR>
+// PERSIST: the grid is a few workgroups per CU and a lane group walks its row groups with the NEXT group's loads in
+// flight while it reduces / normalises / stores the current one (two register buffers).  One-shot workgroups serialise
+// load latency -> arithmetic -> store per wave and pay a workgroup launch per 32 rows: 3.2 TB/s on ViT's 50432 x 768;
+template <typename T, int NCH, int RW, int LPR, bool PERSIST, bool HASRES>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, T* __restrict__ y, long rows,
                                                         int C, int x_ld, int y_ld, float eps, float* __restrict__ stats,
@@ -42,33 +45,51 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
     constexpr int V = 16 / (int)sizeof(T);
     constexpr int GPW = 64 / LPR;                    // row groups per wave
     const int lane = threadIdx.x & (LPR - 1);
-    const long row0 = (((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * GPW + ((threadIdx.x & 63) / LPR)) * RW;
+    const long gstride = (long)gridDim.x * 4 * GPW * RW;       // rows between two groups of this lane group (PERSIST)
+    long row0 = (((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * GPW + ((threadIdx.x & 63) / LPR)) * RW;
     if (row0 >= rows) return;
     const int nch = C / V;
-    // all RW x NCH 16-byte loads of this wave are issued before the first reduction: the kernel is a
-    // pure HBM stream and needs the bytes in flight, not the arithmetic
-    u32x4 raw[RW][NCH];
-    long wrow[RW];      // window row of image row row0 + r (modes 1, 2)
+    // gamma / beta of this lane's channels: once per wave, not once per row
+    float gm[NCH][V], bt[NCH][V];
 #pragma unroll
-    for (int r = 0; r < RW; ++r) {
-        wrow[r] = (wm.mode != 0 && row0 + r < rows) ? win_row(wm, row0 + r) : 0;
-        const long srow = wm.mode == 2 ? wrow[r] : row0 + r;
+    for (int i = 0; i < NCH; ++i) {
+        const int ch = lane + LPR * i;
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int ch = lane + LPR * i;
-            raw[r][i] = u32x4{0u, 0u, 0u, 0u};
-            if (ch < nch && row0 + r < rows)
-                raw[r][i] = *reinterpret_cast<const u32x4*>(x + srow * x_ld + ch * V);
+        for (int e = 0; e < V; ++e) {
+            const int c = ch < nch ? ch * V + e : 0;
+            gm[i][e] = gamma ? gamma[c] : 1.f;
+            bt[i][e] = beta ? beta[c] : 0.f;
         }
     }
-    if (wm.mode == 2) {   // + residual (image order), rounded to T as the two-kernel path stores it, written out
+    // all RW x NCH 16-byte loads of a group are issued before the first reduction: the kernel is a
+    // pure HBM stream and needs the bytes in flight, not the arithmetic
+    constexpr int RR = HASRES ? RW : 1, RN = HASRES ? NCH : 1;     // the residual buffers exist only in mode 2
+    auto load_group = [&](long r0, u32x4 (&raw)[RW][NCH], u32x4 (&rsd)[RR][RN], long (&wrow)[RW]) {
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            wrow[r] = (wm.mode != 0 && r0 + r < rows) ? win_row(wm, r0 + r) : 0;
+            const long srow = wm.mode == 2 ? wrow[r] : r0 + r;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int ch = lane + LPR * i;
+                raw[r][i] = u32x4{0u, 0u, 0u, 0u};
+                if constexpr (HASRES) rsd[r][i] = u32x4{0u, 0u, 0u, 0u};
+                if (ch < nch && r0 + r < rows) {
+                    raw[r][i] = *reinterpret_cast<const u32x4*>(x + srow * x_ld + ch * V);
+                    if constexpr (HASRES) rsd[r][i] = *reinterpret_cast<const u32x4*>(res + (r0 + r) * x_ld + ch * V);
+                }
+            }
+        }
+    };
+    auto process = [&](long row0, u32x4 (&raw)[RW][NCH], const u32x4 (&rsd)[RR][RN], const long (&wrow)[RW]) {
+    if constexpr (HASRES) {   // + residual (image order), rounded to T as the two-kernel path stores it, written out
 #pragma unroll
         for (int r = 0; r < RW; ++r)
 #pragma unroll
             for (int i = 0; i < NCH; ++i) {
                 const int ch = lane + LPR * i;
                 if (ch < nch && row0 + r < rows) {
-                    const u32x4 rv = *reinterpret_cast<const u32x4*>(res + (row0 + r) * x_ld + ch * V);
+                    const u32x4 rv = rsd[r][i];
                     if constexpr (sizeof(T) == 2) {
                         const half8v a = __builtin_bit_cast(half8v, raw[r][i]), b = __builtin_bit_cast(half8v, rv);
                         half8v o;
@@ -81,18 +102,6 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
                     *reinterpret_cast<u32x4*>(sum_out + (row0 + r) * x_ld + ch * V) = raw[r][i];
                 }
             }
-    }
-    // gamma / beta of this lane's channels: once per wave, not once per row
-    float gm[NCH][V], bt[NCH][V];
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        const int ch = lane + LPR * i;
-#pragma unroll
-        for (int e = 0; e < V; ++e) {
-            const int c = ch < nch ? ch * V + e : 0;
-            gm[i][e] = gamma ? gamma[c] : 1.f;
-            bt[i][e] = beta ? beta[c] : 0.f;
-        }
     }
     // three phases over all RW rows at once (the RW reduction chains are independent, so their cross-lane
     // latencies overlap): sums -> means, centred squares -> rstd, normalise + store
@@ -174,6 +183,61 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
             }
         }
     }
+    };
+    u32x4 rawA[RW][NCH], rsdA[RR][RN];
+    long wrowA[RW];
+    load_group(row0, rawA, rsdA, wrowA);
+    if constexpr (!PERSIST) {
+        process(row0, rawA, rsdA, wrowA);
+    } else {
+        u32x4 rawB[RW][NCH], rsdB[RR][RN];
+        long wrowB[RW];
+        while (true) {      // two groups per trip so that both buffers keep static names (no runtime-indexed registers)
+            const long r1 = row0 + gstride;
+            if (r1 < rows) load_group(r1, rawB, rsdB, wrowB);
+            process(row0, rawA, rsdA, wrowA);
+            if (r1 >= rows) break;
+            row0 = r1 + gstride;
+            if (row0 < rows) load_group(row0, rawA, rsdA, wrowA);
+            process(r1, rawB, rsdB, wrowB);
+            if (row0 >= rows) break;
+        }
+    }
+}
+
+static int ln_cus() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+// One instantiation: one-shot workgroups (a row group each), or a persistent grid of as many workgroups as are resident
+// (occupancy query, once per instantiation) walking the row groups.
+template <typename T, int NCH, int RW, int LPR, bool PERSIST, bool HASRES>
+static void launch_ln_case(const void* x, const float* gamma, const float* beta, void* y, long rows, int C, int x_ld, int y_ld,
+                           float eps, hipStream_t st, float* stats, const WinMap& wm, const void* res, void* sum_out) {
+    auto* kern = &layernorm_kernel<T, NCH, RW, LPR, PERSIST, HASRES>;
+    long grid = (rows + 4 * RW * (64 / LPR) - 1) / (4 * RW * (64 / LPR));
+    if (PERSIST) {
+        static int per_cu = 0;
+        if (per_cu == 0) {
+            int nb = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), 256, 0) != hipSuccess || nb < 1) {
+                (void)hipGetLastError();
+                nb = 2;
+            }
+            per_cu = nb > 8 ? 8 : nb;
+        }
+        const long cap = (long)ln_cus() * per_cu;
+        if (grid > 2 * cap) grid = cap;      // few row groups: one each (no two-trip tail)
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), 0, st, (const T*)x, gamma, beta, (T*)y, rows, C, x_ld, y_ld, eps,
+                       stats, wm, (const T*)res, (T*)sum_out);
 }
 
 template <typename T>
@@ -182,17 +246,21 @@ static int launch_ln(const void* x, const float* gamma, const float* beta, void*
                      const void* res = nullptr, void* sum_out = nullptr) {
     constexpr int V = 16 / (int)sizeof(T);
     const int nch = C / V;
-#define LN_CASE(n, rw, lpr)                                                                                       \
-    hipLaunchKernelGGL((layernorm_kernel<T, n, rw, lpr>),                                                         \
-                       dim3((unsigned)((rows + 4 * rw * (64 / lpr) - 1) / (4 * rw * (64 / lpr)))), dim3(256), 0, st, \
-                       (const T*)x, gamma, beta, (T*)y, rows, C, x_ld, y_ld, eps, stats, wm, (const T*)res, (T*)sum_out)
-    if (nch <= 16) LN_CASE(1, 4, 16);
-    else if (nch <= 32) LN_CASE(1, 4, 32);
-    else if (nch <= 64) LN_CASE(1, 8, 64);
-    else if (nch <= 128) LN_CASE(2, 8, 64);
-    else if (nch <= 256) LN_CASE(4, 2, 64);
-    else if (nch <= 512) LN_CASE(8, 1, 64);
-    else if (nch <= 1024) LN_CASE(16, 1, 64);
+    // tuning flavour: TLXMI_LN=1 keeps the one-shot workgroups of round 1 (A/B)
+    const bool oneshot = tune_int("TLXMI_LN", 0) == 1;
+#define LN_CASE(n, rw, lpr, pers)                                                                                              \
+    {                                                                                                                          \
+        if (res) launch_ln_case<T, n, rw, lpr, pers, true>(x, gamma, beta, y, rows, C, x_ld, y_ld, eps, st, stats, wm, res, sum_out); \
+        else launch_ln_case<T, n, rw, lpr, pers, false>(x, gamma, beta, y, rows, C, x_ld, y_ld, eps, st, stats, wm, res, sum_out);   \
+    }
+    // persistent shapes: half the rows per lane group of the one-shot form (the second register buffer holds the next group)
+    if (nch <= 16) { if (oneshot) LN_CASE(1, 4, 16, false) else LN_CASE(1, 2, 16, true) }
+    else if (nch <= 32) { if (oneshot) LN_CASE(1, 4, 32, false) else LN_CASE(1, 2, 32, true) }
+    else if (nch <= 64) { if (oneshot) LN_CASE(1, 8, 64, false) else LN_CASE(1, 4, 64, true) }
+    else if (nch <= 128) { if (oneshot) LN_CASE(2, 8, 64, false) else LN_CASE(2, 2, 64, true) }      // ViT-B (96): 45 -> 35 us on 50432 rows
+    else if (nch <= 256) LN_CASE(4, 2, 64, false)
+    else if (nch <= 512) LN_CASE(8, 1, 64, false)
+    else if (nch <= 1024) LN_CASE(16, 1, 64, false)
     else return fail(TLXMI_ERR_UNSUPPORTED, "layernorm: C=%d too wide for the in-register row kernel", C);
 #undef LN_CASE
     return check_launch("layernorm");
