@@ -147,6 +147,33 @@ int tlxmi_conv2d(const tlxmi_conv2d_desc* d, const void* x, const void* w_packed
 int tlxmi_conv2d_maxpool_supported(const tlxmi_conv2d_desc* d);
 
 /* ------------------------------------------------------------------------------------------
+ * Image pre-processing on the device (the host pipeline of demo/image_classification/predict.py:22-29,
+ * Compose([Resize((h, w)), Normalize(mean, std), ToTensor(data_format)])): uint8 HWC images in, network input out.
+ *   images:  [N][H][W][C] uint8, C <= 4
+ *   xbounds / xk, ybounds / yk: the resampler tables of the two passes — bounds[o] = (first input sample, count),
+ *            k[o][t] integer weights with 22 fractional bits, row pitch kw / kh — built by the caller exactly as Pillow's
+ *            ImagingResample does (tlxcv_amd/tlx/vision/transforms/resample.py), which makes the result bit-identical to
+ *            PIL.Image.resize on the host; an axis that keeps its size passes the identity table (count 1, weight 1 << 22)
+ *   mean / std: [C] fp32 when `normalize`, else the value is scaled by 1/255 (ToTensor on uint8)
+ *   workspace: tlxmi_preprocess_u8_workspace_bytes(d) bytes (the uint8 image after the horizontal pass)
+ *   out:     layout 0 [N][C][out_h][out_w] ("CHW"), 1 [N][out_h][out_w][C] ("HWC"), 2 the fold_b x fold_b space-to-depth
+ *            NHWC image of tlxmi_nchw_to_nhwc_s2d ([N][out_h/b][out_w/b][cpad], channel (ph*b + pw)*C + c, zero padded)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct tlxmi_preproc_desc {
+    int32_t N, H, W, C;
+    int32_t out_h, out_w;
+    int32_t kh, kw;
+    int32_t out_dtype;
+    int32_t layout;
+    int32_t fold_b, cpad;
+    int32_t normalize;
+} tlxmi_preproc_desc;
+size_t tlxmi_preprocess_u8_workspace_bytes(const tlxmi_preproc_desc* d);
+int tlxmi_preprocess_u8(const tlxmi_preproc_desc* d, const void* images, const int32_t* xbounds, const int32_t* xk,
+                        const int32_t* ybounds, const int32_t* yk, const float* mean, const float* std_, void* workspace,
+                        void* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * The seam between two ResNet bottleneck blocks in one launch (resnet.py:142-156 of block b, :143-145 of block b + 1):
  *     y  = relu( (t2 . W3^T) * scale3 + shift3 + skip )      conv3 + bn3 + residual add + relu of block b
  *     t1 = relu( (y  . W1^T) * scale1 + shift1 )             conv1 + bn1 + relu of block b + 1

@@ -46,6 +46,11 @@ class SeamDesc(C.Structure):
         "K1", "N1", "N2", "t2_ld", "skip_ld", "y_ld", "t1_ld", "act")]
 
 
+class PreprocDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("N", "H", "W", "C", "out_h", "out_w", "kh", "kw", "out_dtype", "layout", "fold_b",
+                                         "cpad", "normalize")]
+
+
 _vp, _i, _f, _u, _l = C.c_void_p, C.c_int, C.c_float, C.c_uint32, C.c_int64
 
 # name -> argtypes; every function returns int status unless listed in _SPECIAL
@@ -57,6 +62,7 @@ PROTOTYPES = {
     "tlxmi_fold_bn": [_vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp],
     "tlxmi_conv2d": [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "tlxmi_bottleneck_seam": [C.POINTER(SeamDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "tlxmi_preprocess_u8": [C.POINTER(PreprocDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "tlxmi_linear_splitk": [_i, _l, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _u, _vp, _i, _vp],
     "tlxmi_group_conv2d": [C.POINTER(ConvDesc), _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "tlxmi_pack_group_filter": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
@@ -92,6 +98,7 @@ _SPECIAL = {
     "tlxmi_packed_group_filter_bytes": ([_i, _i, _i, _i, _i, _i], C.c_size_t),
     "tlxmi_group_conv_chunks": ([_i, _i, _i, _i], C.c_int),
     "tlxmi_conv2d_maxpool_supported": ([C.POINTER(ConvDesc)], C.c_int),
+    "tlxmi_preprocess_u8_workspace_bytes": ([C.POINTER(PreprocDesc)], C.c_size_t),
     "tlxmi_bottleneck_seam_supported": ([_i, _i, _i, _i], C.c_int),
 }
 ALL_SYMBOLS = sorted(list(PROTOTYPES) + list(_SPECIAL))

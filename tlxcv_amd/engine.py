@@ -149,6 +149,58 @@ def nchw_to_nhwc_s2d(x, b, dtype=None):
     return y
 
 
+_resample_tables = {}
+
+
+def _resample_table(n_in, n_out, interpolation, device):
+    key = (n_in, n_out, interpolation, str(device))
+    if key not in _resample_tables:
+        import numpy as np
+        from .tlx.vision.transforms import resample
+        if n_in == n_out:       # PIL skips the pass: identity table
+            b = np.stack([np.arange(n_out, dtype=np.int32), np.ones(n_out, dtype=np.int32)], 1)
+            k = np.full((n_out, 1), 1 << resample.PRECISION_BITS, dtype=np.int32)
+        else:
+            b, k = resample.coefficients(n_in, n_out, interpolation)
+        _resample_tables[key] = (torch.from_numpy(np.ascontiguousarray(b)).to(device), torch.from_numpy(np.ascontiguousarray(k)).to(device), k.shape[1])
+    return _resample_tables[key]
+
+
+def preprocess_u8(images, size, mean=None, std=None, layout="CHW", dtype=torch.float32, interpolation="bilinear", fold=0):
+    """uint8 HWC images (N,H,W,C) on the device -> Resize(size) -> Normalize(mean, std) (or /255 without) -> ToTensor,
+    one call (tlxmi_preprocess_u8), bit-identical to the host pipeline of tlx.vision.transforms.  layout 'CHW' -> (N,C,h,w),
+    'HWC' -> (N,h,w,C); fold=b -> the b x b space-to-depth NHWC image the stem kernels read ((N,h/b,w/b,pad(b*b*C)))."""
+    need_gpu(images, "images")
+    if images.dtype != torch.uint8 or images.dim() != 4:
+        raise RuntimeError("preprocess_u8: a (N, H, W, C) uint8 tensor is expected")
+    images = images.contiguous()
+    N, H, W, Cc = images.shape
+    oh, ow = (size, size) if isinstance(size, int) else (int(size[0]), int(size[1]))
+    xb, xk, kw = _resample_table(W, ow, interpolation, images.device)
+    yb, yk, kh = _resample_table(H, oh, interpolation, images.device)
+    norm = mean is not None
+    m = torch.as_tensor(mean, dtype=torch.float32).reshape(-1).to(images.device).contiguous() if norm else None
+    sd = torch.as_tensor(std, dtype=torch.float32).reshape(-1).to(images.device).contiguous() if norm else None
+    if norm and (m.numel() != Cc or sd.numel() != Cc):
+        raise RuntimeError(f"preprocess_u8: mean / std must have {Cc} entries")
+    if fold:
+        v = vec(dtype)
+        cpad = (fold * fold * Cc + v - 1) // v * v
+        out = torch.empty((N, oh // fold, ow // fold, cpad), dtype=dtype, device=images.device)
+        lay = 2
+    elif layout == "CHW":
+        out, lay, cpad = torch.empty((N, Cc, oh, ow), dtype=dtype, device=images.device), 0, 0
+    elif layout == "HWC":
+        out, lay, cpad = torch.empty((N, oh, ow, Cc), dtype=dtype, device=images.device), 1, 0
+    else:
+        raise ValueError("layout should be CHW or HWC")
+    d = _lib.PreprocDesc(N=N, H=H, W=W, C=Cc, out_h=oh, out_w=ow, kh=kh, kw=kw, out_dtype=dt_code(dtype), layout=lay, fold_b=int(fold),
+                         cpad=cpad, normalize=1 if norm else 0)
+    ws = torch.empty(_lib.load().tlxmi_preprocess_u8_workspace_bytes(C.byref(d)), dtype=torch.uint8, device=images.device)
+    _lib.call("tlxmi_preprocess_u8", C.byref(d), _p(images), _p(xb), _p(xk), _p(yb), _p(yk), _p(m), _p(sd), _p(ws), _p(out), _stream())
+    return out
+
+
 def s2d_filter(w_oihw, b, pad):
     """Re-index an OIHW filter for a b x b space-to-depth input (host side, once):
     W2[o][(ph*b+pw)*C + c][r2][s2] = W[o][c][b*r2 + ph - off][b*s2 + pw - off], zero outside;

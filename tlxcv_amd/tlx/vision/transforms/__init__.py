@@ -15,10 +15,44 @@ __all__ = ["Compose", "Resize", "Normalize", "ToTensor", "CentralCrop", "HWC2CHW
 
 
 class Compose:
+    """Compose([Resize, Normalize, ToTensor]) — the pipeline of every inference demo (predict.py:22-28) — runs as ONE device
+    launch when a GPU is present (uint8 image up, tlxmi_preprocess_u8: Pillow's resampler restated in integer arithmetic,
+    so the tensor is bit-identical to what the host transforms below produce); any other composition, or no GPU, runs
+    the host transforms one by one.  `batch(images)` does a whole (N, H, W, C) uint8 batch in one launch."""
+
     def __init__(self, transforms):
         self.transforms = list(transforms)
 
+    def _device_plan(self):
+        ts = self.transforms
+        if len(ts) == 3 and isinstance(ts[0], Resize) and isinstance(ts[1], Normalize) and isinstance(ts[2], ToTensor):
+            return ts[0], ts[1], ts[2]
+        if len(ts) == 2 and isinstance(ts[0], Resize) and isinstance(ts[1], ToTensor):
+            return ts[0], None, ts[1]
+        return None
+
+    def batch(self, images, dtype=torch.float32, fold=0):
+        """(N, H, W, C) uint8 (numpy, or a torch tensor on host or device) -> the batch tensor, on the device."""
+        from .... import engine as E
+        plan = self._device_plan()
+        if plan is None:
+            raise NotImplementedError("Compose.batch: only [Resize, Normalize, ToTensor] / [Resize, ToTensor] run on the device")
+        rs, nm, tt = plan
+        if isinstance(images, torch.Tensor):
+            t = images
+        else:
+            arr = np.ascontiguousarray(images)
+            t = torch.from_numpy(arr if arr.flags.writeable else arr.copy())
+        if t.dim() == 3:
+            t = t.unsqueeze(0)
+        return E.preprocess_u8(t.cuda(), rs.size, None if nm is None else nm.mean, None if nm is None else nm.std,
+                               layout=tt.data_format, dtype=dtype, interpolation=rs.interpolation, fold=fold)
+
     def __call__(self, data):
+        a = data if isinstance(data, np.ndarray) else None
+        if (a is not None and a.dtype == np.uint8 and a.ndim == 3 and a.shape[-1] in (1, 3, 4) and torch.cuda.is_available()
+                and self._device_plan() is not None and self.transforms[0].interpolation in ("bilinear", "bicubic")):
+            return self.batch(a)[0]
         for t in self.transforms:
             data = t(data)
         return data
