@@ -147,6 +147,24 @@ int tlxmi_conv2d(const tlxmi_conv2d_desc* d, const void* x, const void* w_packed
 int tlxmi_conv2d_maxpool_supported(const tlxmi_conv2d_desc* d);
 
 /* ------------------------------------------------------------------------------------------
+ * YOLOv3 post-processing (tlxcv/models/detection/yolov3.py:541-579, utils/ops.py:255-329).
+ * tlxmi_yolo_box: one head map x ([N][A*(5+C)][H][W], or [N][H][W][A*(5+C)] with channels_last) -> boxes
+ *   [N][Mtot][4] (x1, y1, x2, y2 in image pixels) and scores [N][Mtot][C] fp32, written at box offset m_offset ..
+ *   m_offset + A*H*W (the heads of one image append).  img_size [N][2] = (height, width) int32; anchors [A][2].
+ *   The published algorithm of Paddle's yolo_box (the op the reference calls and only has on the Paddle backend).
+ * tlxmi_multiclass_nms: tlx_multiclass_nms — best class per box, score >= score_threshold, class-aware greedy NMS
+ *   (IoU > nms_threshold, descending score), the first keep_top_k survivors as rows (class, score, x1, y1, x2, y2) of
+ *   detections [N][keep_top_k][6] (zero filled), counts [N].  M <= 65536 boxes per image; workspace:
+ *   tlxmi_multiclass_nms_workspace_bytes(N, M).
+ * ---------------------------------------------------------------------------------------- */
+int tlxmi_yolo_box(const void* x, int dtype, int N, int A, int C, int H, int W, int channels_last, const int32_t* img_size,
+                   const float* anchors, float conf_thresh, int downsample_ratio, int clip_bbox, float scale_x_y,
+                   float* boxes, float* scores, int Mtot, int m_offset, void* stream);
+size_t tlxmi_multiclass_nms_workspace_bytes(int N, int M);
+int tlxmi_multiclass_nms(const float* boxes, const float* scores, int N, int M, int C, float score_threshold, float nms_threshold,
+                         int keep_top_k, void* workspace, float* detections, int32_t* counts, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Image pre-processing on the device (the host pipeline of demo/image_classification/predict.py:22-29,
  * Compose([Resize((h, w)), Normalize(mean, std), ToTensor(data_format)])): uint8 HWC images in, network input out.
  *   images:  [N][H][W][C] uint8, C <= 4

@@ -380,6 +380,47 @@ def gen_paddle_converted(relpath, ctor_name, fn, batch, wseed, xseed, fname, hw=
         param_names=np.array(list(shapes.keys())), torch_version=torch.__version__)
 
 
+def gen_yolo_post(fname):
+    """YOLOv3 post-processing (SURVEY 8f rank 3) on the yolov3_b1 case: head maps from the reference's own model object;
+    decode = oracle/detection.py's restatement of Paddle's yolo_box (UNPINNED: the op exists on the Paddle backend only);
+    NMS = the reference's OWN tlx_multiclass_nms (detection/utils/ops.py:255-329, torchvision.ops from oracle/shims) run on
+    those boxes, and required to equal the restatement.  Plus a denser synthetic NMS case (overlapping boxes, 7 classes)."""
+    from oracle import detection as OD
+    ref = import_reference("tlxcv/models/detection/yolov3.py", "ref_yolov3_post", package=("refdet", "tlxcv/models/detection"))
+    ref_nms = ref.cvt_results.__globals__["tlx_multiclass_nms"]
+    g = np.load(os.path.join(OUT, "yolov3_b1.npz"))
+    heads = [torch.from_numpy(g[f"head{i}"]) for i in range(3)]
+    model = ref.YOLOv3()
+    anchors = model.yolo_head.mask_anchors
+    hw = int(g["hw"])
+    im_shape = torch.tensor([[hw, hw]], dtype=torch.float32)
+    boxes, scores = OD.yolo_decode(heads, anchors, 92, im_shape, torch.ones_like(im_shape), conf_thresh=0.005, downsample_ratio=32)
+    sys.path.insert(0, SHIMS)
+    try:
+        out = {}
+        for tag, b, s_, thr in (("yolo", boxes, scores, 0.01), ("dense", None, None, 0.3)):
+            if b is None:
+                rng = np.random.default_rng(50)
+                ctr, wh = rng.uniform(0, 200, (2, 600, 2)), rng.uniform(5, 60, (2, 600, 2))
+                b = torch.from_numpy(np.concatenate([ctr - wh / 2, ctr + wh / 2], -1).astype(np.float32))
+                s_ = torch.from_numpy((rng.random((2, 600, 7)) ** 3).astype(np.float32))
+            det_ref = ref_nms(b, s_, score_threshold=thr, nms_threshold=0.5, keep_top_k=100)
+            det_re = OD.multiclass_nms(b, s_, thr, 0.5, 100)
+            for x, y in zip(det_ref, det_re):
+                assert (x is None) == (y is None) and (x is None or torch.equal(x, y)), "NMS restatement disagrees with tlx_multiclass_nms"
+            out[f"{tag}_boxes"], out[f"{tag}_scores"] = b.numpy(), s_.numpy()
+            out[f"{tag}_counts"] = np.array([0 if d is None else d.shape[0] for d in det_ref], dtype=np.int32)
+            out[f"{tag}_det"] = np.concatenate([np.zeros((0, 6), np.float32)] + [d.numpy() for d in det_ref if d is not None])
+            out[f"{tag}_thr"] = np.float32(thr)
+            print(f"[yolo post {tag}] {b.shape[1]} boxes -> detections per image {out[f'{tag}_counts'].tolist()}")
+    finally:
+        sys.path.remove(SHIMS)
+    np.savez_compressed(os.path.join(OUT, fname), anchors=np.array(anchors, dtype=np.float32), hw=hw,
+                        pinned_by="reference-file-on-tlx_cpu (NMS: the reference's tlx_multiclass_nms with torchvision.ops from oracle/shims; "
+                                  "box decode: restatement of paddle.vision.ops.yolo_box, UNPINNED — Paddle-only in the reference)",
+                        restatement_max_abs_diff=np.float64(0.0), **out)
+
+
 def gen_tlx_npz(fname):
     """SURVEY 8f rank 1 — checkpoint interchange.  Two small instances of the reference's own classes (its
     VisionTransformer at 32 x 32 / width 32 / depth 2, its MobileNetV1 at scale 0.125, 10 classes) are filled from the
@@ -463,6 +504,7 @@ def main(only=()):
     job(gen_mobilenet_det, 1, 128, 23, 17, "mobilenet_det_b1.npz")
     job(gen_tlx_npz, "tlx_npz_small.npz")
     job(gen_detr_mha, "detr_mha.npz")
+    job(gen_yolo_post, "yolov3_post_b1.npz")
     for fn, args, kw in jobs:
         fn(*args, **kw)
 

@@ -117,6 +117,18 @@ def reduce_mean(input_tensor, axis=None, keepdims=False):
     return torch.mean(input_tensor) if axis is None else torch.mean(input_tensor, dim=axis, keepdim=keepdims)
 
 
+def reduce_max(input_tensor, axis=None, keepdims=False):
+    return torch.max(input_tensor) if axis is None else torch.max(input_tensor, dim=axis, keepdim=keepdims).values
+
+
+def squeeze(input, axis=None):
+    return input.squeeze() if axis is None else input.squeeze(axis)
+
+
+def argsort(values, axis=-1, descending=False):
+    return torch.argsort(values, dim=axis, descending=descending, stable=True)
+
+
 def argmax(x, axis=None, dtype="int64"):
     return torch.argmax(x, dim=axis)
 

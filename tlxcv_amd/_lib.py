@@ -63,6 +63,8 @@ PROTOTYPES = {
     "tlxmi_conv2d": [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "tlxmi_bottleneck_seam": [C.POINTER(SeamDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "tlxmi_preprocess_u8": [C.POINTER(PreprocDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "tlxmi_yolo_box": [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _f, _i, _i, _f, _vp, _vp, _i, _i, _vp],
+    "tlxmi_multiclass_nms": [_vp, _vp, _i, _i, _i, _f, _f, _i, _vp, _vp, _vp, _vp],
     "tlxmi_linear_splitk": [_i, _l, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _u, _vp, _i, _vp],
     "tlxmi_group_conv2d": [C.POINTER(ConvDesc), _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "tlxmi_pack_group_filter": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
@@ -99,6 +101,7 @@ _SPECIAL = {
     "tlxmi_group_conv_chunks": ([_i, _i, _i, _i], C.c_int),
     "tlxmi_conv2d_maxpool_supported": ([C.POINTER(ConvDesc)], C.c_int),
     "tlxmi_preprocess_u8_workspace_bytes": ([C.POINTER(PreprocDesc)], C.c_size_t),
+    "tlxmi_multiclass_nms_workspace_bytes": ([_i, _i], C.c_size_t),
     "tlxmi_bottleneck_seam_supported": ([_i, _i, _i, _i], C.c_int),
 }
 ALL_SYMBOLS = sorted(list(PROTOTYPES) + list(_SPECIAL))

@@ -1,0 +1,221 @@
+// YOLOv3 post-processing on the device: box decode + multiclass NMS.
+//
+// tlxmi_yolo_box — YOLOBox.__call__ (tlxcv/models/detection/yolov3.py:558-579) calls `yolo_box_func`, which exists only on
+//   the Paddle backend (detection/utils/ops.py:436-452: paddle.vision.ops.yolo_box).  Its published algorithm, restated:
+//   head map x [N][A*(5+C)][H][W]; for anchor a, cell (k, l):  conf = sigmoid(x[a, 4]); below conf_thresh the box and its
+//   scores stay zero; else
+//       cx = (l + sigmoid(x[a,0]) * s - 0.5*(s - 1)) * img_w / W        cy likewise with k, img_h, H
+//       bw = exp(x[a,2]) * anchor_w * img_w / (downsample * W)          bh likewise
+//       box = (cx - bw/2, cy - bh/2, cx + bw/2, cy + bh/2), clipped to [0, img - 1] when clip_bbox
+//       score[c] = conf * sigmoid(x[a, 5 + c])
+//   written at box index a*H*W + k*W + l of the image's list ([N][Mtot][4] and [N][Mtot][C]: several heads append).
+// tlxmi_multiclass_nms — tlx_multiclass_nms (detection/utils/ops.py:255-329), the reference's torch-side NMS: per image,
+//   best class and its score per box, keep score >= score_threshold, torchvision.ops.batched_nms (greedy, descending
+//   score, suppress IoU > nms_threshold within a class — by the coordinate trick: boxes shifted by class * (max coordinate
+//   + 1), reproduced here so that borderline IoUs round the same way), the first keep_top_k survivors, rows (class, score,
+//   x1, y1, x2, y2).  One workgroup per image: bitonic sort of (score, index) keys in a workspace, then the greedy sweep with
+//   the suppression flags in LDS.  A coverage kernel (integer / compare work, a few boxes per image in practice).
+#include "common.h"
+
+namespace tlxmi {
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+template <typename T>
+__global__ void yolo_box_kernel(const T* __restrict__ x, const int* __restrict__ img_size, const float* __restrict__ anchors,
+                                float* __restrict__ boxes, float* __restrict__ scores, int N, int A, int C, int H, int W,
+                                long x_nstride, int x_cstride, int x_pstride, int Mtot, int m_off, float conf_thresh, int downsample,
+                                int clip_bbox, float scale_xy) {
+    const long total = (long)N * A * H * W;
+    const float bias = -0.5f * (scale_xy - 1.0f);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int l = (int)(i % W);
+        long r = i / W;
+        const int k = (int)(r % H);
+        r /= H;
+        const int a = (int)(r % A);
+        const long n = r / A;
+        const T* xp = x + n * x_nstride + (long)(k * W + l) * x_pstride;     // entry e of anchor a: channel a*(5+C) + e
+        auto ent = [&](int e) { return (float)xp[(long)(a * (5 + C) + e) * x_cstride]; };
+        const long m = n * Mtot + m_off + (long)a * H * W + (long)k * W + l;
+        float* bp = boxes + m * 4;
+        float* sp = scores + m * C;
+        const float conf = sigmoidf_(ent(4));
+        if (conf < conf_thresh) {
+            bp[0] = bp[1] = bp[2] = bp[3] = 0.f;
+            for (int c = 0; c < C; ++c) sp[c] = 0.f;
+            continue;
+        }
+        const float img_h = (float)img_size[2 * n], img_w = (float)img_size[2 * n + 1];
+        const float cx = ((float)l + sigmoidf_(ent(0)) * scale_xy + bias) * img_w / (float)W;
+        const float cy = ((float)k + sigmoidf_(ent(1)) * scale_xy + bias) * img_h / (float)H;
+        const float bw = expf(ent(2)) * anchors[2 * a] * img_w / (float)(downsample * W);
+        const float bh = expf(ent(3)) * anchors[2 * a + 1] * img_h / (float)(downsample * H);
+        float x1 = cx - bw / 2, y1 = cy - bh / 2, x2 = cx + bw / 2, y2 = cy + bh / 2;
+        if (clip_bbox) {
+            x1 = x1 > 0.f ? x1 : 0.f;
+            y1 = y1 > 0.f ? y1 : 0.f;
+            x2 = x2 < img_w - 1.f ? x2 : img_w - 1.f;
+            y2 = y2 < img_h - 1.f ? y2 : img_h - 1.f;
+        }
+        bp[0] = x1; bp[1] = y1; bp[2] = x2; bp[3] = y2;
+        for (int c = 0; c < C; ++c) sp[c] = conf * sigmoidf_(ent(5 + c));
+    }
+}
+
+// keys[n][MP]: (score bits << 32) | ~index for candidates (score >= threshold), 0 otherwise / for padding; cls[n][M]
+__global__ void nms_keys_kernel(const float* __restrict__ scores, unsigned long long* __restrict__ keys, int* __restrict__ cls, int N, int M,
+                                int C, int MP, float thr) {
+    const long total = (long)N * MP;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i % MP);
+        const long n = i / MP;
+        unsigned long long key = 0ull;
+        if (m < M) {
+            const float* sp = scores + (n * M + m) * C;
+            float best = sp[0];
+            int bc = 0;
+            for (int c = 1; c < C; ++c)
+                if (sp[c] > best) { best = sp[c]; bc = c; }        // first maximal value, as argmax
+            cls[n * M + m] = bc;
+            if (best >= thr && best > 0.f) key = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)m);
+            else if (best >= thr) key = 1ull + (unsigned long long)(0xFFFFFFFEu - (unsigned)m);   // score 0 with a threshold <= 0: still a candidate
+        }
+        keys[i] = key;
+    }
+}
+
+__global__ __launch_bounds__(1024) void nms_image_kernel(const float* __restrict__ boxes, unsigned long long* __restrict__ keys,
+                                                         const int* __restrict__ cls, float* __restrict__ det, int* __restrict__ count, int M,
+                                                         int MP, float nms_thr, int keep_top_k) {
+    extern __shared__ __attribute__((aligned(16))) char nms_smem[];
+    unsigned char* sup = reinterpret_cast<unsigned char*>(nms_smem);       // [MP] suppression flags
+    __shared__ float red[1024];
+    __shared__ int s_k;
+    const int n = blockIdx.x, t = threadIdx.x;
+    unsigned long long* kp = keys + (long)n * MP;
+    // bitonic sort, descending
+    for (int size = 2; size <= MP; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int i = t; i < MP / 2; i += 1024) {
+                const int lo = ((i / stride) * stride * 2) + (i % stride), hi = lo + stride;
+                const bool desc = ((lo / size) & 1) == 0;
+                const unsigned long long a = kp[lo], b = kp[hi];
+                if (desc ? (a < b) : (a > b)) { kp[lo] = b; kp[hi] = a; }
+            }
+        }
+    __syncthreads();
+    // number of candidates, largest coordinate among them
+    int mine = 0;
+    float mx = -INFINITY;
+    for (int i = t; i < MP; i += 1024) {
+        sup[i] = 0;
+        const unsigned long long k = kp[i];
+        if (k != 0ull) {
+            ++mine;
+            const float* b = boxes + ((long)n * M + (0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull))) * 4;
+            mx = fmaxf(fmaxf(fmaxf(mx, b[0]), fmaxf(b[1], b[2])), b[3]);
+        }
+    }
+    if (t == 0) s_k = 0;
+    __syncthreads();
+    atomicAdd(&s_k, mine);
+    red[t] = mx;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if (t < o) red[t] = fmaxf(red[t], red[t + o]);
+        __syncthreads();
+    }
+    const int K = s_k;
+    const float shift = red[0] + 1.0f;                     // batched_nms: offsets = class * (max coordinate + 1)
+    float* dp = det + (long)n * keep_top_k * 6;
+    int kept = 0;
+    for (int i = 0; i < K && kept < keep_top_k; ++i) {
+        if (sup[i]) continue;                              // (uniform: flags only change between the barriers below)
+        const unsigned long long ki = kp[i];
+        const int mi = (int)(0xFFFFFFFFu - (unsigned)(ki & 0xFFFFFFFFull));
+        const float* bi = boxes + ((long)n * M + mi) * 4;
+        const int ci = cls[(long)n * M + mi];
+        const float off = (float)ci * shift;
+        const float ax1 = bi[0] + off, ay1 = bi[1] + off, ax2 = bi[2] + off, ay2 = bi[3] + off;
+        const float aarea = (ax2 - ax1) * (ay2 - ay1);
+        if (t == 0) {
+            float* o = dp + kept * 6;
+            o[0] = (float)ci; o[1] = __uint_as_float((unsigned)(ki >> 32)); o[2] = bi[0]; o[3] = bi[1]; o[4] = bi[2]; o[5] = bi[3];
+        }
+        ++kept;
+        for (int j = i + 1 + t; j < K; j += 1024) {
+            if (sup[j]) continue;
+            const int mj = (int)(0xFFFFFFFFu - (unsigned)(kp[j] & 0xFFFFFFFFull));
+            const float* bj = boxes + ((long)n * M + mj) * 4;
+            const float offj = (float)cls[(long)n * M + mj] * shift;
+            const float bx1 = bj[0] + offj, by1 = bj[1] + offj, bx2 = bj[2] + offj, by2 = bj[3] + offj;
+            const float w = fminf(ax2, bx2) - fmaxf(ax1, bx1), h = fminf(ay2, by2) - fmaxf(ay1, by1);
+            const float inter = (w > 0.f ? w : 0.f) * (h > 0.f ? h : 0.f);
+            const float iou = inter / (aarea + (bx2 - bx1) * (by2 - by1) - inter);
+            if (iou > nms_thr) sup[j] = 1;
+        }
+        __syncthreads();
+    }
+    if (t == 0) count[n] = kept;
+    for (int i = kept * 6 + t; i < keep_top_k * 6; i += 1024) dp[i] = 0.f;
+}
+
+}  // namespace tlxmi
+
+using namespace tlxmi;
+
+extern "C" int tlxmi_yolo_box(const void* x, int dtype, int N, int A, int C, int H, int W, int channels_last, const int32_t* img_size,
+                              const float* anchors, float conf_thresh, int downsample_ratio, int clip_bbox, float scale_x_y,
+                              float* boxes, float* scores, int Mtot, int m_offset, void* stream) {
+    TLXMI_REQUIRE(x && img_size && anchors && boxes && scores, TLXMI_ERR_BAD_ARG, "yolo_box: null argument");
+    TLXMI_REQUIRE(dtype == TLXMI_F16 || dtype == TLXMI_F32, TLXMI_ERR_BAD_ARG, "yolo_box: bad dtype");
+    TLXMI_REQUIRE(N > 0 && A > 0 && C > 0 && H > 0 && W > 0 && downsample_ratio > 0 && m_offset >= 0 && m_offset + A * H * W <= Mtot,
+                  TLXMI_ERR_BAD_ARG, "yolo_box: bad extent (boxes %d + %d of %d)", m_offset, A * H * W, Mtot);
+    const int ch = A * (5 + C);
+    // channels_first [N][ch][H][W]: channel stride H*W, pixel stride 1; channels_last [N][H][W][ch]: channel stride 1, pixel stride ch
+    const long nst = (long)ch * H * W;
+    const int cst = channels_last ? 1 : H * W, pst = channels_last ? ch : 1;
+    const long total = (long)N * A * H * W;
+    const unsigned grid = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if (dtype == TLXMI_F16)
+        hipLaunchKernelGGL((yolo_box_kernel<half_t>), dim3(grid), dim3(256), 0, as_stream(stream), (const half_t*)x, img_size, anchors, boxes, scores, N, A, C, H, W,
+                           nst, cst, pst, Mtot, m_offset, conf_thresh, downsample_ratio, clip_bbox, scale_x_y);
+    else
+        hipLaunchKernelGGL((yolo_box_kernel<float>), dim3(grid), dim3(256), 0, as_stream(stream), (const float*)x, img_size, anchors, boxes, scores, N, A, C, H, W,
+                           nst, cst, pst, Mtot, m_offset, conf_thresh, downsample_ratio, clip_bbox, scale_x_y);
+    return check_launch("yolo_box");
+}
+
+static int nms_pow2(int m) { int p = 2; while (p < m) p <<= 1; return p; }
+
+extern "C" size_t tlxmi_multiclass_nms_workspace_bytes(int N, int M) {
+    if (N <= 0 || M <= 0) return 0;
+    return (size_t)N * nms_pow2(M) * 8 + (size_t)N * M * 4;
+}
+
+extern "C" int tlxmi_multiclass_nms(const float* boxes, const float* scores, int N, int M, int C, float score_threshold, float nms_threshold,
+                                    int keep_top_k, void* workspace, float* detections, int32_t* counts, void* stream) {
+    TLXMI_REQUIRE(boxes && scores && workspace && detections && counts, TLXMI_ERR_BAD_ARG, "multiclass_nms: null argument");
+    TLXMI_REQUIRE(N > 0 && M > 0 && C > 0 && keep_top_k > 0, TLXMI_ERR_BAD_ARG, "multiclass_nms: bad extent");
+    const int MP = nms_pow2(M);
+    TLXMI_REQUIRE(MP <= 65536, TLXMI_ERR_UNSUPPORTED, "multiclass_nms: %d boxes per image (<= 65536)", M);
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(workspace);
+    int* cls = reinterpret_cast<int*>(keys + (size_t)N * MP);
+    hipStream_t st = as_stream(stream);
+    const long total = (long)N * MP;
+    const unsigned grid = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(nms_keys_kernel, dim3(grid), dim3(256), 0, st, scores, keys, cls, N, M, C, MP, score_threshold);
+    const size_t lds = (size_t)MP;
+    if (lds > 48 * 1024) {
+        static bool raised = false;
+        if (!raised) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&nms_image_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            if (e != hipSuccess) return fail(TLXMI_ERR_LAUNCH, "multiclass_nms: cannot raise LDS limit: %s", hipGetErrorString(e));
+            raised = true;
+        }
+    }
+    hipLaunchKernelGGL(nms_image_kernel, dim3(N), dim3(1024), lds, st, boxes, keys, cls, detections, counts, M, MP, nms_threshold, keep_top_k);
+    return check_launch("multiclass_nms");
+}

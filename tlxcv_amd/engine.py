@@ -767,6 +767,45 @@ def mha(q, k, v, heads, scale, mask=None, need_weights=False, batch_first=False)
     return out, avg
 
 
+def yolo_box(heads_nhwc, anchors, num_classes, img_size, conf_thresh=0.005, downsample_ratio=32, clip_bbox=True, scale_x_y=1.0):
+    """YOLOBox.__call__ (yolov3.py:558-579) on the device: `heads_nhwc` are the head maps (N,H,W,A*(5+C)) from the coarsest
+    stride down, `anchors` the flat (w, h, w, h, ...) list per head (YOLOv3Head.mask_anchors), img_size (N,2) int32 (h, w).
+    -> boxes (N, M, 4) fp32, scores (N, M, C) fp32 with M = sum A*H*W, heads appended in order."""
+    N = heads_nhwc[0].shape[0]
+    As = [len(a) // 2 for a in anchors]
+    Ms = [A * h.shape[1] * h.shape[2] for A, h in zip(As, heads_nhwc)]
+    Mtot = sum(Ms)
+    dev = heads_nhwc[0].device
+    boxes = torch.empty((N, Mtot, 4), dtype=torch.float32, device=dev)
+    scores = torch.empty((N, Mtot, num_classes), dtype=torch.float32, device=dev)
+    img = img_size.to(device=dev, dtype=torch.int32).contiguous()
+    off = 0
+    for i, (h, anc) in enumerate(zip(heads_nhwc, anchors)):
+        need_gpu(h, "head map")
+        if not h.is_contiguous() or h.shape[-1] != As[i] * (5 + num_classes):
+            raise RuntimeError(f"yolo_box: head {i} must be a dense (N,H,W,{As[i] * (5 + num_classes)}) map")
+        a = torch.tensor(anc, dtype=torch.float32, device=dev)
+        _lib.call("tlxmi_yolo_box", _p(h), dt_code(h.dtype), N, As[i], num_classes, h.shape[1], h.shape[2], 1, _p(img), _p(a),
+                  C.c_float(conf_thresh), int(downsample_ratio // 2 ** i), 1 if clip_bbox else 0, C.c_float(scale_x_y), _p(boxes), _p(scores),
+                  Mtot, off, _stream())
+        off += Ms[i]
+    return boxes, scores
+
+
+def multiclass_nms(boxes, scores, score_threshold=0.05, nms_threshold=0.5, keep_top_k=100):
+    """tlx_multiclass_nms (detection/utils/ops.py:255-329) on the device: boxes (N,M,4), scores (N,M,C) fp32 ->
+    (detections (N, keep_top_k, 6) rows (class, score, x1, y1, x2, y2), counts (N,) int32)."""
+    need_gpu(boxes, "boxes")
+    boxes, scores = boxes.float().contiguous(), scores.float().contiguous()
+    N, M, Cc = scores.shape
+    ws = torch.empty(_lib.load().tlxmi_multiclass_nms_workspace_bytes(N, M), dtype=torch.uint8, device=boxes.device)
+    det = torch.empty((N, keep_top_k, 6), dtype=torch.float32, device=boxes.device)
+    cnt = torch.empty((N,), dtype=torch.int32, device=boxes.device)
+    _lib.call("tlxmi_multiclass_nms", _p(boxes), _p(scores), N, M, Cc, C.c_float(score_threshold), C.c_float(nms_threshold), int(keep_top_k),
+              _p(ws), _p(det), _p(cnt), _stream())
+    return det, cnt
+
+
 def attention_table(bias, mask, N):
     """bias (heads, N, N) + mask (nW, N, N) or None -> the pre-summed, padded table of tlxmi_attention_comb:
     (max(nW,1), heads, NP, NP) fp32, NP = 32 * ceil(N / 32).  Built once per layer (the reference adds the two on

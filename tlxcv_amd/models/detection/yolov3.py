@@ -4,8 +4,14 @@ Mirrors tlxcv/models/detection/yolov3.py: YoloDetBlock :122-183, YOLOv3FPN :186-
 (head conv :311-322, 3*(num_classes+5) channels, bias).  In the neck, `interpolate(route, scale_factor=2)` +
 `tlx.concat([route, x])` (:246-256) are two copy kernels into one pre-sized NHWC buffer (nearest x2 written
 at channel offset 0, the backbone map at its channel offset) instead of materialising both.
-Out of scope: YOLOv3Loss, Gt2YoloTarget, box decode and NMS — `yolo_box` exists only on
-the Paddle backend in the reference (utils/ops.py:436-452).  forward() returns the raw head maps."""
+Post-processing runs on the device too: YOLOBox (:541-579) = tlxmi_yolo_box — the published
+algorithm of paddle.vision.ops.yolo_box, the op the reference calls and has on the Paddle backend only
+(utils/ops.py:436-452) — and MultiClassNMS = tlxmi_multiclass_nms, following the reference's torch-side
+tlx_multiclass_nms (utils/ops.py:255-329) with scores as (N, boxes, classes).  Off Paddle the reference's own glue between
+the two is inconsistent (scores handed over transposed, a list where three values are unpacked: post_process.py:46), so
+the end-to-end detections cannot be pinned against it; each stage is checked against its restatement (oracle/detection.py).
+Out of scope: YOLOv3Loss, Gt2YoloTarget (training)."""
+import numpy as np
 import torch
 
 from ... import engine as E
@@ -127,6 +133,38 @@ class YOLOv3Head(nn.Module):
         return [from_nhwc(y, self.data_format) for y in self.run_nhwc([as_nhwc(f, self.data_format) for f in feats])]
 
 
+class YOLOBox:
+    """yolov3.py:541-579; __call__ takes the head maps as NHWC engine tensors."""
+
+    def __init__(self, num_classes=92, conf_thresh=0.005, downsample_ratio=32, clip_bbox=True, scale_x_y=1.0,
+                 data_format="channels_first"):
+        self.num_classes, self.conf_thresh, self.downsample_ratio = num_classes, conf_thresh, downsample_ratio
+        self.clip_bbox, self.scale_x_y, self.data_format = clip_bbox, scale_x_y, data_format
+
+    def __call__(self, yolo_head_out_nhwc, anchors, im_shape, scale_factor, var_weight=None):
+        origin_shape = (im_shape / scale_factor).to(torch.int32)                      # :560-561
+        return E.yolo_box(yolo_head_out_nhwc, anchors, self.num_classes, origin_shape, self.conf_thresh, self.downsample_ratio,
+                          self.clip_bbox, self.scale_x_y)
+
+
+class MultiClassNMS:
+    """utils/layers.py:84-129 with the semantics of tlx_multiclass_nms (utils/ops.py:255-329)."""
+
+    def __init__(self, score_threshold=0.05, nms_top_k=-1, keep_top_k=100, nms_threshold=0.5, **kwds):
+        self.score_threshold, self.nms_top_k, self.keep_top_k, self.nms_threshold = score_threshold, nms_top_k, keep_top_k, nms_threshold
+
+    def __call__(self, bboxes, score):
+        return E.multiclass_nms(bboxes, score, self.score_threshold, self.nms_threshold, self.keep_top_k)
+
+
+def cvt_results(det, cnt):
+    """utils/ops.py:397-405 on the (detections, counts) of MultiClassNMS: rows of all images concatenated."""
+    cnt_h = cnt.cpu().numpy()
+    rows = np.concatenate([det[i, :int(c)].cpu().numpy() for i, c in enumerate(cnt_h)] or [np.zeros((0, 6), np.float32)])
+    return dict(labels=rows[:, 0].astype(int), scores=rows[:, 1].astype(float), boxes=rows[:, 2:].astype(int),
+                bbox_num=cnt_h.item() if cnt_h.size == 1 else cnt_h)
+
+
 class YOLOv3(nn.Module):
     def __init__(self, backbone="DarkNet", data_format="channels_first", for_mot=False):
         super().__init__()
@@ -134,7 +172,8 @@ class YOLOv3(nn.Module):
         self.backbone = create(backbone, **kwds)
         self.neck = YOLOv3FPN(**kwds)
         self.yolo_head = YOLOv3Head(**kwds)
-        self.post_process = None      # decode + NMS: CPU/Paddle-only in the reference, out of scope
+        self.decode = YOLOBox(**kwds)                                                           # :41-42
+        self.nms = MultiClassNMS(score_threshold=0.01, nms_threshold=0.5, nms_top_k=1000)       # :43-47
         self.for_mot, self.data_format = for_mot, data_format
 
     def forward(self, inputs):
@@ -144,5 +183,15 @@ class YOLOv3(nn.Module):
         neck = self.neck.run_nhwc(body)
         head = self.yolo_head.run_nhwc(neck)
         conv = lambda ts: [from_nhwc(t, self.data_format) for t in ts]
-        return {"images": inputs["images"], "body_feats": conv(body), "neck_feats": conv(neck),
-                "yolo_head_outs": conv(head)}
+        out = {"images": inputs["images"], "body_feats": conv(body), "neck_feats": conv(neck), "yolo_head_outs": conv(head)}
+        # :67-103: decode + NMS -> labels / scores / boxes / bbox_num
+        img = inputs["images"]
+        n, (h, w) = img.shape[0], (img.shape[2:4] if self.data_format == "channels_first" else img.shape[1:3])
+        im_shape = inputs.get("im_shape", torch.tensor([[h, w]] * n, dtype=torch.float32))
+        scale_factor = inputs.get("scale_factor", torch.ones_like(torch.as_tensor(im_shape, dtype=torch.float32)))
+        bboxes, scores = self.decode(head, self.yolo_head.mask_anchors, torch.as_tensor(im_shape, dtype=torch.float32).cpu(),
+                                     torch.as_tensor(scale_factor, dtype=torch.float32).cpu())
+        det, cnt = self.nms(bboxes, scores)
+        out.update(cvt_results(det, cnt))
+        out["detections"], out["detection_counts"] = det, cnt
+        return out
