@@ -208,6 +208,13 @@ typedef struct tlxmi_seam_desc {
     int32_t act;                         /* TLXMI_ACT_RELU */
 } tlxmi_seam_desc;
 int tlxmi_bottleneck_seam_supported(int dtype, int K1, int N1, int N2);
+/* tlxmi_bottleneck_seam_proj: the seam of a block WITH a projection shortcut (resnet.py:246-261, layer1.0: 1x1 conv + BN on
+ * the block's input at stride 1): skip = (x . Wd^T) * scale_d + shift_d is computed in the launch instead of being read
+ * from a stored map.  x: [rows][skip_ld], K1 channels.  fp16, K1 = N2 = 64 only (TLXMI_ERR_UNSUPPORTED otherwise). */
+int tlxmi_bottleneck_seam_proj(const tlxmi_seam_desc* d, const void* t2, const void* w3_packed, const float* scale3,
+                               const float* shift3, const void* x, const void* wd_packed, const float* scale_d,
+                               const float* shift_d, void* y, const void* w1_packed, const float* scale1,
+                               const float* shift1, void* t1, void* stream);
 int tlxmi_bottleneck_seam(const tlxmi_seam_desc* d, const void* t2, const void* w3_packed, const float* scale3,
                           const float* shift3, const void* skip, void* y, const void* w1_packed, const float* scale1,
                           const float* shift1, void* t1, void* stream);

@@ -66,6 +66,35 @@ def test_seam_at_full_size_is_consistent_with_two_launches(dev, fp16_mode):
     assert (y.float() - y2.float()).abs().max().item() <= 4e-3 and (t1.float() - t12.float()).abs().max().item() <= 8e-3
 
 
+@pytest.mark.parametrize("N,H,W", [(1, 9, 9), (2, 14, 14), (16, 56, 56)])
+def test_seam_with_the_projection_shortcut_inside(dev, fp16_mode, N, H, W):
+    """layer1.0 (resnet.py:246-261): skip = bn_d(conv_d(x)) computed in the seam launch; equal to the three-launch path
+    (shortcut conv, expand conv + skip, reduce conv) to fp16 rounding, and to the oracle."""
+    K1, N1, N2 = 64, 256, 64
+    t2, _, w3, w1, s3, h3, s1, h1 = _make(K1, N1, N2, N, H, W, seed=5 + H)
+    rng = np.random.default_rng(77 + H)
+    x = q16(torch.relu(rnd(rng, (N, K1, H, W))))
+    wd = q16(rnd(rng, (N1, K1, 1, 1), (2.0 / K1) ** 0.5))
+    sd = torch.from_numpy(rng.uniform(0.5, 1.5, N1).astype(np.float32))
+    hd = rnd(rng, (N1,), 0.2)
+    skip_ref = q16(OF.conv_bn_act(x, wd, sd, hd, None, E.ACT_NONE))                  # the shortcut as stored: fp16
+    y_ref = OF.conv_bn_act(t2, w3, s3, h3, skip_ref, E.ACT_RELU)
+    t1_ref = OF.conv_bn_act(q16(y_ref), w1, s1, h1, None, E.ACT_RELU)
+    nh = lambda a: a.permute(0, 2, 3, 1).contiguous().half().to(dev)                 # noqa: E731
+    pk3, pk1, pkd = (E.PackedFilter(w.to(dev), torch.float16) for w in (w3, w1, wd))
+    dv = lambda *ts: [t.to(dev) for t in ts]                                         # noqa: E731
+    s3d, h3d, s1d, h1d, sdd, hdd = dv(s3, h3, s1, h1, sd, hd)
+    y, t1 = E.bottleneck_seam(nh(t2), pk3, s3d, h3d, nh(x), pk1, s1d, h1d, proj=(pkd, sdd, hdd))
+    skip2 = E.conv2d(nh(x), pkd, 1, 0, 1, sdd, hdd, None, E.ACT_NONE)
+    y2 = E.conv2d(nh(t2), pk3, 1, 0, 1, s3d, h3d, skip2, E.ACT_RELU)
+    t12 = E.conv2d(y2, pk1, 1, 0, 1, s1d, h1d, None, E.ACT_RELU)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(y.float().cpu().permute(0, 3, 1, 2), y_ref, atol=3e-3, rtol=3e-3)
+    torch.testing.assert_close(t1.float().cpu().permute(0, 3, 1, 2), t1_ref, atol=5e-3, rtol=5e-3)
+    torch.testing.assert_close(y.float(), y2.float(), atol=3e-3, rtol=3e-3)
+    torch.testing.assert_close(t1.float(), t12.float(), atol=5e-3, rtol=5e-3)
+
+
 def test_unsupported_triples_are_reported_not_run(dev):
     assert not E.bottleneck_seam_supported(96, 384, 96, torch.float16)
     assert not E.bottleneck_seam_supported(64, 256, 64, torch.float32)

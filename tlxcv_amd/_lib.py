@@ -62,6 +62,7 @@ PROTOTYPES = {
     "tlxmi_fold_bn": [_vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp],
     "tlxmi_conv2d": [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "tlxmi_bottleneck_seam": [C.POINTER(SeamDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "tlxmi_bottleneck_seam_proj": [C.POINTER(SeamDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "tlxmi_preprocess_u8": [C.POINTER(PreprocDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "tlxmi_yolo_box": [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _f, _i, _i, _f, _vp, _vp, _i, _i, _vp],
     "tlxmi_multiclass_nms": [_vp, _vp, _i, _i, _i, _f, _f, _i, _vp, _vp, _vp, _vp],

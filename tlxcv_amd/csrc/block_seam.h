@@ -12,6 +12,9 @@ struct SeamArgs {
     int x_ld, res_ld, y_ld, z_ld;      // elements between rows
     unsigned x_bytes, w3_bytes, res_bytes, y_bytes, w1_bytes, z_bytes;
     int y_nt, z_nt;                    // non-temporal stores of y / t1
+    const char* wd;                    // PROJ form: packed shortcut filter [N1][K1]; `res` is then the block input [M][res_ld]
+    const float *scale_d, *shift_d;
+    unsigned wd_bytes;
 };
 
 bool block_seam_shape_ok(int K1, int N1, int N2);

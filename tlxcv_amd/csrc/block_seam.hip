@@ -59,14 +59,18 @@ static __device__ __forceinline__ int bs_f2(int r) { return (((r >> 1) & 1) << 2
 
 // K1: input channels of the expand conv (t2), N2: output channels of the reduce conv (t1); N1 (channels of y) is a
 // runtime multiple of 64.  PW: MFMA pixel blocks (16 pixels) per wave; 8 waves per workgroup.
-template <int K1, int N2, int PW, int NW>
+// PROJ: the skip is not a stored map but the projection shortcut bn_d(conv_d(xp)) of the block (resnet.py:246-261, a 1x1 conv
+// on the block's K1-channel input at stride 1: ResNet's layer1.0), computed here as a second product per step — the 411 MB
+// shortcut map is neither written nor read.
+template <int K1, int N2, int PW, int NW, bool PROJ = false>
 __global__ __launch_bounds__(64 * NW) void seam_kernel(const SeamArgs a) {
     constexpr int NT = 64 * NW;          // threads
     constexpr int IPT = 512 / NT;        // 16-byte chunks of a panel each thread stages
     constexpr int KS = K1 / 32;          // k-steps of GEMM1
     constexpr int CB = K1 / 64;          // W3 panels of a step
     constexpr int Q2 = N2 / 64;          // W1' panels of a step
-    constexpr int NP = CB + Q2;
+    constexpr int CD = PROJ ? CB : 0;    // Wd panels of a step (the shortcut's input has K1 channels too)
+    constexpr int NP = CB + Q2 + CD;
     constexpr int T2 = N2 / 16;          // MFMA row tiles of GEMM2
     constexpr int PANEL = 64 * 128;
     constexpr int OOB = (int)0x80000000;
@@ -74,6 +78,7 @@ __global__ __launch_bounds__(64 * NW) void seam_kernel(const SeamArgs a) {
     char* const wbuf = smem;                                                   // two step buffers of NP panels
     float* const tab3 = reinterpret_cast<float*>(smem + 2 * NP * PANEL);       // scale3[N1], shift3[N1]
     float* const tab1 = tab3 + 2 * a.N1;                                       // scale1[N2], shift1[N2]
+    float* const tabd = tab1 + 2 * N2;                                         // PROJ: scale_d[N1], shift_d[N1]
 
     const int t = threadIdx.x, lane = t & 63;
     const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -81,6 +86,7 @@ __global__ __launch_bounds__(64 * NW) void seam_kernel(const SeamArgs a) {
 
     const __amdgpu_buffer_rsrc_t xsrd = bs_srd(a.x, a.x_bytes), w3srd = bs_srd(a.w3, a.w3_bytes), w1srd = bs_srd(a.w1, a.w1_bytes);
     const __amdgpu_buffer_rsrc_t rsrd = bs_srd(a.res, a.res_bytes), ysrd = bs_srd(a.y, a.y_bytes), zsrd = bs_srd(a.z, a.z_bytes);
+    const __amdgpu_buffer_rsrc_t wdsrd = bs_srd(PROJ ? a.wd : a.w3, PROJ ? a.wd_bytes : 0u);
 
     // staging: chunk k of this thread in every panel = (row, physical slot) of index k*NT + t; the logical chunks it fetches
     auto stage_load = [&](int c, u32x4 (&st)[NP][IPT]) {
@@ -92,6 +98,8 @@ __global__ __launch_bounds__(64 * NW) void seam_kernel(const SeamArgs a) {
             for (int cb = 0; cb < CB; ++cb) st[cb][k] = bs_load16(w3srd, ((64 * c + srow) * K1 + 64 * cb + 8 * sl1) * 2);
 #pragma unroll
             for (int q = 0; q < Q2; ++q) st[CB + q][k] = bs_load16(w1srd, ((64 * q + srow) * a.N1 + 64 * c + 8 * sl2) * 2);
+#pragma unroll
+            for (int cb = 0; cb < CD; ++cb) st[CB + Q2 + cb][k] = bs_load16(wdsrd, ((64 * c + srow) * K1 + 64 * cb + 8 * sl1) * 2);
         }
     };
     auto stage_write = [&](int buf, const u32x4 (&st)[NP][IPT]) {
@@ -118,7 +126,16 @@ __global__ __launch_bounds__(64 * NW) void seam_kernel(const SeamArgs a) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
             xf[ks][pw] = bs_load16(xsrd, pok[pw] ? (pix[pw] * a.x_ld + 32 * ks + 8 * g) * 2 : OOB);
+    u32x4 xpf[PROJ ? KS : 1][PW];      // PROJ: fragments of the block input (B operand of the shortcut product)
+    if constexpr (PROJ) {
+#pragma unroll
+        for (int pw = 0; pw < PW; ++pw)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                xpf[ks][pw] = bs_load16(rsrd, pok[pw] ? (pix[pw] * a.res_ld + 32 * ks + 8 * g) * 2 : OOB);
+    }
     auto skip_load = [&](int c, u32x4 (&sk)[PW][2]) {
+        if constexpr (PROJ) return;
 #pragma unroll
         for (int pw = 0; pw < PW; ++pw)
 #pragma unroll
@@ -137,6 +154,12 @@ __global__ __launch_bounds__(64 * NW) void seam_kernel(const SeamArgs a) {
         for (int i = t; i < N2; i += NT) {
             tab1[i] = a.scale1 ? a.scale1[i] : 1.f;
             tab1[N2 + i] = a.shift1 ? a.shift1[i] : 0.f;
+        }
+        if constexpr (PROJ) {
+            for (int i = t; i < a.N1; i += NT) {
+                tabd[i] = a.scale_d ? a.scale_d[i] : 1.f;
+                tabd[a.N1 + i] = a.shift_d ? a.shift_d[i] : 0.f;
+            }
         }
         stage_write(0, st);
     }
@@ -182,6 +205,20 @@ __global__ __launch_bounds__(64 * NW) void seam_kernel(const SeamArgs a) {
                 for (int pw = 0; pw < PW; ++pw) acc1[ci][pw] = bs_mma(af, xf[ks][pw], acc1[ci][pw]);
             }
         }
+        f32x4 accd[PROJ ? 4 : 1][PW];
+        if constexpr (PROJ) {
+#pragma unroll
+            for (int ci = 0; ci < 4; ++ci) {
+#pragma unroll
+                for (int pw = 0; pw < PW; ++pw) accd[ci][pw] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const u32x4 af = *reinterpret_cast<const u32x4*>(wb + (CB + Q2 + (ks >> 1)) * PANEL + (a1off[ci] ^ ((ks & 1) << 6)));
+#pragma unroll
+                    for (int pw = 0; pw < PW; ++pw) accd[ci][pw] = bs_mma(af, xpf[ks][pw], accd[ci][pw]);
+                }
+            }
+        }
 
         // ---- epilogue 1: folded BatchNorm, + skip, ReLU; y out; the rounded values are GEMM2's B fragments
         u32x4 yf[PW][2];
@@ -192,9 +229,24 @@ __global__ __launch_bounds__(64 * NW) void seam_kernel(const SeamArgs a) {
             for (int h = 0; h < 2; ++h) {
                 const f32x4 s0 = *reinterpret_cast<const f32x4*>(sc + 8 * h), s1 = *reinterpret_cast<const f32x4*>(sc + 8 * h + 4);
                 const f32x4 h0 = *reinterpret_cast<const f32x4*>(sh + 8 * h), h1 = *reinterpret_cast<const f32x4*>(sh + 8 * h + 4);
+                f32x4 d0 = s0, d1 = s0, e0 = s0, e1 = s0;
+                if constexpr (PROJ) {
+                    const float* scd = tabd + 64 * c + 16 * g + 8 * h;
+                    d0 = *reinterpret_cast<const f32x4*>(scd); d1 = *reinterpret_cast<const f32x4*>(scd + 4);
+                    e0 = *reinterpret_cast<const f32x4*>(scd + a.N1); e1 = *reinterpret_cast<const f32x4*>(scd + a.N1 + 4);
+                }
 #pragma unroll
                 for (int pw = 0; pw < PW; ++pw) {
-                    const half8v rv = __builtin_bit_cast(half8v, sk[pw][h]);
+                    half8v rv;
+                    if constexpr (PROJ) {       // the shortcut as the two-launch path stores it: rounded to fp16 once
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            rv[e] = (half_t)(accd[2 * h][pw][e] * d0[e] + e0[e]);
+                            rv[4 + e] = (half_t)(accd[2 * h + 1][pw][e] * d1[e] + e1[e]);
+                        }
+                    } else {
+                        rv = __builtin_bit_cast(half8v, sk[pw][h]);
+                    }
                     half8v o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -253,11 +305,11 @@ __global__ __launch_bounds__(64 * NW) void seam_kernel(const SeamArgs a) {
     }
 }
 
-template <int K1, int N2, int PW, int NW> static int launch_seam_t(const SeamArgs& a, hipStream_t st) {
-    constexpr int NP = K1 / 64 + N2 / 64;
-    const size_t lds = (size_t)2 * NP * 64 * 128 + (size_t)(2 * a.N1 + 2 * N2) * sizeof(float);
+template <int K1, int N2, int PW, int NW, bool PROJ = false> static int launch_seam_t(const SeamArgs& a, hipStream_t st) {
+    constexpr int NP = K1 / 64 + N2 / 64 + (PROJ ? K1 / 64 : 0);
+    const size_t lds = (size_t)2 * NP * 64 * 128 + (size_t)(2 * a.N1 + 2 * N2 + (PROJ ? 2 * a.N1 : 0)) * sizeof(float);
     if (lds > 160 * 1024) return fail(TLXMI_ERR_UNSUPPORTED, "block_seam: %zu bytes of LDS", lds);
-    const void* fn = reinterpret_cast<const void*>(&seam_kernel<K1, N2, PW, NW>);
+    const void* fn = reinterpret_cast<const void*>(&seam_kernel<K1, N2, PW, NW, PROJ>);
     if (lds > 64 * 1024) {
         static bool raised = false;
         if (!raised) {
@@ -277,7 +329,7 @@ template <int K1, int N2, int PW, int NW> static int launch_seam_t(const SeamArg
 
 bool block_seam_shape_ok(int K1, int N1, int N2) {
     if (N1 % 64 || N1 < 64 || N1 > 2048) return false;
-    return (K1 == 64 && (N2 == 64 || N2 == 128)) || (K1 == 128 && (N2 == 128 || N2 == 256));
+    return (K1 == 64 && (N2 == 64 || N2 == 128)) || (K1 == 128 && (N2 == 128 || N2 == 256)) || (K1 == 256 && N2 == 256);
 }
 
 int launch_block_seam(const SeamArgs& a0, int K1, int N2, hipStream_t st) {
@@ -287,12 +339,17 @@ int launch_block_seam(const SeamArgs& a0, int K1, int N2, hipStream_t st) {
     b.z_nt = (vv & 2) ? 1 : 0;        // t1 is small and read back at once by the next conv: a plain store keeps it in the Infinity Cache (-124 us per ResNet-50 forward vs nt)
     b.y_nt = (vv & 4) ? 1 : 0;
     const SeamArgs& a = b;
+    if (a.wd) {
+        if (K1 == 64 && N2 == 64) return launch_seam_t<64, 64, 2, 4, true>(a, st);
+        return fail(TLXMI_ERR_UNSUPPORTED, "block_seam: the projection-shortcut form is compiled for 64 -> N1 -> 64 channels");
+    }
     if (K1 == 64 && N2 == 64) return v ? launch_seam_t<64, 64, 2, 8>(a, st) : launch_seam_t<64, 64, 2, 4>(a, st);
     if (K1 == 64 && N2 == 128) return v ? launch_seam_t<64, 128, 2, 8>(a, st) : launch_seam_t<64, 128, 2, 4>(a, st);
     // (measured, batch 256: 56 x 56 seams 226 / 268 us with 4 waves vs 233 / 288 with 8; 28 x 28 seams 153 / 194 us with 8 waves
     //  vs 185 / 266 with 4 — the 128-channel filters are 256 - 384 KB per pass and want more pixels per staging)
     if (K1 == 128 && N2 == 128) return v ? launch_seam_t<128, 128, 2, 4>(a, st) : launch_seam_t<128, 128, 2, 8>(a, st);
     if (K1 == 128 && N2 == 256) return v ? launch_seam_t<128, 256, 1, 4>(a, st) : launch_seam_t<128, 256, 1, 8>(a, st);
+    if (K1 == 256 && N2 == 256) return v ? launch_seam_t<256, 256, 1, 4>(a, st) : launch_seam_t<256, 256, 1, 8>(a, st);
     return fail(TLXMI_ERR_UNSUPPORTED, "block_seam: no instantiation for %d -> N1 -> %d channels", K1, N2);
 }
 
@@ -304,15 +361,16 @@ extern "C" int tlxmi_bottleneck_seam_supported(int dtype, int K1, int N1, int N2
     return dtype == TLXMI_F16 && block_seam_shape_ok(K1, N1, N2) ? 1 : 0;
 }
 
-extern "C" int tlxmi_bottleneck_seam(const tlxmi_seam_desc* d, const void* t2, const void* w3_packed, const float* scale3,
-                                     const float* shift3, const void* skip, void* y, const void* w1_packed, const float* scale1,
-                                     const float* shift1, void* t1, void* stream) {
+static int seam_impl(const tlxmi_seam_desc* d, const void* t2, const void* w3_packed, const float* scale3,
+                     const float* shift3, const void* skip, void* y, const void* w1_packed, const float* scale1,
+                     const float* shift1, void* t1, void* stream, const void* wd_packed, const float* scale_d, const float* shift_d) {
     TLXMI_REQUIRE(d && t2 && w3_packed && skip && y && w1_packed && t1, TLXMI_ERR_BAD_ARG, "bottleneck_seam: null argument");
     TLXMI_REQUIRE(d->dtype == TLXMI_F16, TLXMI_ERR_UNSUPPORTED, "bottleneck_seam: fp16 only (the fp32 parity mode runs the two convolutions)");
     TLXMI_REQUIRE(d->rows > 0 && d->K1 > 0 && d->N1 > 0 && d->N2 > 0, TLXMI_ERR_BAD_ARG, "bottleneck_seam: bad extent");
     if (!block_seam_shape_ok(d->K1, d->N1, d->N2))
         return fail(TLXMI_ERR_UNSUPPORTED, "bottleneck_seam: no kernel for %d -> %d -> %d channels", d->K1, d->N1, d->N2);
-    TLXMI_REQUIRE(d->t2_ld >= d->K1 && d->skip_ld >= d->N1 && d->y_ld >= d->N1 && d->t1_ld >= d->N2, TLXMI_ERR_BAD_ARG, "bottleneck_seam: row stride below the channel count");
+    TLXMI_REQUIRE(d->t2_ld >= d->K1 && d->skip_ld >= (wd_packed ? d->K1 : d->N1) && d->y_ld >= d->N1 && d->t1_ld >= d->N2, TLXMI_ERR_BAD_ARG, "bottleneck_seam: row stride below the channel count");
+    TLXMI_REQUIRE(!wd_packed || (aligned16(wd_packed) && d->K1 == 64 && d->N2 == 64), TLXMI_ERR_UNSUPPORTED, "bottleneck_seam_proj: 64 -> N1 -> 64 channels only");
     TLXMI_REQUIRE(d->t2_ld % 8 == 0 && d->skip_ld % 8 == 0 && d->y_ld % 8 == 0 && d->t1_ld % 8 == 0 && aligned16(t2) && aligned16(skip) && aligned16(y) &&
                       aligned16(t1) && aligned16(w3_packed) && aligned16(w1_packed),
                   TLXMI_ERR_ALIGNMENT, "bottleneck_seam: rows must be whole 16-byte chunks");
@@ -330,9 +388,28 @@ extern "C" int tlxmi_bottleneck_seam(const tlxmi_seam_desc* d, const void* t2, c
     a.x_bytes = (unsigned)(rows * d->t2_ld * 2); a.res_bytes = (unsigned)(rows * d->skip_ld * 2);
     a.y_bytes = (unsigned)(rows * d->y_ld * 2); a.z_bytes = (unsigned)(rows * d->t1_ld * 2);
     // packed filters (tlxmi_pack_filter, 1x1): [Cout rounded up to 128][K] row-major; K1 and N1 are multiples of 64
+    a.wd = (const char*)wd_packed; a.scale_d = scale_d; a.shift_d = shift_d;
+    a.wd_bytes = wd_packed ? (unsigned)(((size_t)(d->N1 + 127) / 128 * 128) * (size_t)d->K1 * 2) : 0u;
     a.w3_bytes = (unsigned)(((size_t)(d->N1 + 127) / 128 * 128) * (size_t)d->K1 * 2);
     a.w1_bytes = (unsigned)(((size_t)(d->N2 + 127) / 128 * 128) * (size_t)d->N1 * 2);
     const int rc = launch_block_seam(a, d->K1, d->N2, as_stream(stream));
     if (rc != TLXMI_OK) return rc;
     return check_launch("bottleneck_seam");
+}
+
+extern "C" int tlxmi_bottleneck_seam(const tlxmi_seam_desc* d, const void* t2, const void* w3_packed, const float* scale3,
+                                     const float* shift3, const void* skip, void* y, const void* w1_packed, const float* scale1,
+                                     const float* shift1, void* t1, void* stream) {
+    return seam_impl(d, t2, w3_packed, scale3, shift3, skip, y, w1_packed, scale1, shift1, t1, stream, nullptr, nullptr, nullptr);
+}
+
+// The same with the block's projection shortcut computed in place of a stored skip map: skip = (x . Wd^T) * scale_d + shift_d,
+// rounded to fp16 as the stand-alone convolution would store it (resnet.py:246-261 downsample of layer1.0: 1x1, stride 1).
+// x: [rows][skip_ld] with K1 channels (the block's input).  fp16, K1 = N2 = 64.
+extern "C" int tlxmi_bottleneck_seam_proj(const tlxmi_seam_desc* d, const void* t2, const void* w3_packed, const float* scale3,
+                                          const float* shift3, const void* x, const void* wd_packed, const float* scale_d,
+                                          const float* shift_d, void* y, const void* w1_packed, const float* scale1,
+                                          const float* shift1, void* t1, void* stream) {
+    TLXMI_REQUIRE(wd_packed, TLXMI_ERR_BAD_ARG, "bottleneck_seam_proj: null shortcut filter");
+    return seam_impl(d, t2, w3_packed, scale3, shift3, x, y, w1_packed, scale1, shift1, t1, stream, wd_packed, scale_d, shift_d);
 }

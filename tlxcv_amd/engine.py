@@ -359,9 +359,11 @@ def bottleneck_seam_supported(K1, N1, N2, dtype):
     return bool(_lib.load().tlxmi_bottleneck_seam_supported(dt_code(dtype), int(K1), int(N1), int(N2)))
 
 
-def bottleneck_seam(t2, pk3, scale3, shift3, skip, pk1, scale1, shift1):
+def bottleneck_seam(t2, pk3, scale3, shift3, skip, pk1, scale1, shift1, proj=None):
     """One launch for the seam between two bottleneck blocks (tlxmi_bottleneck_seam): y = relu(conv3(t2) * scale3 + shift3 +
-    skip); t1 = relu(conv1'(y) * scale1 + shift1).  t2 (N,H,W,K1), skip (N,H,W,N1) -> (y (N,H,W,N1), t1 (N,H,W,N2))."""
+    skip); t1 = relu(conv1'(y) * scale1 + shift1).  t2 (N,H,W,K1), skip (N,H,W,N1) -> (y (N,H,W,N1), t1 (N,H,W,N2)).
+    proj=(pk_d, scale_d, shift_d): `skip` is the block's INPUT (N,H,W,K1) and the projection shortcut conv_d + bn_d is computed
+    inside the launch (tlxmi_bottleneck_seam_proj) instead of being read from a stored map."""
     need_gpu(t2, "input")
     N, H, W, ld = t2.shape
     if skip.shape[:3] != t2.shape[:3] or skip.dtype != t2.dtype or not skip.is_contiguous() or not t2.is_contiguous():
@@ -371,18 +373,26 @@ def bottleneck_seam(t2, pk3, scale3, shift3, skip, pk1, scale1, shift1):
     rows = N * H * W
     d = _lib.SeamDesc(dtype=dt_code(t2.dtype), rows=rows, K1=pk3.Cin, N1=pk3.Cout, N2=pk1.Cout, t2_ld=ld, skip_ld=skip.shape[-1],
                       y_ld=pk3.Cout, t1_ld=pk1.Cout, act=ACT_RELU)
-    args = (C.byref(d), _p(t2), _p(pk3.buf), _p(scale3), _p(shift3), _p(skip), _p(y), _p(pk1.buf), _p(scale1), _p(shift1), _p(t1), _stream())
+    if proj is None:
+        name = "tlxmi_bottleneck_seam"
+        args = (C.byref(d), _p(t2), _p(pk3.buf), _p(scale3), _p(shift3), _p(skip), _p(y), _p(pk1.buf), _p(scale1), _p(shift1), _p(t1), _stream())
+    else:
+        name = "tlxmi_bottleneck_seam_proj"
+        pkd, sd, hd = proj
+        args = (C.byref(d), _p(t2), _p(pk3.buf), _p(scale3), _p(shift3), _p(skip), _p(pkd.buf), _p(sd), _p(hd), _p(y), _p(pk1.buf), _p(scale1),
+                _p(shift1), _p(t1), _stream())
     if _probe is None:
-        _lib.call("tlxmi_bottleneck_seam", *args)
+        _lib.call(name, *args)
         return y, t1
     es = t2.element_size()
-    alg_bytes = (rows * (pk3.Cin + 2 * pk3.Cout + pk1.Cout) + pk3.Cout * pk3.Cin + pk1.Cout * pk1.Cin) * es
-    flops = 2 * rows * (pk3.Cout * pk3.Cin + pk1.Cout * pk1.Cin)
+    skip_ch = pk3.Cout if proj is None else proj[0].Cin
+    alg_bytes = (rows * (pk3.Cin + skip_ch + pk3.Cout + pk1.Cout) + pk3.Cout * pk3.Cin + pk1.Cout * pk1.Cin) * es
+    flops = 2 * rows * (pk3.Cout * pk3.Cin + pk1.Cout * pk1.Cin + (0 if proj is None else pk3.Cout * proj[0].Cin))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    _lib.call("tlxmi_bottleneck_seam", *args)
+    _lib.call(name, *args)
     e1.record()
-    _probe.append((e0, e1, alg_bytes, flops, (N, H, W, pk3.Cin, pk3.Cout, pk1.Cout, "seam", True)))
+    _probe.append((e0, e1, alg_bytes, flops, (N, H, W, pk3.Cin, pk3.Cout, pk1.Cout, "seam" if proj is None else "seam+proj", True)))
     return y, t1
 
 

@@ -94,17 +94,19 @@ class BottleneckBlock(nn.Module):
     #    conv3 needs; the caller then runs conv3 + skip + relu either alone (finish) or in ONE launch together with the
     #    next block's conv1 (E.bottleneck_seam): the wide map between two blocks is written once and not re-read.
     def run_head(self, v, t1=None):
-        """v: the block's input; t1: relu(bn1(conv1(v))) if the previous seam launch already computed it."""
+        """v: the block's input; t1: relu(bn1(conv1(v))) if the previous seam launch already computed it.  -> conv2's output."""
         out = t1 if t1 is not None else self.conv1.run_nhwc(v, self.bn1, E.ACT_RELU)
-        out = self.conv2.run_nhwc(out, self.bn2, E.ACT_RELU)
-        identity = v if self.downsample is None else self.downsample[0].run_nhwc(v, self.downsample[1])
-        return out, identity
+        return self.conv2.run_nhwc(out, self.bn2, E.ACT_RELU)
+
+    def shortcut(self, v):
+        return v if self.downsample is None else self.downsample[0].run_nhwc(v, self.downsample[1])
 
     def finish(self, out, identity):
         return self.conv3.run_nhwc(out, self.bn3, E.ACT_RELU, res=identity)
 
-    def seam_with(self, nxt, out, identity):
-        """(block output, nxt's conv1 output) in one launch, or None when there is no fused kernel for these layers."""
+    def seam_with(self, nxt, out, v):
+        """(block output, nxt's conv1 output) in one launch — `v` is the block's input, the skip or the projection shortcut's
+        source — or None when there is no fused kernel for these layers."""
         c3, c1 = self.conv3, nxt.conv1
         dt = E.precision()
         if (dt != torch.float16 or c3.n_group != 1 or c1.n_group != 1 or c1.kernel_size != (1, 1) or c1.stride != (1, 1)
@@ -115,7 +117,17 @@ class BottleneckBlock(nn.Module):
         pk1 = c1._cached("pk", lambda: E.PackedFilter(c1.filters, dt))
         s3, h3 = c3._cached(("bn", id(self.bn3)), lambda: self.bn3.folded(None), deps=(self.bn3,))
         s1, h1 = c1._cached(("bn", id(nxt.bn1)), lambda: nxt.bn1.folded(None), deps=(nxt.bn1,))
-        return E.bottleneck_seam(out, pk3, s3, h3, identity, pk1, s1, h1)
+        if self.downsample is None:
+            return E.bottleneck_seam(out, pk3, s3, h3, v, pk1, s1, h1)
+        cd, bnd = self.downsample[0], self.downsample[1]
+        if (cd.kernel_size == (1, 1) and cd.stride == (1, 1) and cd.padding == (0, 0) and cd.n_group == 1 and cd.biases is None
+                and c3.in_channels == 64 and c1.out_channels == 64 and cd.in_channels == 64 and v.shape[-1] == 64):
+            # layer1.0: the projection shortcut (1x1, stride 1, 64 channels in) is computed inside the seam launch: its 411 MB
+            # map (batch 256) is neither written nor read
+            pkd = cd._cached("pk", lambda: E.PackedFilter(cd.filters, dt))
+            sd, hd = cd._cached(("bn", id(bnd)), lambda: bnd.folded(None), deps=(bnd,))
+            return E.bottleneck_seam(out, pk3, s3, h3, v, pk1, s1, h1, proj=(pkd, sd, hd))
+        return E.bottleneck_seam(out, pk3, s3, h3, self.shortcut(v), pk1, s1, h1)
 
 
 def run_bottleneck_chain(blocks, v):
@@ -123,14 +135,14 @@ def run_bottleneck_chain(blocks, v):
     kernel (fp16; resnet.py:142-156 per block).  Falls back block by block to conv3 + skip as its own launch."""
     t1 = None
     for i, blk in enumerate(blocks):
-        out, identity = blk.run_head(v, t1)
+        out = blk.run_head(v, t1)
         t1 = None
         nxt = blocks[i + 1] if i + 1 < len(blocks) else None
-        fused = blk.seam_with(nxt, out, identity) if isinstance(nxt, BottleneckBlock) else None
+        fused = blk.seam_with(nxt, out, v) if isinstance(nxt, BottleneckBlock) else None
         if fused is not None:
             v, t1 = fused
         else:
-            v = blk.finish(out, identity)
+            v = blk.finish(out, blk.shortcut(v))
     return v
 
 

@@ -10,7 +10,7 @@ from tlxcv_amd import engine as E
 dev = torch.device("cuda:0")
 tlxcv_amd.set_precision("fp16")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-for K1, N1, N2, hw in ((64, 256, 64, 56), (64, 256, 128, 56), (128, 512, 128, 28), (128, 512, 256, 28)):
+for K1, N1, N2, hw in ((64, 256, 64, 56), (64, 256, 128, 56), (128, 512, 128, 28), (128, 512, 256, 28), (256, 1024, 256, 14)):
     g = torch.Generator().manual_seed(1)
     t2 = torch.randn((B, hw, hw, K1), generator=g).half().to(dev)
     skip = torch.randn((B, hw, hw, N1), generator=g).half().to(dev)
