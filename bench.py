@@ -224,6 +224,7 @@ def main():
     ap.add_argument("--workload", default="resnet50", choices=list(WORK))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="headline workload only (skip the ViT-B/16 and Swin-B lines)")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=0|1", help="engine.set_option(NAME, value) before building")
     ap.add_argument("--no-graph", action="store_true", help="launch kernel by kernel instead of replaying a hipGraph")
     a = ap.parse_args()
     if a.batch is None:
@@ -241,6 +242,9 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     tlxcv_amd.set_precision("fp16")
+    for o in a.option:
+        name, _, val = o.partition("=")
+        tlxcv_amd.engine.set_option(name, int(val or "1"))
 
     res, params, model = measure(a.workload, a.batch, a.steps, a.warmup, dev, rank, world, graph=not a.no_graph)
     line = {

@@ -15,6 +15,7 @@ struct SeamArgs {
     const char* wd;                    // PROJ form: packed shortcut filter [N1][K1]; `res` is then the block input [M][res_ld]
     const float *scale_d, *shift_d;
     unsigned wd_bytes;
+    int debug;                         // tuning flavour: ablation bits
 };
 
 bool block_seam_shape_ok(int K1, int N1, int N2);

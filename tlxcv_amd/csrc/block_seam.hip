@@ -23,7 +23,13 @@
 // 128-byte lines; the filters are staged through LDS per step (below).
 // Bound: HBM.  Algorithmic bytes per pixel: (K1 + 2*N1 + N2) * 2.
 #include "common.h"
+#include <stdio.h>
 #include "block_seam.h"
+#ifdef TLXMI_TUNING
+#define TLXMI_DBG_NT(x) (x)
+#else
+#define TLXMI_DBG_NT(x) (false)     // product: plain stores of y and t1 (the non-temporal forms are A/B candidates only)
+#endif
 
 namespace tlxmi {
 
@@ -59,11 +65,36 @@ static __device__ __forceinline__ int bs_f2(int r) { return (((r >> 1) & 1) << 2
 
 // K1: input channels of the expand conv (t2), N2: output channels of the reduce conv (t1); N1 (channels of y) is a
 // runtime multiple of 64.  PW: MFMA pixel blocks (16 pixels) per wave; 8 waves per workgroup.
+// relu(acc * scale + skip + shift) of 4 channels -> 4 packed halves, 2.5 VALU instructions a value: the skip enters the FMA as
+// its fp16 operand (v_fma_mix_f32), the shift is a packed fp32 add, ReLU runs on the packed halves after the one rounding
+// (max(x, 0) commutes with round-to-nearest).  One rounding to fp16, as in the two-launch path.
+static __device__ __forceinline__ unsigned bs_pkrelu(unsigned v) {
+    unsigned r;
+    asm("v_pk_max_f16 %0, %1, 0" : "=v"(r) : "v"(v));
+    return r;
+}
+static __device__ __forceinline__ u32x2 bs_bn_skip_relu4(f32x4 acc, f32x4 sc, f32x4 sh, half4v skip) {
+    f32x2 t0 = f32x2{__builtin_fmaf(acc[0], sc[0], (float)skip[0]), __builtin_fmaf(acc[1], sc[1], (float)skip[1])};
+    f32x2 t1 = f32x2{__builtin_fmaf(acc[2], sc[2], (float)skip[2]), __builtin_fmaf(acc[3], sc[3], (float)skip[3])};
+    t0 += f32x2{sh[0], sh[1]};
+    t1 += f32x2{sh[2], sh[3]};
+    const half2v p0 = half2v{(half_t)t0[0], (half_t)t0[1]}, p1 = half2v{(half_t)t1[0], (half_t)t1[1]};
+    return u32x2{bs_pkrelu(__builtin_bit_cast(unsigned, p0)), bs_pkrelu(__builtin_bit_cast(unsigned, p1))};
+}
+static __device__ __forceinline__ u32x2 bs_bn_relu4(f32x4 acc, f32x4 sc, f32x4 sh) {
+    const f32x2 t0 = f32x2{__builtin_fmaf(acc[0], sc[0], sh[0]), __builtin_fmaf(acc[1], sc[1], sh[1])};
+    const f32x2 t1 = f32x2{__builtin_fmaf(acc[2], sc[2], sh[2]), __builtin_fmaf(acc[3], sc[3], sh[3])};
+    const half2v p0 = half2v{(half_t)t0[0], (half_t)t0[1]}, p1 = half2v{(half_t)t1[0], (half_t)t1[1]};
+    return u32x2{bs_pkrelu(__builtin_bit_cast(unsigned, p0)), bs_pkrelu(__builtin_bit_cast(unsigned, p1))};
+}
+
 // PROJ: the skip is not a stored map but the projection shortcut bn_d(conv_d(xp)) of the block (resnet.py:246-261, a 1x1 conv
 // on the block's K1-channel input at stride 1: ResNet's layer1.0), computed here as a second product per step — the 411 MB
 // shortcut map is neither written nor read.
-template <int K1, int N2, int PW, int NW, bool PROJ = false>
-__global__ __launch_bounds__(64 * NW) void seam_kernel(const SeamArgs a) {
+// WPS: waves per SIMD the register budget is cut for (0: the compiler's choice — with 4-wave workgroups it spreads into the
+// AGPRs and a CU then holds ONE workgroup however little LDS it takes)
+template <int K1, int N2, int PW, int NW, bool PROJ = false, int WPS = 0>
+__global__ __launch_bounds__(64 * NW, WPS ? WPS : 1) void seam_kernel(const SeamArgs a) {
     constexpr int NT = 64 * NW;          // threads
     constexpr int IPT = 512 / NT;        // 16-byte chunks of a panel each thread stages
     constexpr int KS = K1 / 32;          // k-steps of GEMM1
@@ -163,6 +194,13 @@ __global__ __launch_bounds__(64 * NW) void seam_kernel(const SeamArgs a) {
         }
         stage_write(0, st);
     }
+#ifdef TLXMI_TUNING
+    if (a.debug >> 8) {      // experiment: the workgroup in the odd wave slot of its SIMD starts late (two workgroups of a CU out of phase)
+        const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);    // HW_ID.wave_id
+        if (slot & 1)
+            for (int i = 0; i < (a.debug >> 8); ++i) __builtin_amdgcn_s_sleep(8);
+    }
+#endif
     __syncthreads();
 
     // A-fragment addresses inside a panel: row arow + 4*ci; W3: chunk 4*h + g (h = k-step & 1); W1': chunk 2*g + s
@@ -188,8 +226,8 @@ __global__ __launch_bounds__(64 * NW) void seam_kernel(const SeamArgs a) {
         const bool more = c + 1 < nch;
         u32x4 st[NP][IPT], skn[PW][2];
         if (more) {                                   // next step's filters and skip: in flight under this step's MFMAs
-            stage_load(c + 1, st);
-            skip_load(c + 1, skn);
+            if (!TLXMI_DBG(a, 8)) stage_load(c + 1, st);
+            if (!TLXMI_DBG(a, 2)) skip_load(c + 1, skn);
         }
 
         // ---- GEMM1: 64 channels of the expand conv
@@ -198,6 +236,7 @@ __global__ __launch_bounds__(64 * NW) void seam_kernel(const SeamArgs a) {
         for (int ci = 0; ci < 4; ++ci) {
 #pragma unroll
             for (int pw = 0; pw < PW; ++pw) acc1[ci][pw] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (TLXMI_DBG(a, 16)) continue;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const u32x4 af = *reinterpret_cast<const u32x4*>(wb + (ks >> 1) * PANEL + (a1off[ci] ^ ((ks & 1) << 6)));
@@ -247,16 +286,12 @@ __global__ __launch_bounds__(64 * NW) void seam_kernel(const SeamArgs a) {
                     } else {
                         rv = __builtin_bit_cast(half8v, sk[pw][h]);
                     }
-                    half8v o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float v0 = acc1[2 * h][pw][e] * s0[e] + h0[e] + (float)rv[e];
-                        const float v1 = acc1[2 * h + 1][pw][e] * s1[e] + h1[e] + (float)rv[4 + e];
-                        o[e] = (half_t)fmaxf(v0, 0.f);
-                        o[4 + e] = (half_t)fmaxf(v1, 0.f);
-                    }
-                    yf[pw][h] = __builtin_bit_cast(u32x4, o);
-                    if (a.y_nt) bs_store16_nt(ysrd, yf[pw][h], pok[pw] ? (pix[pw] * a.y_ld + 64 * c + 16 * g + 8 * h) * 2 : OOB);
+                    const u32x2 o0 = bs_bn_skip_relu4(acc1[2 * h][pw], s0, h0, half4v{rv[0], rv[1], rv[2], rv[3]});
+                    const u32x2 o1 = bs_bn_skip_relu4(acc1[2 * h + 1][pw], s1, h1, half4v{rv[4], rv[5], rv[6], rv[7]});
+                    const u32x4 o = u32x4{o0[0], o0[1], o1[0], o1[1]};
+                    yf[pw][h] = o;
+                    if (TLXMI_DBG(a, 1)) continue;
+                    if (TLXMI_DBG_NT(a.y_nt)) bs_store16_nt(ysrd, yf[pw][h], pok[pw] ? (pix[pw] * a.y_ld + 64 * c + 16 * g + 8 * h) * 2 : OOB);
                     else bs_store16(ysrd, yf[pw][h], pok[pw] ? (pix[pw] * a.y_ld + 64 * c + 16 * g + 8 * h) * 2 : OOB);
                 }
             }
@@ -265,6 +300,7 @@ __global__ __launch_bounds__(64 * NW) void seam_kernel(const SeamArgs a) {
         // ---- GEMM2: this step's 64 channels are two k-steps of the reduce conv
 #pragma unroll
         for (int tt = 0; tt < T2; ++tt) {
+            if (TLXMI_DBG(a, 16)) continue;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const u32x4 af = *reinterpret_cast<const u32x4*>(wb + (CB + (tt >> 2)) * PANEL + (a2off[tt & 3] ^ (s << 4)));
@@ -292,24 +328,21 @@ __global__ __launch_bounds__(64 * NW) void seam_kernel(const SeamArgs a) {
             const f32x4 h0 = *reinterpret_cast<const f32x4*>(sh + 8 * h), h1 = *reinterpret_cast<const f32x4*>(sh + 8 * h + 4);
 #pragma unroll
             for (int pw = 0; pw < PW; ++pw) {
-                half8v o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    o[e] = (half_t)fmaxf(acc2[4 * q + 2 * h][pw][e] * s0[e] + h0[e], 0.f);
-                    o[4 + e] = (half_t)fmaxf(acc2[4 * q + 2 * h + 1][pw][e] * s1[e] + h1[e], 0.f);
-                }
-                if (a.z_nt) bs_store16_nt(zsrd, __builtin_bit_cast(u32x4, o), pok[pw] ? (pix[pw] * a.z_ld + 64 * q + 16 * g + 8 * h) * 2 : OOB);
-                else bs_store16(zsrd, __builtin_bit_cast(u32x4, o), pok[pw] ? (pix[pw] * a.z_ld + 64 * q + 16 * g + 8 * h) * 2 : OOB);
+                const u32x2 o0 = bs_bn_relu4(acc2[4 * q + 2 * h][pw], s0, h0), o1 = bs_bn_relu4(acc2[4 * q + 2 * h + 1][pw], s1, h1);
+                const u32x4 o = u32x4{o0[0], o0[1], o1[0], o1[1]};
+                if (TLXMI_DBG(a, 4)) continue;
+                if (TLXMI_DBG_NT(a.z_nt)) bs_store16_nt(zsrd, o, pok[pw] ? (pix[pw] * a.z_ld + 64 * q + 16 * g + 8 * h) * 2 : OOB);
+                else bs_store16(zsrd, o, pok[pw] ? (pix[pw] * a.z_ld + 64 * q + 16 * g + 8 * h) * 2 : OOB);
             }
         }
     }
 }
 
-template <int K1, int N2, int PW, int NW, bool PROJ = false> static int launch_seam_t(const SeamArgs& a, hipStream_t st) {
+template <int K1, int N2, int PW, int NW, bool PROJ = false, int WPS = 0> static int launch_seam_t(const SeamArgs& a, hipStream_t st) {
     constexpr int NP = K1 / 64 + N2 / 64 + (PROJ ? K1 / 64 : 0);
     const size_t lds = (size_t)2 * NP * 64 * 128 + (size_t)(2 * a.N1 + 2 * N2 + (PROJ ? 2 * a.N1 : 0)) * sizeof(float);
     if (lds > 160 * 1024) return fail(TLXMI_ERR_UNSUPPORTED, "block_seam: %zu bytes of LDS", lds);
-    const void* fn = reinterpret_cast<const void*>(&seam_kernel<K1, N2, PW, NW, PROJ>);
+    const void* fn = reinterpret_cast<const void*>(&seam_kernel<K1, N2, PW, NW, PROJ, WPS>);
     if (lds > 64 * 1024) {
         static bool raised = false;
         if (!raised) {
@@ -320,6 +353,13 @@ template <int K1, int N2, int PW, int NW, bool PROJ = false> static int launch_s
     }
     const long grid = ((long)a.M + NW * 16 * PW - 1) / (NW * 16 * PW);
     if (grid >= (1l << 31)) return fail(TLXMI_ERR_UNSUPPORTED, "block_seam: too many rows");
+#ifdef TLXMI_TUNING
+    if (tune_int("TLXMI_SEAM_OCC", 0)) {
+        int nb = -1;
+        hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64 * NW, lds);
+        fprintf(stderr, "seam<%d,%d,%d,%d,%d>: lds %zu, grid %ld, occupancy %d workgroups / CU (%s)\n", K1, N2, PW, NW, (int)PROJ, lds, grid, nb, hipGetErrorString(oe));
+    }
+#endif
     SeamArgs b = a;
     void* args[] = {&b};
     hipError_t e = hipLaunchKernel(fn, dim3((unsigned)grid), dim3(64 * NW), args, lds, st);
@@ -338,10 +378,16 @@ int launch_block_seam(const SeamArgs& a0, int K1, int N2, hipStream_t st) {
     SeamArgs b = a0;
     b.z_nt = (vv & 2) ? 1 : 0;        // t1 is small and read back at once by the next conv: a plain store keeps it in the Infinity Cache (-124 us per ResNet-50 forward vs nt)
     b.y_nt = (vv & 4) ? 1 : 0;
+    b.debug = (int)tune_int("TLXMI_SEAM_DBG", 0);      // ablation bits (tuning flavour only; see the kernel)
     const SeamArgs& a = b;
     if (a.wd) {
         if (K1 == 64 && N2 == 64) return launch_seam_t<64, 64, 2, 4, true>(a, st);
         return fail(TLXMI_ERR_UNSUPPORTED, "block_seam: the projection-shortcut form is compiled for 64 -> N1 -> 64 channels");
+    }
+    if (vv & 16) {      // A/B: 4-wave workgroups with the register budget of 2 / 3 waves per SIMD (2 / 3 workgroups per CU)
+        if (K1 == 64 && N2 == 64) return launch_seam_t<64, 64, 2, 4, false, 3>(a, st);
+        if (K1 == 64 && N2 == 128) return launch_seam_t<64, 128, 2, 4, false, 3>(a, st);
+        if (K1 == 128 && N2 == 128) return launch_seam_t<128, 128, 2, 4, false, 2>(a, st);
     }
     if (K1 == 64 && N2 == 64) return v ? launch_seam_t<64, 64, 2, 8>(a, st) : launch_seam_t<64, 64, 2, 4>(a, st);
     if (K1 == 64 && N2 == 128) return v ? launch_seam_t<64, 128, 2, 8>(a, st) : launch_seam_t<64, 128, 2, 4>(a, st);

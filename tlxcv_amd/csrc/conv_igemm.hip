@@ -675,7 +675,7 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
     else if (obi >= 0.0015) { cands[0].eff = 0.85f; cands[1].eff = 0.90f; cands[2].eff = 1.00f; cands[3].eff = 0.90f; }
     if (!allow_stream) cands[7].eff = cands[8].eff = 0.f;
     // the persistent kernel hides the plain epilogue but not the GELU arithmetic (measured: fc1 of ViT-B)
-    if (a.act == TLXMI_ACT_GELU) cands[8].eff = 0.f;
+    if (a.act == TLXMI_ACT_GELU && !tune_int("TLXMI_GELU_STREAM", 0)) cands[8].eff = 0.f;
     // One workgroup per CU: the last round of a 256x256 launch runs a whole tile time however few tiles it
     // has.  When it would be at most half full, the rows of the full rounds go to the 256x256 kernel and the
     // remaining rows to a second launch of the same kernel on 128x256 tiles (gemm_pp128): twice the tiles, about

@@ -20,7 +20,8 @@ _precision = torch.float16
 # Host-side A/B switches (tools/ only; no environment variable is read on the product path).
 _options = {"splitk": True,       # classifier heads: K slices side by side (tlxmi_linear_splitk)
             "lnfuse": False,      # LayerNorm folded into the next Linear (tlxmi_linear_ln): measured neutral, off
-            "attn_comb": True}    # Swin attention with the pre-summed bias + mask table (tlxmi_attention_comb)
+            "attn_comb": True,    # Swin attention with the pre-summed bias + mask table (tlxmi_attention_comb)
+            "seam256": True}      # bottleneck seams with a 256-channel conv3 input (ResNet-50 layer3, 14 x 14) fused too
 
 
 def set_option(name, value):

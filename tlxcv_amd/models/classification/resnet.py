@@ -111,7 +111,8 @@ class BottleneckBlock(nn.Module):
         dt = E.precision()
         if (dt != torch.float16 or c3.n_group != 1 or c1.n_group != 1 or c1.kernel_size != (1, 1) or c1.stride != (1, 1)
                 or c1.padding != (0, 0) or c3.biases is not None or c1.biases is not None
-                or not E.bottleneck_seam_supported(c3.in_channels, c3.out_channels, c1.out_channels, dt)):
+                or not E.bottleneck_seam_supported(c3.in_channels, c3.out_channels, c1.out_channels, dt)
+                or (c3.in_channels >= 256 and not E.option("seam256"))):
             return None
         pk3 = c3._cached("pk", lambda: E.PackedFilter(c3.filters, dt))
         pk1 = c1._cached("pk", lambda: E.PackedFilter(c1.filters, dt))
