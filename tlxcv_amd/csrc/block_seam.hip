@@ -389,6 +389,8 @@ int launch_block_seam(const SeamArgs& a0, int K1, int N2, hipStream_t st) {
         if (K1 == 64 && N2 == 128) return launch_seam_t<64, 128, 2, 4, false, 3>(a, st);
         if (K1 == 128 && N2 == 128) return launch_seam_t<128, 128, 2, 4, false, 2>(a, st);
     }
+    // (64 -> 256 -> 64 with the register budget of 3 waves per SIMD — three workgroups a CU instead of two — is 224 -> 210 us in
+    //  the micro-benchmark and nothing in the ResNet-50 forward, 3.76 vs 3.78 ms: the compiler's choice stays)
     if (K1 == 64 && N2 == 64) return v ? launch_seam_t<64, 64, 2, 8>(a, st) : launch_seam_t<64, 64, 2, 4>(a, st);
     if (K1 == 64 && N2 == 128) return v ? launch_seam_t<64, 128, 2, 8>(a, st) : launch_seam_t<64, 128, 2, 4>(a, st);
     // (measured, batch 256: 56 x 56 seams 226 / 268 us with 4 waves vs 233 / 288 with 8; 28 x 28 seams 153 / 194 us with 8 waves
