@@ -25,10 +25,12 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
                 continue
             s += float(row["Counter_Value"]); k += 1      # every kernel of the run: all of them are forwards of the model
             if "to_nhwc_s2d" in row["Kernel_Name"]:
-                f += 1          # exactly one layout transform per forward: counts the forwards of the run
+                f += 1          # one layout transform per forward and stream: counts the forwards of the run
     tot[c] = s; n[c] = k; fwd[c] = f
-forwards = max(fwd["FETCH_SIZE"], 1)
-fetch_kb, write_kb = tot["FETCH_SIZE"] / forwards, tot["WRITE_SIZE"] / max(fwd["WRITE_SIZE"], 1)
+# ResNet-50 (batch 256) and Swin-B (batch 128) run as two half batches on two streams (engine.two_streams): two transforms a forward
+parts = 2 if wl in ("resnet50", "swin_b") else 1
+forwards = max(fwd["FETCH_SIZE"] // parts, 1)
+fetch_kb, write_kb = tot["FETCH_SIZE"] / forwards, tot["WRITE_SIZE"] / max(fwd["WRITE_SIZE"] // parts, 1)
 res = {"workload": wl, "kernel": "every kernel of a forward", "csrc_sha": bench.csrc_sha(),
        "forwards": forwards, "kernel_launches_per_forward": n["FETCH_SIZE"] / forwards,
        "FETCH_SIZE_KB_raw_per_forward": fetch_kb, "WRITE_SIZE_KB_per_forward": write_kb,
