@@ -1,0 +1,103 @@
+"""engine.two_streams / run_halves: a large batch as two half batches on two HIP streams gives, row for row, what
+each half gives alone; below the threshold, with the option off, on host tensors or with extra arguments nothing is split."""
+import numpy as np
+import pytest
+import torch
+
+import tlxcv_amd
+from tlxcv_amd import engine as E, models, seeded
+
+
+class _Probe:
+    calls = []
+
+    @E.two_streams(4)
+    def forward(self, x, *args):
+        _Probe.calls.append(tuple(x.shape))
+        return x.float().mean(dim=(1, 2, 3), keepdim=False).view(-1, 1) * 2
+
+
+def test_decorator_host_logic_passes_everything_through_that_is_not_a_large_cuda_batch():
+    p = _Probe()
+    _Probe.calls.clear()
+    x = torch.arange(8 * 3 * 2 * 2, dtype=torch.float32).view(8, 3, 2, 2)
+    y = p.forward(x)                                   # host tensor: no split (and no CUDA call)
+    assert _Probe.calls == [(8, 3, 2, 2)] and y.shape == (8, 1)
+    assert p.forward.__name__ == "forward"
+
+
+
+
+@pytest.mark.gpu
+def test_split_rules_on_the_device():
+    dev = torch.device("cuda:0")
+    p = _Probe()
+    x = torch.randn((8, 3, 4, 4), device=dev)
+    _Probe.calls.clear()
+    y = p.forward(x)
+    assert _Probe.calls == [(4, 3, 4, 4), (4, 3, 4, 4)]                 # two halves
+    assert torch.equal(y, x.float().mean(dim=(1, 2, 3)).view(-1, 1) * 2)
+    for xx, why in ((x[:2], "below the threshold"), (x[:7], "odd batch")):
+        _Probe.calls.clear()
+        p.forward(xx)
+        assert _Probe.calls == [tuple(xx.shape)], why
+    _Probe.calls.clear()
+    p.forward(x, 1)                                                     # extra arguments: the plain call
+    assert _Probe.calls == [(8, 3, 4, 4)]
+    E.set_option("two_streams", False)
+    try:
+        _Probe.calls.clear()
+        p.forward(x)
+        assert _Probe.calls == [(8, 3, 4, 4)]
+    finally:
+        E.set_option("two_streams", True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+def test_resnet50_batch_128_in_two_halves_equals_the_halves_alone(prec):
+    dev = torch.device("cuda:0")
+    tlxcv_amd.set_precision(prec)
+    try:
+        m = models.resnet50()
+        m.load_dict(seeded.fill(seeded.shapes_of(m), 1))
+        m = m.to(dev).set_eval()
+        x = torch.from_numpy(seeded.image_batch(32, 0)).to(dev).repeat(4, 1, 1, 1).contiguous()
+        x[64:] = x[64:].flip(3)                                          # the halves differ
+        y = m(x)                                                         # 128 images: split
+        E.set_option("two_streams", False)
+        try:
+            y0, y1 = m(x[:64]), m(x[64:])
+            whole = m(x)                                                 # one launch sequence over all 128
+        finally:
+            E.set_option("two_streams", True)
+        torch.cuda.synchronize()
+        assert torch.equal(y[:64], y0) and torch.equal(y[64:], y1)
+        # against the unsplit forward: the dispatcher may pick other tiles for 128 rows than for 64 — same values to rounding
+        tol = 1e-4 if prec == "fp32" else 3e-3
+        scale = max(1.0, float(whole.float().abs().max()))
+        assert float((y.float() - whole.float()).abs().max()) <= tol * scale
+        assert torch.equal(y.float().argmax(1), whole.float().argmax(1)) or prec == "fp16"
+    finally:
+        tlxcv_amd.set_precision("fp32")
+
+
+@pytest.mark.gpu
+def test_two_streams_inside_a_captured_graph():
+    from tlxcv_amd.graph import GraphedForward
+    dev = torch.device("cuda:0")
+    tlxcv_amd.set_precision("fp16")
+    try:
+        m = models.resnet50()
+        m.load_dict(seeded.fill(seeded.shapes_of(m), 1))
+        m = m.to(dev).set_eval()
+        x = torch.from_numpy(seeded.image_batch(32, 0)).to(dev).repeat(4, 1, 1, 1).contiguous()
+        want = m(x).clone()
+        g = GraphedForward(m, x.clone(), warmup=2)
+        got = g(x).clone()
+        got2 = g(x.flip(0).contiguous()).clone()
+        torch.cuda.synchronize()
+        assert torch.equal(got, want)
+        assert torch.equal(got2, want.flip(0))
+    finally:
+        tlxcv_amd.set_precision("fp32")

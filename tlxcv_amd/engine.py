@@ -115,21 +115,34 @@ def to_model_device(inputs, model):
 # batch 128 9.14 -> 8.60 ms, VGG-16 batch 64 2.75 -> 2.63 ms, ViT-B/16 batch 256 unchanged (not applied there).  The halves are
 # independent (eval-mode forward, no batch statistics): the result is the concatenation, row for row what the halves give alone.
 _side_streams = {}
+_cache_builds = 0
+
+
+def note_cache_build():
+    """A layer built a derived tensor (packed filter, folded BatchNorm, bias / mask table) just now, on the current stream."""
+    global _cache_builds
+    _cache_builds += 1
 
 
 def run_halves(fn, x):
-    """fn(first half) on the current stream, fn(second half) on the device's side stream, joined; returns the concatenation."""
+    """fn(first half) on the current stream, fn(second half) on the device's side stream, joined; returns the concatenation.
+    Derived tensors are built lazily on whichever stream asks first, and the other stream would read them unordered: when a
+    build happened during the call (first forward, new weights, new precision) the streams are joined and the forward is
+    done again in one piece — every later call finds the caches built."""
     cur = torch.cuda.current_stream(x.device)
     idx = x.device.index if x.device.index is not None else torch.cuda.current_device()
     side = _side_streams.get(idx)
     if side is None:
         side = _side_streams[idx] = torch.cuda.Stream(device=x.device)
     n = x.shape[0] // 2
+    builds = _cache_builds
     side.wait_stream(cur)                         # x is ready for the side stream
+    y0 = fn(x[:n])                                # (first: lazy builds land on the caller's stream)
     with torch.cuda.stream(side):
         y1 = fn(x[n:])
-    y0 = fn(x[:n])
     cur.wait_stream(side)
+    if _cache_builds != builds:
+        return fn(x)
     y1.record_stream(cur)
     return torch.cat((y0, y1), 0)
 

@@ -263,6 +263,7 @@ class Module(torch.nn.Module):
         if hit is not None and hit[0] == stamp:
             return hit[1]
         v = build()
+        E.note_cache_build()       # built on the current stream: run_halves() redoes a forward during which this happened
         self._engine_cache[k] = (stamp, v)
         return v
 
