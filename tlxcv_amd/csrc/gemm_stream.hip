@@ -23,7 +23,7 @@
 // Layout of a K tile in LDS, wave->quadrant map, fragment reads, channel permutation: gemm_pp.hip.
 //
 // In-order VMEM sequence of one wave around a tile boundary (L = last K tile of a tile; D = 2 DMA pieces,
-// S = the stores of a quadrant (8 for fp16, 16 for fp32), T = 2 table pieces, 3 with row statistics), and the counted waits:
+// S = the stores of a quadrant (32 outputs per lane: 4 x 16 B for fp16, 8 for fp32), T = 2 table pieces, 3 with row statistics), and the counted waits:
 //     p0(L)   D W1(L+1)                        wait W1(L)          : 8
 //     p1(L)   D X1(L+1), S00                   wait X1(L)          : 8 + S
 //     p2(L)   D X0(L+2), T, S01
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
     constexpr int TABLE = 8 * HALF;            // two tables of 8 x 256 B behind the two K tiles
     constexpr int OOB = (int)0x80000000;
     constexpr int ROWTAB = TABLE + 2 * 2048;   // two tables of 256 rows x (a, b) behind the channel tables
-    constexpr int S = ES == 2 ? 8 : 16, R = ES, TT = ROWAFF ? 3 : 2;   // R: loads of one residual step (2 pixel rows x 8 channels per lane)
+    constexpr int S = ES == 2 ? 4 : 8, R = ES, TT = ROWAFF ? 3 : 2;   // R: loads of one residual step (2 pixel rows x 8 channels per lane)
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int t = threadIdx.x, lane = t & 63;
