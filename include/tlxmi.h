@@ -76,6 +76,12 @@ int tlxmi_version(void);
 const char* tlxmi_last_error(void);
 /* Number of visible HIP devices whose gcnArchName starts with "gfx950"; <0 on HIP error. */
 int tlxmi_device_count(void);
+/* Tile planning of tlxmi_conv2d / tlxmi_linear for launches that will share the device: the dispatcher prices workgroup
+ * rounds for `cus` compute units instead of the device's (a caller running two half batches on two streams passes half:
+ * fewer, larger tiles per launch, the other stream's launches fill the rest).  0 restores the device's count.  Affects
+ * the choice of tile only, never results beyond the summation order of a tile shape; process-wide, returns the previous
+ * value.  (The reference has no counterpart: TensorLayerX's backends pick their own launch shapes.) */
+int tlxmi_set_plan_cus(int cus);
 
 /* ------------------------------------------------------------------------------------------
  * Layout conversion at the model boundary.

@@ -97,6 +97,7 @@ _SPECIAL = {
     "tlxmi_version": ([], C.c_int),
     "tlxmi_last_error": ([], C.c_char_p),
     "tlxmi_device_count": ([], C.c_int),
+    "tlxmi_set_plan_cus": ([_i], C.c_int),
     "tlxmi_packed_filter_bytes": ([_i, _i, _i, _i, _i], C.c_size_t),
     "tlxmi_packed_group_filter_bytes": ([_i, _i, _i, _i, _i, _i], C.c_size_t),
     "tlxmi_group_conv_chunks": ([_i, _i, _i, _i], C.c_int),

@@ -509,6 +509,7 @@ __global__ __launch_bounds__(WGM * 128) void conv_igemm_kernel(const ConvArgs a0
     }
 }
 
+static int g_plan_cus = 0;      // tlxmi_set_plan_cus: CU count the tile choice is priced for (0: the device's)
 static int g_num_cus = 0;
 static int num_cus() {
     if (g_num_cus == 0) {
@@ -681,7 +682,8 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
     // remaining rows to a second launch of the same kernel on 128x256 tiles (gemm_pp128): twice the tiles, about
     // 0.6 of the time, still one round (tail split, below).
     const long t256 = (long)((a.M + 255) / 256) * ((a.Cout + 255) / 256);
-    const int cus = num_cus();
+    // tlxmi_set_plan_cus (tuning flavour: TLXMI_PLAN_CUS too): the launch will share the device with another stream's
+    const int cus = tune_int("TLXMI_PLAN_CUS", 0) > 0 ? (int)tune_int("TLXMI_PLAN_CUS", 0) : g_plan_cus > 0 ? g_plan_cus : num_cus();
     const long full_rounds = t256 / cus;
     // TLXMI_TAIL (A/B): 0 no split, 1 small tiles only (4 * left <= CUs), default: 128 x 256 tiles (2 * left <= CUs)
     const int tail_mode = (int)tune_int("TLXMI_TAIL", 2);
@@ -921,6 +923,12 @@ extern "C" int tlxmi_conv2d(const tlxmi_conv2d_desc* d, const void* x, const voi
                             const float* scale, const float* shift, const void* res, void* y,
                             void* stream) {
     return conv2d_impl(d, 1, x, w_packed, scale, shift, res, y, stream);
+}
+
+extern "C" int tlxmi_set_plan_cus(int cus) {
+    const int prev = g_plan_cus;
+    g_plan_cus = cus > 0 ? cus : 0;
+    return prev;
 }
 
 extern "C" int tlxmi_conv2d_maxpool_supported(const tlxmi_conv2d_desc* d) {

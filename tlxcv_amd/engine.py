@@ -124,31 +124,42 @@ def note_cache_build():
     _cache_builds += 1
 
 
-def run_halves(fn, x):
+def run_halves(fn, x, plan_half=False):
     """fn(first half) on the current stream, fn(second half) on the device's side stream, joined; returns the concatenation.
     Derived tensors are built lazily on whichever stream asks first, and the other stream would read them unordered: when a
     build happened during the call (first forward, new weights, new precision) the streams are joined and the two halves are
-    done again — the same launches every later call makes, so the first result equals the later ones bit for bit."""
+    done again — the same launches every later call makes, so the first result equals the later ones bit for bit.
+    plan_half: the conv / linear dispatcher prices its tiles for half the CUs while the halves are enqueued
+    (tlxmi_set_plan_cus): ResNet-50 batch 256 -2 % (larger tiles per launch), Swin-B +3 % (not used there)."""
     cur = torch.cuda.current_stream(x.device)
     idx = x.device.index if x.device.index is not None else torch.cuda.current_device()
     side = _side_streams.get(idx)
     if side is None:
         side = _side_streams[idx] = torch.cuda.Stream(device=x.device)
     n = x.shape[0] // 2
-    for _ in range(3):
-        builds = _cache_builds
-        side.wait_stream(cur)                     # x is ready for the side stream (and: a redo starts after everything before it)
-        y0 = fn(x[:n])                            # (first: lazy builds land on the caller's stream)
-        with torch.cuda.stream(side):
-            y1 = fn(x[n:])
-        cur.wait_stream(side)
-        if _cache_builds == builds:
-            y1.record_stream(cur)
-            return torch.cat((y0, y1), 0)
+    lib = _lib.load()
+    if plan_half:
+        if idx not in _cus:
+            _cus[idx] = torch.cuda.get_device_properties(idx).multi_processor_count
+        prev = lib.tlxmi_set_plan_cus(_cus[idx] // 2)
+    try:
+        for _ in range(3):
+            builds = _cache_builds
+            side.wait_stream(cur)                 # x is ready for the side stream (and: a redo starts after everything before it)
+            y0 = fn(x[:n])                        # (first: lazy builds land on the caller's stream)
+            with torch.cuda.stream(side):
+                y1 = fn(x[n:])
+            cur.wait_stream(side)
+            if _cache_builds == builds:
+                y1.record_stream(cur)
+                return torch.cat((y0, y1), 0)
+    finally:
+        if plan_half:
+            lib.tlxmi_set_plan_cus(prev)
     return fn(x)
 
 
-def two_streams(min_batch):
+def two_streams(min_batch, plan_half=False):
     """Decorator of a model's forward(self, x): batches of at least `min_batch` (even) images run as run_halves()."""
     def deco(fwd):
         import functools
@@ -157,7 +168,7 @@ def two_streams(min_batch):
         def wrapper(self, x, *args, **kwargs):
             if (_options["two_streams"] and not args and not kwargs and isinstance(x, torch.Tensor) and x.is_cuda
                     and x.dim() == 4 and x.shape[0] >= min_batch and x.shape[0] % 2 == 0 and _probe is None):
-                return run_halves(lambda h: fwd(self, h), x)
+                return run_halves(lambda h: fwd(self, h), x, plan_half)
             return fwd(self, x, *args, **kwargs)
         return wrapper
     return deco
