@@ -27,6 +27,7 @@
 // chunk (l&7) ^ ((r>>1)&7) of its row.  Pieces are dealt to waves so that this chunk index is
 // the same for every piece a lane loads (one im2col position per lane per step).
 #include "common.h"
+#include <stdio.h>
 #include "gemm256.h"
 #include "conv_halo.h"
 #include <stdlib.h>
@@ -686,7 +687,9 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
     const int cus = tune_int("TLXMI_PLAN_CUS", 0) > 0 ? (int)tune_int("TLXMI_PLAN_CUS", 0) : g_plan_cus > 0 ? g_plan_cus : num_cus();
     const long full_rounds = t256 / cus;
     // TLXMI_TAIL (A/B): 0 no split, 1 small tiles only (4 * left <= CUs), default: 128 x 256 tiles (2 * left <= CUs)
-    const int tail_mode = (int)tune_int("TLXMI_TAIL", 2);
+    // (a shared device, tlxmi_set_plan_cus: no tail splits — the other stream's launches fill a short last round, the extra
+    //  launches only cost: ResNet-50 batch 256 in two halves 3.70 -> 3.59 ms)
+    const int tail_mode = (int)tune_int("TLXMI_TAIL", g_plan_cus > 0 ? 0 : 2);
     const bool tail_split = gemm256_ok && allow_split && tail_mode != 0 && full_rounds >= 1 && (t256 % cus) != 0 &&
                             (tail_mode == 1 ? 4 : 2) * (t256 % cus) <= cus;
     int best = 0;
@@ -722,6 +725,11 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
     if (forced >= 0 && forced < NC && !(cands[forced].bn == 128 && a.Cout <= 64) &&
         (forced < 5 || (forced <= 9 && gemm256_ok) || ((forced == 7 || forced == 9) && pp_conv_ok) ||
          (forced == 10 && (pp_conv128_ok || gemm128_ok)))) best = forced;
+#ifdef TLXMI_TUNING
+    if (tune_int("TLXMI_TRACE_TILES", 0))
+        fprintf(stderr, "tile M=%d K=%d N=%d R=%d s=%d res=%d plan_cus=%d -> cand %d (%dx%d)\n", a.M, a.C * a.R * a.S, a.Cout, a.R, a.sh, a.res ? 1 : 0, cus, best,
+                cands[best].bm, cands[best].bn);
+#endif
     if ((best == 7 || best >= 9) && as_conv && allow_split && tail_mode != 0) {
         // Image-axis tail split: one workgroup per CU, so a last round with few tiles costs a whole tile time.  The
         // images whose rows fill the whole rounds stay on this kernel; the last few images are a convolution of their
