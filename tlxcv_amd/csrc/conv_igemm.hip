@@ -726,6 +726,17 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
         (forced < 5 || (forced <= 9 && gemm256_ok) || ((forced == 7 || forced == 9) && pp_conv_ok) ||
          (forced == 10 && (pp_conv128_ok || gemm128_ok)))) best = forced;
 #ifdef TLXMI_TUNING
+    // TLXMI_FORCE="M:K:N:R:s=cand,...": force a candidate for one layer shape (tools/tile_search.py)
+    if (const char* fs = getenv("TLXMI_FORCE")) {
+        char key[96];
+        snprintf(key, sizeof key, "%d:%d:%d:%d:%d=", a.M, a.C * a.R * a.S, a.Cout, a.R, a.sh);
+        const char* hit = strstr(fs, key);
+        if (hit && (hit == fs || hit[-1] == ',')) {
+            const int f = atoi(hit + strlen(key));
+            if (f >= 0 && f < NC && !(cands[f].bn == 128 && a.Cout <= 64) && (f != 4 || a.ktiles >= 4) &&
+                (f < 5 || (f <= 9 && gemm256_ok) || ((f == 7 || f == 9) && pp_conv_ok) || (f == 10 && (pp_conv128_ok || gemm128_ok)))) best = f;
+        }
+    }
     if (tune_int("TLXMI_TRACE_TILES", 0))
         fprintf(stderr, "tile M=%d K=%d N=%d R=%d s=%d res=%d plan_cus=%d -> cand %d (%dx%d)\n", a.M, a.C * a.R * a.S, a.Cout, a.R, a.sh, a.res ? 1 : 0, cus, best,
                 cands[best].bm, cands[best].bn);
