@@ -1,5 +1,5 @@
 #!/bin/bash
-# Host side, after `gpurun -- bash tools/refresh_profiles.sh` (and `tools/gpu_ci.sh bench benchvit benchswin`): copy the
+# Host side, after `gpurun -- bash tools/refresh_profiles.sh` (and `tools/gpu_ci.sh bench`): copy the
 # summaries to be judged from the scratch gpurun_out/ into profiles/<round>/.  gpurun MERGES into gpurun_out/, so older
 # rocprof run directories may still be there: always take the newest file.
 set -u
@@ -16,6 +16,6 @@ for wl in resnet50 vit_b16 swin_b; do
 done
 if [ -f gpurun_out/bench.log ]; then
   : > profiles/$R/bench_lines.jsonl
-  for f in bench benchvit benchswin; do grep '^{"metric"' gpurun_out/$f.log >> profiles/$R/bench_lines.jsonl; done
+  grep '^{"metric"' gpurun_out/bench.log >> profiles/$R/bench_lines.jsonl     # the default run: ResNet-50 + also[ViT-B/16, Swin-B]
 fi
 ls -la profiles/$R
