@@ -101,3 +101,30 @@ def test_two_streams_inside_a_captured_graph():
         assert torch.equal(got2, want.flip(0))
     finally:
         tlxcv_amd.set_precision("fp32")
+
+
+@pytest.mark.gpu
+def test_plan_cus_changes_tiles_not_results():
+    """tlxmi_set_plan_cus (include/tlxmi.h): process-wide, returns the previous value; a layer planned for half the CUs
+    gives the same values to fp16 rounding (another tile shape, another summation order at most)."""
+    from tlxcv_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    tlxcv_amd.set_precision("fp16")
+    try:
+        g = torch.Generator().manual_seed(3)
+        x = torch.randn((32, 14, 14, 256), generator=g).half().to(dev)
+        pk = E.PackedFilter((torch.randn((256, 256, 3, 3), generator=g) * (2 / 2304) ** 0.5).to(dev), torch.float16)
+        assert lib.tlxmi_set_plan_cus(0) == 0
+        y_full = E.conv2d(x, pk, 1, 1, 1, None, None, None, E.ACT_RELU)
+        assert lib.tlxmi_set_plan_cus(128) == 0
+        try:
+            y_half = E.conv2d(x, pk, 1, 1, 1, None, None, None, E.ACT_RELU)
+        finally:
+            assert lib.tlxmi_set_plan_cus(0) == 128
+        assert lib.tlxmi_set_plan_cus(-5) == 0 and lib.tlxmi_set_plan_cus(0) == 0      # negative values mean "the device's"
+        torch.cuda.synchronize()
+        scale = float(y_full.float().abs().max())
+        assert float((y_full.float() - y_half.float()).abs().max()) <= 2e-3 * scale
+    finally:
+        tlxcv_amd.set_precision("fp32")
