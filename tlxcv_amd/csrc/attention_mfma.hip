@@ -331,8 +331,17 @@ __global__ __launch_bounds__(256) void attn_win_kernel(const AttnArgs a, const i
 
     const int vlane = (4 * g + (li >> 2)) * SR + (li & 3) * 8;
     const int klane = li * SR + g * 16;
-    fetch(blockIdx.x);
-    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    // Item order of a workgroup.  With hd = 32 a token's 128-byte line holds the q (k, v) rows of TWO adjacent heads: a workgroup
+    // takes head pairs — items 2p, 2p + 1 back to back, p = blockIdx, blockIdx + grid, ... — so that the second head finds the
+    // line in this CU's cache; with one item per workgroup the two halves went to workgroups on different XCDs (two L2s fetched
+    // every line).  G = 1: item = blockIdx + n * grid.
+    constexpr int G = HD == 32 ? 2 : 1;
+    auto item_at = [&](int n) -> int {
+        if (G == 1 || (heads & 1)) return (int)blockIdx.x + n * (int)gridDim.x;
+        return 2 * ((int)blockIdx.x + (n >> 1) * (int)gridDim.x) + (n & 1);
+    };
+    fetch(item_at(0));
+    for (int n = 0, item = item_at(0); item < nitems; item = item_at(++n)) {
         // ---- this item's K / V rows from the prefetch registers to LDS (zero rows for padded keys)
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
@@ -350,7 +359,7 @@ __global__ __launch_bounds__(256) void attn_win_kernel(const AttnArgs a, const i
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) tb[kt] = treg[kt];
         __syncthreads();
-        fetch(item + gridDim.x);       // travels while this item computes
+        fetch(item_at(n + 1));         // travels while this item computes
 
         if (wv < nqt) {
             const int b = item / heads, h = item - b * heads;
@@ -445,7 +454,8 @@ template <int HD, int NT, int KF> static int launch_win_kf(const AttnArgs& a, hi
         cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
     }
     const long nitems = (long)a.B * a.heads;
-    const long grid = nitems < (long)cus * 6 ? nitems : (long)cus * 6;
+    const long units = (HD == 32 && !(a.heads & 1)) ? nitems / 2 : nitems;      // head pairs (kernel: item_at)
+    const long grid = units < (long)cus * 6 ? units : (long)cus * 6;
     hipLaunchKernelGGL((attn_win_kernel<HD, NT, KF>), dim3((unsigned)grid), dim3(256), lds, st, a, (int)nitems);
     return check_launch("attention(windows)");
 }
