@@ -122,12 +122,34 @@ def measure(workload, batch, steps, warmup, dev, rank, world, graph=True, probe_
         r2, w2, _ = D.init()
         assert (r2, w2) == (rank, world)
 
+    # N > 1: the all-gather of step i runs on RCCL's stream under the forward of step i + 1 (dist.GatherPipe); every step's
+    # gather is complete inside the timed region (fence() flushes the last one before the barrier)
+    pipe = D.GatherPipe() if world > 1 else None
+    last = [None]
+    pipe_ok = [True]
+
     def step():
         y = fwd(x) if fwd is model else fwd()
-        return D.all_gather_logits(y) if world > 1 else y
+        if pipe is None:
+            return y
+        if pipe_ok[0]:
+            try:
+                g = pipe.put(y)
+            except Exception as e:                      # an RCCL build without async all_gather_into_tensor: gather in step
+                print(f"[bench] GatherPipe unavailable ({e!r}); synchronous all-gather per step", file=sys.stderr, flush=True)
+                pipe_ok[0] = False
+                g = D.all_gather_logits(y)
+        else:
+            g = D.all_gather_logits(y)
+        if g is not None:
+            last[0] = g
+        return y
 
     def fence():
         if world > 1:
+            g = pipe.flush()
+            if g is not None:
+                last[0] = g
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -147,6 +169,9 @@ def measure(workload, batch, steps, warmup, dev, rank, world, graph=True, probe_
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert torch.isfinite(y.float()).all(), "non-finite logits"
+    if world > 1:
+        assert last[0] is not None and last[0].shape[0] == batch * world and torch.isfinite(last[0].float()).all(), "gathered logits"
+        assert torch.equal(last[0][rank * batch:(rank + 1) * batch].to(y.device), y), "this rank's rows of the gathered logits"
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
     median_ms = per_step[steps // 2] if steps % 2 else 0.5 * (per_step[steps // 2 - 1] + per_step[steps // 2])
     ms_per_step = 1e3 * dt / steps

@@ -98,3 +98,55 @@ def test_shard_bounds_cover_exactly():
             spans = [shard_bounds(n, r, w) for r in range(w)]
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+
+def _worker_pipe(rank, world, port, q):
+    """dist.GatherPipe: step i's gather is returned by put() of step i + 1 (flush() gives the last); the staged copy
+    protects a source buffer that the next step overwrites in place (a replayed hipGraph's static output)."""
+    sys.path.insert(0, REPO)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from tlxcv_amd import dist as D
+    D.init(backend="gloo")
+    pipe = D.GatherPipe()
+    static = torch.empty((3, 4), dtype=torch.float32)          # rewritten in place every step
+    got = []
+    steps = 5
+    for i in range(steps):
+        static.copy_(torch.full((3, 4), float(100 * i + rank)))
+        g = pipe.put(static)
+        assert (g is None) == (i == 0)
+        if g is not None:
+            got.append(g.clone())
+    got.append(pipe.flush().clone())
+    assert pipe.flush() is None
+    ok = len(got) == steps
+    for i, g in enumerate(got):
+        want = torch.cat([torch.full((3, 4), float(100 * i + r)) for r in range(world)], 0)
+        ok = ok and bool(torch.equal(g, want))
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gather_pipeline_overlaps_steps_without_mixing_them():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_pipe, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert sorted(r for r, _ in res) == [0, 1] and all(ok for _, ok in res), res
+
+
+def test_gather_pipe_without_a_process_group_is_a_one_step_delay():
+    from tlxcv_amd import dist as D
+    pipe = D.GatherPipe()
+    a, b = torch.ones(2, 3), torch.zeros(2, 3)
+    assert pipe.put(a) is None
+    assert pipe.put(b) is a
+    assert pipe.flush() is b and pipe.flush() is None

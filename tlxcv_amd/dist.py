@@ -80,6 +80,52 @@ def _gather_rows(padded, group=None):
     return out
 
 
+class GatherPipe:
+    """The all-gather of step i overlapped with the forward of step i + 1 (equal shards).  put(y) copies this rank's logits
+    into one of two staging buffers (a forward that replays a hipGraph rewrites its static output every step) and starts the
+    all-gather asynchronously — RCCL runs it on its own stream, the caller's stream goes on to the next forward — then waits
+    for the PREVIOUS step's gather and returns that result (None on the first call).  flush() returns the last one.
+    With the gloo rehearsal backend (device tensors staged through the host) every gather is synchronous."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.stage = [None, None]
+        self.n = 0
+        self.pending = None        # (out, work)
+
+    def _wait(self):
+        if self.pending is None:
+            return None
+        out, work = self.pending
+        self.pending = None
+        if work is not None:
+            work.wait()
+        return out
+
+    def put(self, local_logits):
+        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+            prev, self.pending = self._wait(), (local_logits, None)
+            return prev
+        world = dist.get_world_size(self.group)
+        if local_logits.is_cuda and dist.get_backend(self.group) == "gloo":
+            prev, self.pending = self._wait(), (_gather_rows(local_logits.contiguous(), self.group), None)
+            return prev
+        k = self.n & 1
+        self.n += 1
+        if self.stage[k] is None or self.stage[k].shape != local_logits.shape or self.stage[k].dtype != local_logits.dtype:
+            self.stage[k] = torch.empty_like(local_logits, memory_format=torch.contiguous_format)
+        self.stage[k].copy_(local_logits)
+        b, c = local_logits.shape
+        out = torch.empty((b * world, c), dtype=local_logits.dtype, device=local_logits.device)
+        work = dist.all_gather_into_tensor(out, self.stage[k], group=self.group, async_op=True)
+        prev = self._wait()
+        self.pending = (out, work)
+        return prev
+
+    def flush(self):
+        return self._wait()
+
+
 def sharded_forward(model, x, total=None):
     """Logits of a batch sharded across ranks, on every rank, in batch order.
     total=None: `x` is the GLOBAL batch (every rank holds it, e.g. a broadcast request) and each rank runs its
