@@ -30,6 +30,21 @@ def main(out_dir):
     res["pred_global4"] = D.sharded_predict(m, x).cpu().numpy()
     tlxcv_amd.set_precision("fp16")
     res["logits_fp16"] = D.sharded_forward(m, x).float().cpu().numpy()
+    # the bench loop's gather pipeline (dist.GatherPipe) over three steps of a replayed hipGraph: step i's gather comes back
+    # one call later; the graph's static output is rewritten in between
+    from tlxcv_amd.graph import GraphedForward
+    lo, hi = D.shard_bounds(4, rank, world)
+    xs = x[lo:hi].contiguous()
+    gf = GraphedForward(m, xs.clone())
+    pipe = D.GatherPipe()
+    outs = []
+    for i in range(3):
+        y = gf(xs if i != 1 else xs.flip(0).contiguous())
+        got = pipe.put(y)
+        if got is not None:
+            outs.append(got.float().cpu().numpy())
+    outs.append(pipe.flush().float().cpu().numpy())
+    res["pipe_steps"] = np.stack(outs)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **res)
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()

@@ -51,6 +51,12 @@ def test_two_ranks_on_one_gpu_gather_the_golden_logits(dev, tmp_path):
         assert np.abs(r["logits_shard3"] - ref[:3]).max() <= 1e-4, rank
         assert (r["pred_global4"] == g["argmax"]).all(), rank                    # bit-exact class indices
         check_fp16_logits(r["logits_fp16"], ref, g["argmax"], "resnet50_b4")
+        # gather pipeline over a replayed graph (fp16): steps 0 and 2 = the batch in order, step 1 = each rank's shard flipped
+        ps = r["pipe_steps"]
+        assert ps.shape == (3, 4, 1000)
+        check_fp16_logits(ps[0], ref, g["argmax"], "resnet50_b4")
+        assert np.array_equal(ps[2], ps[0])
+        check_fp16_logits(ps[1], ref[[1, 0, 3, 2]], g["argmax"][[1, 0, 3, 2]], "resnet50_b4")
     a, b = (np.load(os.path.join(str(tmp_path), f"rank{k}.npz")) for k in range(2))
     for k in a.files:
         assert np.array_equal(a[k], b[k]), k                                     # the ranks agree bit for bit
