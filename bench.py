@@ -274,6 +274,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="headline workload only (skip the ViT-B/16 and Swin-B lines)")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=0|1", help="engine.set_option(NAME, value) before building")
+    ap.add_argument("--no-probe", action="store_true", help="timed region only: no instrumented per-kernel pass, no two_in_flight run (profiling runs)")
     ap.add_argument("--no-graph", action="store_true", help="launch kernel by kernel instead of replaying a hipGraph")
     a = ap.parse_args()
     if a.batch is None:
@@ -295,7 +296,7 @@ def main():
         name, _, val = o.partition("=")
         tlxcv_amd.engine.set_option(name, int(val or "1"))
 
-    res, params, model = measure(a.workload, a.batch, a.steps, a.warmup, dev, rank, world, graph=not a.no_graph)
+    res, params, model = measure(a.workload, a.batch, a.steps, a.warmup, dev, rank, world, graph=not a.no_graph, probe_family=not a.no_probe)
     line = {
         "metric": "images/sec fwd", "value": res["value"], "unit": "images/sec", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": res["ms_per_step"],

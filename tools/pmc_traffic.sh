@@ -8,7 +8,7 @@ WL=${1:-resnet50}
 OUT=gpurun_out/traffic_$WL
 rm -rf $OUT; mkdir -p $OUT
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$c -- python3 bench.py --workload $WL --steps 3 --warmup 2 --no-cpu-baseline --no-also > $OUT/$c.log 2>&1
+  timeout -k 10 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$c -- python3 bench.py --workload $WL --steps 3 --warmup 2 --no-cpu-baseline --no-also --no-probe > $OUT/$c.log 2>&1
   echo "pass $c rc=$?"
 done
 python3 - "$WL" <<'PY'
