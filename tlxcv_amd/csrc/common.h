@@ -34,9 +34,15 @@ inline long tune_int(const char* name, long dflt) {
     return (e && *e) ? atol(e) : dflt;
 }
 #define TLXMI_DBG(args, bit) (((args).debug & (bit)) != 0)
+// A/B (TLXMI_DEBUG bit 0x4000): flips the store policy of the half-line quadrant stores — gemm_pp (plain GEMM) / gemm256 to
+// write-back, conv_halo to non-temporal.  Product: convolution outputs (conv_halo, gemm_pp in CONV mode) are written back
+// through L2 — the next launch reads them at once, and the two 64-byte halves of a line merge before they leave; Linear outputs
+// stay non-temporal.
+#define TLXMI_WB_STORES(args) (((args).debug & 0x4000) != 0)
 #else
 constexpr long tune_int(const char*, long dflt) { return dflt; }
 #define TLXMI_DBG(args, bit) (false)
+#define TLXMI_WB_STORES(args) (false)
 #endif
 
 // ---- device-side vector types -------------------------------------------------------------

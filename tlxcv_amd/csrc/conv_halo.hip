@@ -52,6 +52,9 @@ static __device__ __forceinline__ u32x4 ch_load16(__amdgpu_buffer_rsrc_t rsrc, i
 static __device__ __forceinline__ void ch_store16_nt(__amdgpu_buffer_rsrc_t rsrc, u32x4 v, int voff) {
     __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff, 0, 2);
 }
+static __device__ __forceinline__ void ch_store16_wb(__amdgpu_buffer_rsrc_t rsrc, u32x4 v, int voff) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff, 0, 0);
+}
 
 // R x S taps, PB = bytes per input pixel (C * 2); S * PB must be a multiple of 64 (one MFMA K slice)
 // PI = MFMA pixel sub-tiles per wave: a tile is TP = 32 * PI consecutive pixels (8 where the filter registers
@@ -234,7 +237,8 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const HaloArgs a) {
                             if (jrow > 0) m = ch_pkmax4(m, *reinterpret_cast<const u32x4*>(rp + off));
                         }
                         const int opix = (tj.n * a.tpi + jrow) * (16 * PI / 2) + xh;     // pooled pixel index (N, Ho/2, Wo/2)
-                        ch_store16_nt(ysrd, m, (in && st_ok && ch * 8 < a.Cout && !TLXMI_DBG(a, 2)) ? (opix * a.y_ld + a.nt * 64 + ch * 8) * 2 : OOB);
+                        if (!TLXMI_WB_STORES(a)) ch_store16_wb(ysrd, m, (in && st_ok && ch * 8 < a.Cout && !TLXMI_DBG(a, 2)) ? (opix * a.y_ld + a.nt * 64 + ch * 8) * 2 : OOB);
+                        else ch_store16_nt(ysrd, m, (in && st_ok && ch * 8 < a.Cout && !TLXMI_DBG(a, 2)) ? (opix * a.y_ld + a.nt * 64 + ch * 8) * 2 : OOB);
                     }
                 }
         }
@@ -420,7 +424,8 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const HaloArgs a) {
                     half8v hv;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) hv[e] = (half_t)v[e];
-                    ch_store16_nt(ysrd, __builtin_bit_cast(u32x4, hv), (ok && !TLXMI_DBG(a, 2)) ? (mg * a.y_ld + ch0) * 2 : OOB);
+                    if (!TLXMI_WB_STORES(a)) ch_store16_wb(ysrd, __builtin_bit_cast(u32x4, hv), (ok && !TLXMI_DBG(a, 2)) ? (mg * a.y_ld + ch0) * 2 : OOB);
+                    else ch_store16_nt(ysrd, __builtin_bit_cast(u32x4, hv), (ok && !TLXMI_DBG(a, 2)) ? (mg * a.y_ld + ch0) * 2 : OOB);
                 }
             }
             // the rows of tile p+2 have landed; the PI stores just issued (and nothing else) may stay in flight

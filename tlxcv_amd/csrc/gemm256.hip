@@ -33,6 +33,9 @@ static __device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, 
 static __device__ __forceinline__ void buf_store16_nt(__amdgpu_buffer_rsrc_t rsrc, u32x4 v, int voff) {
     __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff, 0, 2);
 }
+static __device__ __forceinline__ void buf_store16_wb(__amdgpu_buffer_rsrc_t rsrc, u32x4 v, int voff) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff, 0, 0);
+}
 
 template <typename T> struct Mma256;
 template <> struct Mma256<half_t> {
@@ -229,13 +232,16 @@ __global__ __launch_bounds__(WGN * 128, 2) void gemm256_kernel(const Gemm256Args
                 half8v h;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) h[e] = (half_t)v[e];
-                buf_store16_nt(ysrd, __builtin_bit_cast(u32x4, h), yo);
+                if (TLXMI_WB_STORES(a)) buf_store16_wb(ysrd, __builtin_bit_cast(u32x4, h), yo);
+                else buf_store16_nt(ysrd, __builtin_bit_cast(u32x4, h), yo);
             } else {
                 f32x4 f0, f1;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { f0[e] = v[e]; f1[e] = v[4 + e]; }
-                buf_store16_nt(ysrd, __builtin_bit_cast(u32x4, f0), yo);
-                buf_store16_nt(ysrd, __builtin_bit_cast(u32x4, f1), yo + 16);
+                if (TLXMI_WB_STORES(a)) buf_store16_wb(ysrd, __builtin_bit_cast(u32x4, f0), yo);
+                else buf_store16_nt(ysrd, __builtin_bit_cast(u32x4, f0), yo);
+                if (TLXMI_WB_STORES(a)) buf_store16_wb(ysrd, __builtin_bit_cast(u32x4, f1), yo + 16);
+                else buf_store16_nt(ysrd, __builtin_bit_cast(u32x4, f1), yo + 16);
             }
         }
     }
@@ -248,6 +254,7 @@ __global__ __launch_bounds__(WGN * 128, 2) void gemm256_kernel(const Gemm256Args
 // variant 1: 256 x 128.
 template <typename T, int BN, int WGN, int NSLOT> static int launch_v(const Gemm256Args& a0, hipStream_t st, bool& raised) {
     Gemm256Args a = a0;
+    a.debug = (int)tune_int("TLXMI_DEBUG", 0);     // A/B bits: tuning flavour only
     a.mtiles = (a.M + 255) / 256;
     a.ntiles = (a.Cout + BN - 1) / BN;
     {

@@ -40,6 +40,9 @@ static __device__ __forceinline__ u32x4 pp_load16(__amdgpu_buffer_rsrc_t rsrc, i
 static __device__ __forceinline__ void pp_store16_nt(__amdgpu_buffer_rsrc_t rsrc, u32x4 v, int voff) {
     __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff, 0, 2);
 }
+static __device__ __forceinline__ void pp_store16_wb(__amdgpu_buffer_rsrc_t rsrc, u32x4 v, int voff) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff, 0, 0);
+}
 
 template <typename T> struct MmaPP;
 template <> struct MmaPP<half_t> {
@@ -418,13 +421,16 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
                         half8v hv;
 #pragma unroll
                         for (int e = 0; e < 8; ++e) hv[e] = (half_t)v[e];
-                        pp_store16_nt(ysrd, __builtin_bit_cast(u32x4, hv), yo);
+                        if (CONV || TLXMI_WB_STORES(a)) pp_store16_wb(ysrd, __builtin_bit_cast(u32x4, hv), yo);
+                        else pp_store16_nt(ysrd, __builtin_bit_cast(u32x4, hv), yo);
                     } else {
                         f32x4 f0, f1;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { f0[e] = v[e]; f1[e] = v[4 + e]; }
-                        pp_store16_nt(ysrd, __builtin_bit_cast(u32x4, f0), yo);
-                        pp_store16_nt(ysrd, __builtin_bit_cast(u32x4, f1), yo + 16);
+                        if (CONV || TLXMI_WB_STORES(a)) pp_store16_wb(ysrd, __builtin_bit_cast(u32x4, f0), yo);
+                        else pp_store16_nt(ysrd, __builtin_bit_cast(u32x4, f0), yo);
+                        if (CONV || TLXMI_WB_STORES(a)) pp_store16_wb(ysrd, __builtin_bit_cast(u32x4, f1), yo + 16);
+                        else pp_store16_nt(ysrd, __builtin_bit_cast(u32x4, f1), yo + 16);
                     }
                 }
             }
