@@ -116,6 +116,12 @@ def to_model_device(inputs, model):
 # independent (eval-mode forward, no batch statistics): the result is the concatenation, row for row what the halves give alone.
 _side_streams = {}
 _cache_builds = 0
+_halves_depth = 0        # > 0 while run_halves() enqueues its two half batches
+
+
+def in_halves():
+    """True while a two-stream forward is being enqueued (launch-shape choices that count on the other stream's launches)."""
+    return _halves_depth > 0
 
 
 def note_cache_build():
@@ -142,6 +148,8 @@ def run_halves(fn, x, plan_half=False):
         if idx not in _cus:
             _cus[idx] = torch.cuda.get_device_properties(idx).multi_processor_count
         prev = lib.tlxmi_set_plan_cus(_cus[idx] // 2)
+    global _halves_depth
+    _halves_depth += 1
     try:
         for _ in range(3):
             builds = _cache_builds
@@ -154,6 +162,7 @@ def run_halves(fn, x, plan_half=False):
                 y1.record_stream(cur)
                 return torch.cat((y0, y1), 0)
     finally:
+        _halves_depth -= 1
         if plan_half:
             lib.tlxmi_set_plan_cus(prev)
     return fn(x)

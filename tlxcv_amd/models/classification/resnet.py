@@ -114,6 +114,13 @@ class BottleneckBlock(nn.Module):
                 or not E.bottleneck_seam_supported(c3.in_channels, c3.out_channels, c1.out_channels, dt)
                 or (c3.in_channels >= 256 and not E.option("seam256"))):
             return None
+        # Where the fused launch pays (tools/small_batch.py, graph replay, one box): a seam runs its 64-channel steps one after
+        # the other, so with few pixels it is a chain of latencies — batch 1 0.91 ms with all seams, 0.78 without the 14 x 14
+        # ones, 0.74 without any; from 16 images the 56 x 56 / 28 x 28 seams win (batch 32: 1.09 vs 1.14 ms), the 14 x 14 ones
+        # (1 MB of filters per 128 pixels) only from ~96 images, or inside a two-stream forward (batch 128 = 2 x 64: 2.12 vs 2.16).
+        n_img = out.shape[0]
+        if n_img < 12 or (c3.in_channels >= 256 and n_img < 96 and not E.in_halves()):
+            return None
         pk3 = c3._cached("pk", lambda: E.PackedFilter(c3.filters, dt))
         pk1 = c1._cached("pk", lambda: E.PackedFilter(c1.filters, dt))
         s3, h3 = c3._cached(("bn", id(self.bn3)), lambda: self.bn3.folded(None), deps=(self.bn3,))
