@@ -78,7 +78,8 @@ const char* tlxmi_last_error(void);
 int tlxmi_device_count(void);
 /* Tile planning of tlxmi_conv2d / tlxmi_linear for launches that will share the device: the dispatcher prices workgroup
  * rounds for `cus` compute units instead of the device's (a caller running two half batches on two streams passes half:
- * fewer, larger tiles per launch, the other stream's launches fill the rest).  0 restores the device's count.  Affects
+ * fewer, larger tiles per launch, the other stream's launches fill the rest) and does not split a short last round off into
+ * a launch of its own (any cus > 0, the device's own count included).  0 restores the single-stream planning.  Affects
  * the choice of tile only, never results beyond the summation order of a tile shape; process-wide, returns the previous
  * value.  (The reference has no counterpart: TensorLayerX's backends pick their own launch shapes.) */
 int tlxmi_set_plan_cus(int cus);

@@ -130,13 +130,14 @@ def note_cache_build():
     _cache_builds += 1
 
 
-def run_halves(fn, x, plan_half=False):
+def run_halves(fn, x, plan=None):
     """fn(first half) on the current stream, fn(second half) on the device's side stream, joined; returns the concatenation.
     Derived tensors are built lazily on whichever stream asks first, and the other stream would read them unordered: when a
     build happened during the call (first forward, new weights, new precision) the streams are joined and the two halves are
     done again — the same launches every later call makes, so the first result equals the later ones bit for bit.
-    plan_half: the conv / linear dispatcher prices its tiles for half the CUs while the halves are enqueued
-    (tlxmi_set_plan_cus): ResNet-50 batch 256 -2 % (larger tiles per launch), Swin-B +3 % (not used there)."""
+    plan: while the halves are enqueued the conv / linear dispatcher is told that its launches share the device
+    (tlxmi_set_plan_cus) — "half": tiles priced for half the CUs and no tail splits (ResNet-50 batch 256 -3 %; Swin-B +3 %),
+    "full": the device's CU count, no tail splits only (Swin-B batch 128 -1.3 %)."""
     cur = torch.cuda.current_stream(x.device)
     idx = x.device.index if x.device.index is not None else torch.cuda.current_device()
     side = _side_streams.get(idx)
@@ -144,10 +145,10 @@ def run_halves(fn, x, plan_half=False):
         side = _side_streams[idx] = torch.cuda.Stream(device=x.device)
     n = x.shape[0] // 2
     lib = _lib.load()
-    if plan_half:
+    if plan is not None:
         if idx not in _cus:
             _cus[idx] = torch.cuda.get_device_properties(idx).multi_processor_count
-        prev = lib.tlxmi_set_plan_cus(_cus[idx] // 2)
+        prev = lib.tlxmi_set_plan_cus(_cus[idx] // 2 if plan == "half" else _cus[idx])
     global _halves_depth
     _halves_depth += 1
     try:
@@ -163,12 +164,12 @@ def run_halves(fn, x, plan_half=False):
                 return torch.cat((y0, y1), 0)
     finally:
         _halves_depth -= 1
-        if plan_half:
+        if plan is not None:
             lib.tlxmi_set_plan_cus(prev)
     return fn(x)
 
 
-def two_streams(min_batch, plan_half=False):
+def two_streams(min_batch, plan=None):
     """Decorator of a model's forward(self, x): batches of at least `min_batch` (even) images run as run_halves()."""
     def deco(fwd):
         import functools
@@ -177,7 +178,7 @@ def two_streams(min_batch, plan_half=False):
         def wrapper(self, x, *args, **kwargs):
             if (_options["two_streams"] and not args and not kwargs and isinstance(x, torch.Tensor) and x.is_cuda
                     and x.dim() == 4 and x.shape[0] >= min_batch and x.shape[0] % 2 == 0 and _probe is None):
-                return run_halves(lambda h: fwd(self, h), x, plan_half)
+                return run_halves(lambda h: fwd(self, h), x, plan)
             return fwd(self, x, *args, **kwargs)
         return wrapper
     return deco

@@ -202,7 +202,7 @@ class ResNet(nn.Module):
                                 batch_norm=batch_norm, data_format=data_format))
         return nn.Sequential(layers)
 
-    @E.two_streams(128, plan_half=True)
+    @E.two_streams(128, plan="half")
     def forward(self, x):
         if (self.data_format == 'channels_first' and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
                 and not x.permute(0, 2, 3, 1).is_contiguous()):

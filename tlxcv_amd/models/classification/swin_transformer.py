@@ -254,7 +254,7 @@ class SwinTransformer(nn.Module):
         x = self.norm(x)                               # :608
         return E.global_avgpool(x)                     # mean over tokens == avgpool(x^T) + flatten, :609-610
 
-    @E.two_streams(128)
+    @E.two_streams(128, plan="full")
     def forward(self, x):
         x = self.forward_features(x)
         return self.head.run(x) if isinstance(self.head, nn.Linear) else x
