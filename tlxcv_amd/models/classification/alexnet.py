@@ -65,6 +65,7 @@ class AlexNet(nn.Module):
             self._fc8 = Linear(in_features=4096, out_features=num_classes, W_init=random_uniform(-stdv, stdv),
                                b_init=xavier_uniform())
 
+    @E.two_streams(128, plan="full")
     def forward(self, inputs):
         E.need_gpu(inputs, "input")
         H, W = (inputs.shape[2], inputs.shape[3]) if self.data_format == 'channels_first' else (inputs.shape[1], inputs.shape[2])

@@ -78,6 +78,7 @@ class MobileNetV1(nn.Module):
         if num_classes > 0:
             self.fc = nn.Linear(in_features=int(1024 * scale), out_features=num_classes)
 
+    @E.two_streams(128, plan="full")
     def forward(self, x):
         v = self.conv1.run_nhwc(as_nhwc(x, self.data_format))      # :255
         for blk in self.dwsl:                                      # :256

@@ -87,6 +87,7 @@ class MobileNetV2(nn.Module):
             self.classifier = nn.Sequential([nn.Dropout(0.2), nn.Linear(in_features=self.last_channel,
                                                                         out_features=num_classes)])
 
+    @E.two_streams(128, plan="full")
     def forward(self, x):
         v = as_nhwc(x, 'channels_first')
         for f in self.features:
@@ -208,6 +209,7 @@ class MobileNetV3(nn.Module):
                 nn.Linear(in_features=self.lastconv_out_channels, out_features=self.last_channel), nn.Hardswish(),
                 nn.Dropout(p=0.2), nn.Linear(in_features=self.last_channel, out_features=num_classes)])
 
+    @E.two_streams(128, plan="full")
     def forward(self, x):
         v = self.conv.run_nhwc(as_nhwc(x, 'channels_first'))
         for b in self.blocks:

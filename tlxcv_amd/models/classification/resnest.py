@@ -194,6 +194,7 @@ class ResNeSt(nn.Module):
         self.out_channels = 2048
         self.out = nn.Linear(in_features=self.out_channels, out_features=num_classes, b_init=xavier_uniform())
 
+    @E.two_streams(128, plan="full")
     def forward(self, x):
         first = list(self.stem)[0] if self.deep_stem else self.stem
         rest = list(self.stem)[1:] if self.deep_stem else []

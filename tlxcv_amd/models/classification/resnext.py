@@ -105,6 +105,7 @@ class ResNeXt(nn.Module):
         self.pool2d_avg_channels = num_channels[-1] * 2
         self.out = nn.Linear(in_features=self.pool2d_avg_channels, out_features=num_classes, b_init=xavier_uniform())
 
+    @E.two_streams(128, plan="half")
     def forward(self, inputs):
         x = inputs
         if (self.data_format == 'channels_first' and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0

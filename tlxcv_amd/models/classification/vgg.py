@@ -55,7 +55,7 @@ class VGG(nn.Module):
                 i += 1
         return v
 
-    @E.two_streams(64)
+    @E.two_streams(32, plan="half")
     def forward(self, x):
         v = self.features_nhwc(as_nhwc(x, self.data_format))
         if self.with_pool:
