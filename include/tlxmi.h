@@ -246,12 +246,11 @@ int tlxmi_group_conv2d(const tlxmi_conv2d_desc* d, int groups, const void* x, co
 /* ------------------------------------------------------------------------------------------
  * nn.Linear with few rows and a large filter — the classifier heads: resnet.py:234-237, vgg.py:42-50 (25088 -> 4096),
  * alexnet.py:162-168, vision_transformer.py:333.  K is cut into `splits` slices that run side by side (K % splits == 0,
- * (K/splits)*elt % 128 == 0); `partials` is a caller-owned scratch of splits*rows*Cout elements of dtype; the partial
- * sums are added in slice order (deterministic), then y = act((sum)*scale + shift (+res)) as tlxmi_conv2d.
+ * (K/splits)*elt % 128 == 0); `partials` is a caller-owned scratch of splits*rows*Cout FLOATS (fp32 for both dtypes: the
+ * fp32 accumulators of a slice are stored unrounded); the partial sums are added in slice order (deterministic, fp32), then
+ * y = act((sum)*scale + shift (+res)) as tlxmi_conv2d.
  * w_packed: tlxmi_pack_filter of the [Cout][K] weight (1x1).
  * ---------------------------------------------------------------------------------------- */
-/* (the per-slice partial sums are stored in `dtype`: with TLXMI_F16 each slice — at least four 128-byte K tiles — is
- * accumulated in fp32 and rounded to fp16 once before the slice-order sum, itself in fp32) */
 int tlxmi_linear_splitk(int dtype, int64_t rows, int K, int Cout, int x_ld, const void* x, const void* w_packed,
                         int splits, void* partials, const float* scale, const float* shift, const void* res,
                         int res_ld, int act, float act_param, uint32_t flags, void* y, int y_ld, void* stream);

@@ -46,6 +46,7 @@ struct ConvArgs {
     int x_ld, y_ld, res_ld;
     long y_nstride, res_nstride;  // elements between images (dense = HoWo*ld; res 0 when broadcast)
     int strided_n;                // 1: y or res is not dense over the batch axis
+    int out_f32;                  // 1: y holds fp32 whatever T is (split-K partial sums: tlxmi_linear_splitk)
     int act;
     float act_param;
     unsigned flags;
@@ -412,12 +413,13 @@ __global__ __launch_bounds__(WGM * 128) void conv_igemm_kernel(const ConvArgs a0
         const bool full = a.vec_io && (ch0 + 8 <= a.Cout);
         if (ch0 < a.Cout) {
             const int row0 = t / CPR;
-            const size_t ystep = (size_t)RPP * a.y_ld * ES, rstep = (size_t)RPP * a.res_ld * ES;
+            const int OES = a.out_f32 ? 4 : ES;           // bytes of an output element
+            const size_t ystep = (size_t)RPP * a.y_ld * OES, rstep = (size_t)RPP * a.res_ld * ES;
             // one specialised, fully unrolled row loop per activation (dispatch happens once, not per element)
             auto rows = [&](auto act_tag) {
                 constexpr int ACT = decltype(act_tag)::value;
                 const char* rp = a.res ? a.res + ((size_t)(bm0 + row0) * a.res_ld + ch0) * ES : nullptr;
-                char* yp = a.y + ((size_t)(bm0 + row0) * a.y_ld + ch0) * ES;
+                char* yp = a.y + ((size_t)(bm0 + row0) * a.y_ld + ch0) * OES;
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) {
                     const int row = row0 + it * RPP;
@@ -473,7 +475,17 @@ __global__ __launch_bounds__(WGM * 128) void conv_igemm_kernel(const ConvArgs a0
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] += rv[e];
                     }
-                    if (full && a.store_policy != 0 && !a.strided_n) {
+                    if (a.out_f32 && sizeof(T) == 2) {        // fp32 partial sums of an fp16 GEMM (dense rows, no batch stride)
+                        float* yf = reinterpret_cast<float*>(yp);
+                        if (full) {
+                            *reinterpret_cast<f32x4*>(yf) = f32x4{v[0], v[1], v[2], v[3]};
+                            *reinterpret_cast<f32x4*>(yf + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e)
+                                if (ch0 + e < a.Cout) yf[e] = v[e];
+                        }
+                    } else if (full && a.store_policy != 0 && !a.strided_n) {
                         // outputs are never re-read by this launch: keep them from evicting the operand panels from L2
                         const int yoff = (int)(yp - a.y);
                         u32x4 pk[ES / 2];
@@ -904,7 +916,7 @@ static int conv2d_impl(const tlxmi_conv2d_desc* d, int nchunk, const void* x, co
         const int pol = (int)tune_int("TLXMI_STORE", 2);
         const long long yb = M * (long long)d->y_ld * es;
         a.y_bytes = yb < (1ll << 31) ? (unsigned)yb : 0u;
-        a.store_policy = (a.y_bytes && !d->y_nstride) ? pol : 0;
+        a.store_policy = (a.y_bytes && !d->y_nstride && !ksplit) ? pol : 0;
     }
     if (ksplit) {      // the packed rows keep the pitch of the whole K; a chunk walks its slice of them
         const int kc_all = d->R * d->S * (d->C * es / 16);
@@ -916,6 +928,7 @@ static int conv2d_impl(const tlxmi_conv2d_desc* d, int nchunk, const void* x, co
     a.gy = a.gres = nchunk > 1 ? cw_out * es : 0;
     a.gc = nchunk > 1 ? cw_out : 0;
     a.gw = nchunk > 1 ? a.w_bytes : 0u;
+    a.out_f32 = ksplit ? 1 : 0;
     if (ksplit) {
         a.gw = (unsigned)(cw_in * es);
         a.gy = (int)ksplit_ystride;
@@ -1029,7 +1042,7 @@ extern "C" int tlxmi_group_conv2d(const tlxmi_conv2d_desc* d, int groups, const 
 // ------------------------------------------------------------------------------------------
 namespace tlxmi {
 template <typename T>
-__global__ void splitk_reduce_kernel(const T* __restrict__ part, int splits, long rows, int Cout, long pstride, const float* __restrict__ scale,
+__global__ void splitk_reduce_kernel(const float* __restrict__ part, int splits, long rows, int Cout, long pstride, const float* __restrict__ scale,
                                      const float* __restrict__ shift, const T* __restrict__ res, int res_ld, int act, float act_param,
                                      unsigned flags, T* __restrict__ y, int y_ld) {
     const long total = rows * Cout;
@@ -1037,7 +1050,7 @@ __global__ void splitk_reduce_kernel(const T* __restrict__ part, int splits, lon
         const long m = i / Cout;
         const int n = (int)(i - m * Cout);
         float v = 0.f;
-        for (int g = 0; g < splits; ++g) v += (float)part[g * pstride + i];
+        for (int g = 0; g < splits; ++g) v += part[g * pstride + i];      // fp32 partial sums, slice order
         if (scale) v *= scale[n];
         if (shift) v += shift[n];
         const bool res_after = (flags & TLXMI_EPI_RES_AFTER_ACT) != 0;
@@ -1063,19 +1076,19 @@ extern "C" int tlxmi_linear_splitk(int dtype, int64_t rows, int K, int Cout, int
     TLXMI_REQUIRE(K % splits == 0 && ((K / splits) * es) % 128 == 0, TLXMI_ERR_ALIGNMENT,
                   "linear_splitk: K=%d must split into %d slices of whole 128-byte K tiles", K, splits);
     const long long pstride = (long long)rows * Cout;          // elements between the partial sums of consecutive slices
-    TLXMI_REQUIRE(pstride * es * splits < (1ll << 31) && aligned16(partials) && (Cout * es) % 16 == 0, TLXMI_ERR_UNSUPPORTED,
-                  "linear_splitk: partial buffer of %lld bytes per slice", pstride * es);
+    TLXMI_REQUIRE(pstride * 4 * splits < (1ll << 31) && aligned16(partials) && (Cout * es) % 16 == 0, TLXMI_ERR_UNSUPPORTED,
+                  "linear_splitk: partial buffer of %lld bytes per slice", pstride * 4);
     tlxmi_conv2d_desc d;
     memset(&d, 0, sizeof d);
     d.dtype = dtype; d.N = (int)rows; d.H = d.W = 1; d.C = K; d.Cout = Cout; d.R = d.S = 1;
     d.stride_h = d.stride_w = d.dil_h = d.dil_w = 1; d.Ho = d.Wo = 1;
     d.x_ld = x_ld; d.y_ld = Cout; d.act = TLXMI_ACT_NONE;
-    const int rc = conv2d_impl(&d, splits, x, w_packed, nullptr, nullptr, nullptr, partials, stream, false, true, pstride * es);
+    const int rc = conv2d_impl(&d, splits, x, w_packed, nullptr, nullptr, nullptr, partials, stream, false, true, pstride * 4);
     if (rc != TLXMI_OK) return rc;
     const long total = (long)rows * Cout;
     const unsigned grid = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     if (dtype == TLXMI_F16)
-        hipLaunchKernelGGL((splitk_reduce_kernel<half_t>), dim3(grid), dim3(256), 0, as_stream(stream), (const half_t*)partials, splits, (long)rows, Cout,
+        hipLaunchKernelGGL((splitk_reduce_kernel<half_t>), dim3(grid), dim3(256), 0, as_stream(stream), (const float*)partials, splits, (long)rows, Cout,
                            (long)pstride, scale, shift, (const half_t*)res, res_ld, act, act_param, flags, (half_t*)y, y_ld);
     else
         hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3(grid), dim3(256), 0, as_stream(stream), (const float*)partials, splits, (long)rows, Cout,

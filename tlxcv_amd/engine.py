@@ -538,7 +538,7 @@ def linear(x, pk, bias=None, res=None, act=ACT_NONE, out=None):
     splits = _linear_splits(rows, shp[-1], pk, x) if (out is None and _probe is None and pk.R == 1 and pk.S == 1) else 0
     if splits:
         # few rows, large filter (classifier heads): K slices side by side + a deterministic reduction (tlxmi_linear_splitk)
-        part = torch.empty((splits, rows, pk.Cout), dtype=x.dtype, device=x.device)
+        part = torch.empty((splits, rows, pk.Cout), dtype=torch.float32, device=x.device)      # fp32 partial sums
         y = torch.empty((rows, pk.Cout), dtype=x.dtype, device=x.device)
         _lib.call("tlxmi_linear_splitk", dt_code(x.dtype), rows, shp[-1], pk.Cout, shp[-1], _p(x), _p(pk.buf), splits, _p(part),
                   None, _p(bias), _p(res), pk.Cout if res is not None else 0, act, C.c_float(0.0), 0, _p(y), pk.Cout, _stream())
