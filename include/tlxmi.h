@@ -256,6 +256,18 @@ int tlxmi_linear_splitk(int dtype, int64_t rows, int K, int Cout, int x_ld, cons
                         int res_ld, int act, float act_param, uint32_t flags, void* y, int y_ld, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Convolution with few output pixels and a long K — the 3x3 convs of ResNet's 7 x 7 stage (resnet.py:111-121: N*49 pixels,
+ * K = 9 * 512) and the strided 1x1 / 3x3 convs entering it: K is cut into `splits` slices that run side by side, each
+ * storing its fp32 accumulators into `partials` (caller-owned, splits * N*Ho*Wo * Cout floats); the partial sums are added
+ * in slice order (deterministic), then y = act(sum*scale + shift (+res)) exactly as tlxmi_conv2d.  Same descriptor and packed
+ * filter as tlxmi_conv2d.  Supported: what tlxmi_conv2d_splitk_supported() reports (R x 3 filters or strided 1x1, dilation 1,
+ * C * elt a power-of-two multiple of 128 bytes, Cout >= 128 and % 8, dense y / res, >= 4 K tiles of 128 bytes per slice).
+ * ---------------------------------------------------------------------------------------- */
+int tlxmi_conv2d_splitk_supported(const tlxmi_conv2d_desc* d, int splits);
+int tlxmi_conv2d_splitk(const tlxmi_conv2d_desc* d, int splits, const void* x, const void* w_packed, void* partials,
+                        const float* scale, const float* shift, const void* res, void* y, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Depthwise conv (groups == C == Cout), HBM-bound, no MFMA.
  * Replaces nn.GroupConv2d(n_group=C)+BN+act: mobilenetv1.py:79-88, mobilenetv2.py:30,
  * mobilenetv3.py (k3/k5).   w: [R][S][C] dtype.

@@ -390,3 +390,76 @@ def test_stem_with_the_max_pool_in_its_epilogue(dev, N, act):
     # geometries without the fused kernel fall back to two launches inside run_stem (nothing else changes for the caller)
     small = conv.run_stem(x[:1, :, :64, :64].contiguous().to(dev), 2, bn, act, 0.1, maxpool=pool)
     assert small.shape == (1, 16, 16, 64)
+
+
+# ---- few output pixels, long K: K slices side by side + reduction (tlxmi_conv2d_splitk; ResNet's 7 x 7 stage at small batch)
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32], ids=["fp16", "fp32"])
+@pytest.mark.parametrize("cfg", [(4, 7, 512, 512, 3, 1, 1, True), (32, 7, 512, 512, 3, 1, 1, False), (2, 14, 512, 256, 3, 2, 1, True),
+                                 (3, 9, 1024, 384, 3, 1, 1, False)], ids=lambda c: "x".join(map(str, c)))
+def test_conv2d_splitk_matches_the_oracle_and_the_single_launch(dev, dtype, cfg):
+    from tlxcv_amd import _lib
+    import ctypes as C
+    N, H, Cin, Cout, R, s, p, with_res = cfg
+    rng = np.random.default_rng(17)
+    x = torch.from_numpy(rng.standard_normal((N, H, H, Cin)).astype(np.float32))
+    w = torch.from_numpy((rng.standard_normal((Cout, Cin, R, R)) * (2.0 / (Cin * R * R)) ** 0.5).astype(np.float32))
+    sc = torch.from_numpy(rng.uniform(0.5, 1.5, Cout).astype(np.float32))
+    sh = torch.from_numpy(rng.standard_normal(Cout).astype(np.float32))
+    Ho = (H + 2 * p - R) // s + 1
+    r = torch.from_numpy(rng.standard_normal((N, Ho, Ho, Cout)).astype(np.float32)) if with_res else None
+    if dtype == torch.float16:
+        x, w = x.half().float(), w.half().float()
+        r = r.half().float() if r is not None else None
+    want = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w, None, s, p).permute(0, 2, 3, 1) * sc + sh
+    if r is not None:
+        want = want + r
+    want = torch.relu(want)
+    pk = E.PackedFilter(w.to(dev), dtype)
+    xd, rd = x.to(dtype).to(dev), (r.to(dtype).to(dev) if r is not None else None)
+    scd, shd = sc.to(dev), sh.to(dev)            # (kept alive: the C-ABI takes raw pointers)
+    out = torch.empty((N, Ho, Ho, Cout), dtype=dtype, device=dev)
+    d = _lib.ConvDesc(dtype=E.dt_code(dtype), N=N, H=H, W=H, C=pk.Cin_pad, Cout=Cout, R=R, S=R, stride_h=s, stride_w=s, pad_h=p, pad_w=p,
+                      dil_h=1, dil_w=1, Ho=Ho, Wo=Ho, x_ld=Cin, y_ld=Cout, res_ld=Cout if r is not None else 0, y_nstride=0, res_nstride=0,
+                      act=E.ACT_RELU, act_param=0.0, flags=0)
+    lib = _lib.load()
+    for splits in (2, 4):
+        assert lib.tlxmi_conv2d_splitk_supported(C.byref(d), splits) == 1
+        part = torch.full((splits, N * Ho * Ho, Cout), float("nan"), dtype=torch.float32, device=dev)
+        out.fill_(float("nan"))
+        _lib.call("tlxmi_conv2d_splitk", C.byref(d), splits, E._p(xd), E._p(pk.buf), E._p(part), E._p(scd), E._p(shd),
+                  E._p(rd), E._p(out), E._stream())
+        torch.cuda.synchronize()
+        got = out.float().cpu()
+        tol = 1e-4 if dtype == torch.float32 else 4e-3
+        assert float((got - want).abs().max()) <= tol * max(1.0, float(want.abs().max())), splits
+    E.set_option("conv_splitk", False)
+    try:
+        one = E.conv2d(xd, pk, s, p, 1, scd, shd, rd, E.ACT_RELU).float().cpu()
+    finally:
+        E.set_option("conv_splitk", True)
+    assert float((got - one).abs().max()) <= (1e-4 if dtype == torch.float32 else 4e-3) * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.gpu
+def test_conv2d_splitk_refuses_what_it_cannot_slice(dev):
+    from tlxcv_amd import _lib
+    import ctypes as C
+    lib = _lib.load()
+
+    def desc(**kw):
+        base = dict(dtype=E.dt_code(torch.float16), N=4, H=7, W=7, C=512, Cout=512, R=3, S=3, stride_h=1, stride_w=1, pad_h=1, pad_w=1,
+                    dil_h=1, dil_w=1, Ho=7, Wo=7, x_ld=512, y_ld=512, res_ld=0, y_nstride=0, res_nstride=0, act=0, act_param=0.0, flags=0)
+        base.update(kw)
+        return _lib.ConvDesc(**base)
+    assert lib.tlxmi_conv2d_splitk_supported(C.byref(desc()), 2) == 1
+    assert lib.tlxmi_conv2d_splitk_supported(C.byref(desc()), 1) == 0                    # not a split
+    assert lib.tlxmi_conv2d_splitk_supported(C.byref(desc()), 32) == 0                   # fewer than 4 K tiles per slice
+    assert lib.tlxmi_conv2d_splitk_supported(C.byref(desc(C=96, x_ld=96)), 2) == 0       # a tap is not whole K tiles
+    assert lib.tlxmi_conv2d_splitk_supported(C.byref(desc(Cout=64, y_ld=64)), 2) == 0    # too few output channels for the GEMM tile
+    assert lib.tlxmi_conv2d_splitk_supported(C.byref(desc(dil_h=2, dil_w=2)), 2) == 0
+    assert lib.tlxmi_conv2d_splitk_supported(C.byref(desc(R=1, S=1, pad_h=0, pad_w=0)), 2) == 0   # a plain 1x1: tlxmi_linear_splitk's job
+    d = desc(Cout=64, y_ld=64)
+    x = torch.zeros((4, 7, 7, 512), dtype=torch.float16, device=dev)
+    with pytest.raises(RuntimeError, match="not supported"):
+        _lib.call("tlxmi_conv2d_splitk", C.byref(d), 2, E._p(x), E._p(x), E._p(x), None, None, None, E._p(x), E._stream())

@@ -61,6 +61,7 @@ PROTOTYPES = {
     "tlxmi_pack_filter": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     "tlxmi_fold_bn": [_vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp],
     "tlxmi_conv2d": [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "tlxmi_conv2d_splitk": [C.POINTER(ConvDesc), _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "tlxmi_bottleneck_seam": [C.POINTER(SeamDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "tlxmi_bottleneck_seam_proj": [C.POINTER(SeamDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "tlxmi_preprocess_u8": [C.POINTER(PreprocDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -102,6 +103,7 @@ _SPECIAL = {
     "tlxmi_packed_group_filter_bytes": ([_i, _i, _i, _i, _i, _i], C.c_size_t),
     "tlxmi_group_conv_chunks": ([_i, _i, _i, _i], C.c_int),
     "tlxmi_conv2d_maxpool_supported": ([C.POINTER(ConvDesc)], C.c_int),
+    "tlxmi_conv2d_splitk_supported": ([C.POINTER(ConvDesc), _i], C.c_int),
     "tlxmi_preprocess_u8_workspace_bytes": ([C.POINTER(PreprocDesc)], C.c_size_t),
     "tlxmi_multiclass_nms_workspace_bytes": ([_i, _i], C.c_size_t),
     "tlxmi_bottleneck_seam_supported": ([_i, _i, _i, _i], C.c_int),

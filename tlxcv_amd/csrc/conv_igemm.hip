@@ -47,6 +47,7 @@ struct ConvArgs {
     long y_nstride, res_nstride;  // elements between images (dense = HoWo*ld; res 0 when broadcast)
     int strided_n;                // 1: y or res is not dense over the batch axis
     int out_f32;                  // 1: y holds fp32 whatever T is (split-K partial sums: tlxmi_linear_splitk)
+    int pp_slices;                // > 1: tlxmi_conv2d_splitk — gemm_pp in CONV mode on K slices, y = fp32 partial planes
     int act;
     float act_param;
     unsigned flags;
@@ -733,7 +734,20 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
     }
     // tuning / test aid: TLXMI_TILE=<candidate> forces a tile shape (read on every call, so one process can
     // compare candidates: tools/ab_tiles.py, tests/test_gemm_gpu.py)
-    const int forced = (int)tune_int("TLXMI_TILE", -1);
+    if (a.pp_slices > 1) {          // K slices: only the gemm_pp convolution candidates take them (7, 9: >= 256 channels out; 10: 128)
+        if (!(as_conv && (pp_conv_ok || pp_conv128_ok))) return fail(TLXMI_ERR_UNSUPPORTED, "conv2d_splitk: this layer has no gemm_pp convolution path");
+        best = -1;
+        best_score = -1.f;
+        for (int i : {7, 9, 10}) {
+            if ((i == 10 ? !pp_conv128_ok : !pp_conv_ok)) continue;
+            const long blocks = (long)((a.M + cands[i].bm - 1) / cands[i].bm) * ((a.Cout + cands[i].bn - 1) / cands[i].bn) * a.pp_slices;
+            const long rounds = (blocks + cus - 1) / cus;
+            const float fill = ((float)a.M * a.Cout) / ((float)(blocks / a.pp_slices) * cands[i].bm * cands[i].bn);
+            const float score = (float)blocks / (float)(rounds * cus) * fill * (i == 7 ? 1.40f : 1.25f);
+            if (score > best_score) { best_score = score; best = i; }
+        }
+    }
+    const int forced = a.pp_slices > 1 ? -1 : (int)tune_int("TLXMI_TILE", -1);
     if (forced >= 0 && forced < NC && !(cands[forced].bn == 128 && a.Cout <= 64) &&
         (forced < 5 || (forced <= 9 && gemm256_ok) || ((forced == 7 || forced == 9) && pp_conv_ok) ||
          (forced == 10 && (pp_conv128_ok || gemm128_ok)))) best = forced;
@@ -753,7 +767,7 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
         fprintf(stderr, "tile M=%d K=%d N=%d R=%d s=%d res=%d plan_cus=%d -> cand %d (%dx%d)\n", a.M, a.C * a.R * a.S, a.Cout, a.R, a.sh, a.res ? 1 : 0, cus, best,
                 cands[best].bm, cands[best].bn);
 #endif
-    if ((best == 7 || best >= 9) && as_conv && allow_split && tail_mode != 0) {
+    if ((best == 7 || best >= 9) && as_conv && allow_split && tail_mode != 0 && a.pp_slices <= 1) {
         // Image-axis tail split: one workgroup per CU, so a last round with few tiles costs a whole tile time.  The
         // images whose rows fill the whole rounds stay on this kernel; the last few images are a convolution of their
         // own on the small tiles (28 x 28 stage of ResNet-50 at batch 256: 784 tiles = 3.06 rounds -> 250 + 6 images).
@@ -841,6 +855,12 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
         }
         if (best == 7 || best >= 9) {
             g.ksteps = a.Kp_bytes / 128;
+            if (a.pp_slices > 1) {
+                g.kslices = a.pp_slices;
+                g.kt_slice = (g.ksteps + a.pp_slices - 1) / a.pp_slices;
+                g.slice_bytes = (long long)a.M * a.y_ld * 4;
+                g.res = nullptr; g.scale = g.shift = nullptr;
+            }
             const int dt = sizeof(T) == 2 ? TLXMI_F16 : TLXMI_F32;
             return best == 7 ? launch_gemm_pp(dt, g, st) : best == 9 ? launch_gemm_pp128(dt, g, st) : launch_gemm_pp_n128(dt, g, st);
         }
@@ -865,7 +885,7 @@ using namespace tlxmi;
 // [g*C/nchunk, (g+1)*C/nchunk) of x and of every packed filter row and writes its partial sums to y + g * ksplit_ystride.
 static int conv2d_impl(const tlxmi_conv2d_desc* d, int nchunk, const void* x, const void* w_packed,
                        const float* scale, const float* shift, const void* res, void* y, void* stream, bool diag32 = false,
-                       bool ksplit = false, long long ksplit_ystride = 0) {
+                       bool ksplit = false, long long ksplit_ystride = 0, int pp_slices = 1) {
     TLXMI_REQUIRE(d && x && w_packed && y, TLXMI_ERR_BAD_ARG, "conv2d: null descriptor or buffer");
     TLXMI_REQUIRE(d->dtype == TLXMI_F16 || d->dtype == TLXMI_F32, TLXMI_ERR_BAD_ARG, "conv2d: bad dtype %d", d->dtype);
     TLXMI_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->C > 0 && d->Cout > 0 && d->R > 0 && d->S > 0,
@@ -929,6 +949,7 @@ static int conv2d_impl(const tlxmi_conv2d_desc* d, int nchunk, const void* x, co
     a.gc = nchunk > 1 ? cw_out : 0;
     a.gw = nchunk > 1 ? a.w_bytes : 0u;
     a.out_f32 = ksplit ? 1 : 0;
+    a.pp_slices = pp_slices;
     if (ksplit) {
         a.gw = (unsigned)(cw_in * es);
         a.gy = (int)ksplit_ystride;
@@ -955,6 +976,59 @@ extern "C" int tlxmi_conv2d(const tlxmi_conv2d_desc* d, const void* x, const voi
                             const float* scale, const float* shift, const void* res, void* y,
                             void* stream) {
     return conv2d_impl(d, 1, x, w_packed, scale, shift, res, y, stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// Convolution with few output pixels and a long K (the 3x3 convs of ResNet's 7 x 7 stage, resnet.py:111-121: 72 K tiles in
+// sequence on 98 tiles of 128 x 256 — latency-bound at any batch): K is cut into `splits` slices that run side by side on
+// the antiphase GEMM kernel (gemm_pp.hip, CONV mode), each storing its fp32 accumulators; splitk_reduce_kernel adds them in
+// slice order and applies scale / shift / residual / activation.
+// ------------------------------------------------------------------------------------------
+namespace tlxmi {
+template <typename T>
+__global__ void splitk_reduce_kernel(const float* __restrict__ part, int splits, long rows, int Cout, long pstride, const float* __restrict__ scale,
+                                     const float* __restrict__ shift, const T* __restrict__ res, int res_ld, int act, float act_param,
+                                     unsigned flags, T* __restrict__ y, int y_ld);
+static bool conv_splitk_shape_ok(const tlxmi_conv2d_desc* d, int splits) {
+    if (!d || (d->dtype != TLXMI_F16 && d->dtype != TLXMI_F32) || splits < 2 || splits > 16) return false;
+    const int es = (int)elt_size(d->dtype);
+    const bool strided1x1 = d->R == 1 && d->S == 1 && d->pad_h == 0 && d->pad_w == 0 && (d->stride_h > 1 || d->stride_w > 1);
+    if (!((d->S == 3 && d->R >= 1 && d->R <= 3) || strided1x1) || d->dil_h != 1 || d->dil_w != 1) return false;
+    if (d->Cout % 8 || d->Cout < 128 || d->y_nstride || d->res_nstride || (d->flags & (TLXMI_EPI_RES_BCAST_N | TLXMI_EPI_MAXPOOL_3S2P1))) return false;
+    if ((d->C * es) % 128) return false;
+    const int tpk = d->C * es / 128;                       // K tiles per tap: a power of two
+    if (tpk & (tpk - 1)) return false;
+    const int ktiles = d->R * d->S * tpk;
+    if (ktiles / splits < 4) return false;                 // at least 4 K tiles per slice
+    const long long M = (long long)d->N * d->Ho * d->Wo;
+    return M > 0 && M * d->Cout * 4 * splits < (1ll << 31) && d->y_ld >= d->Cout;
+}
+}  // namespace tlxmi
+
+extern "C" int tlxmi_conv2d_splitk_supported(const tlxmi_conv2d_desc* d, int splits) { return conv_splitk_shape_ok(d, splits) ? 1 : 0; }
+
+extern "C" int tlxmi_conv2d_splitk(const tlxmi_conv2d_desc* d, int splits, const void* x, const void* w_packed, void* partials,
+                                   const float* scale, const float* shift, const void* res, void* y, void* stream) {
+    TLXMI_REQUIRE(d && x && w_packed && partials && y, TLXMI_ERR_BAD_ARG, "conv2d_splitk: null descriptor or buffer");
+    TLXMI_REQUIRE(conv_splitk_shape_ok(d, splits), TLXMI_ERR_UNSUPPORTED, "conv2d_splitk: layer / slice count not supported (ask tlxmi_conv2d_splitk_supported)");
+    TLXMI_REQUIRE(aligned16(partials), TLXMI_ERR_ALIGNMENT, "conv2d_splitk: partials must be 16-byte aligned");
+    const long long M = (long long)d->N * d->Ho * d->Wo;
+    tlxmi_conv2d_desc dp = *d;
+    dp.y_ld = d->Cout;             // the partial planes are dense [M][Cout] floats
+    dp.act = TLXMI_ACT_NONE;
+    dp.flags = 0;
+    dp.res_ld = 0;
+    const int rc = conv2d_impl(&dp, 1, x, w_packed, nullptr, nullptr, nullptr, partials, stream, false, false, 0, splits);
+    if (rc != TLXMI_OK) return rc;
+    const long total = (long)M * d->Cout;
+    const unsigned grid = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if (d->dtype == TLXMI_F16)
+        hipLaunchKernelGGL((splitk_reduce_kernel<half_t>), dim3(grid), dim3(256), 0, as_stream(stream), (const float*)partials, splits, (long)M, d->Cout,
+                           (long)total, scale, shift, (const half_t*)res, d->res_ld, d->act, d->act_param, d->flags, (half_t*)y, d->y_ld);
+    else
+        hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3(grid), dim3(256), 0, as_stream(stream), (const float*)partials, splits, (long)M, d->Cout,
+                           (long)total, scale, shift, (const float*)res, d->res_ld, d->act, d->act_param, d->flags, (float*)y, d->y_ld);
+    return check_launch("conv2d_splitk");
 }
 
 extern "C" int tlxmi_set_plan_cus(int cus) {

@@ -28,6 +28,10 @@ struct Gemm256Args {
     int conv;
     int cH, cW, cWo, cHoWo, csh, csw, cph, cpw;   // input extent, output extent, stride, padding (dilation 1)
     int ctshift, ctaps;                           // log2(K tiles per tap), R * 3 taps
+    // gemm_pp.hip only — split K (tlxmi_conv2d_splitk): the grid holds kslices copies of the tile grid, copy s multiplies K tiles
+    // [s * kt_slice, (s + 1) * kt_slice) and stores its fp32 accumulators, unscaled, at y + s * slice_bytes ([M][y_ld] floats)
+    int kslices = 1, kt_slice = 0;
+    long long slice_bytes = 0;
 };
 
 int launch_gemm256(int dtype, int variant, const Gemm256Args& a, hipStream_t st);

@@ -90,13 +90,17 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
     // block -> tile: blocks sharing an XCD (id % 8) take consecutive tiles, N tiles fastest
     int tile_m, tile_n;
     {
-        const int nb = a.mtiles * a.ntiles, id = blockIdx.x;
+        const int nb = a.mtiles * a.ntiles, id = a.kslices > 1 ? (int)blockIdx.x % nb : (int)blockIdx.x;
         const int xcd = id & 7, qd = nb >> 3, rm = nb & 7;
         const int L = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (id >> 3);
         tile_m = L / a.ntiles;
         tile_n = L - tile_m * a.ntiles;
     }
     const int bm0 = tile_m * BM, bn0 = tile_n * BN;
+    // split K: this copy of the tile grid multiplies K tiles kt0 .. kt0 + ks - 1 (a K tile past the slice is a zero fill)
+    const int slice = a.kslices > 1 ? (int)blockIdx.x / (a.mtiles * a.ntiles) : 0;
+    const int kt0 = slice * a.kt_slice;
+    const int ks = a.kslices > 1 ? (a.ksteps - kt0 < a.kt_slice ? a.ksteps - kt0 : a.kt_slice) : a.ksteps;
     const __amdgpu_buffer_rsrc_t xsrd = pp_srd(a.x, a.x_bytes), wsrd = pp_srd(a.w, a.w_bytes);
 
     // ---- loader: a piece = 8 rows x 128 B (one wave instruction); wave w fills pieces w and w+8 of a half
@@ -136,23 +140,25 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
     // `buf` = resident K-tile slot the tile goes to (kt & 1 for HM == 2, kt % 3 for HM == 1)
     auto stage_x = [&](int h, int kt, int buf) {
         char* b = lbase + buf * KTB + (h ? RX1 : RX0);
+        const bool mine = kt < ks;                                 // (split K: the slice ends before the filter does)
+        kt += kt0;
         if constexpr (CONV) {
             const int tap = kt >> a.ctshift;                       // wave-uniform; >= ctaps past the end (mask bit clear)
             const int r = (tap * 11) >> 5, s_ = tap - 3 * r;       // tap / 3 for tap <= 8
             const int d = (r * a.cW + s_) * a.x_ld * ES + (((kt - (tap << a.ctshift)) * 8 + lc) << 4);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) pp_dma16(xsrd, b + j * 8192, ((tapmask[h][j] >> tap) & 1u) ? xo[h][j] + d : OOB);
+            for (int j = 0; j < 2; ++j) pp_dma16(xsrd, b + j * 8192, (mine && ((tapmask[h][j] >> tap) & 1u)) ? xo[h][j] + d : OOB);
         } else {
             const int q = kt * 8 + lc;
-            const bool in = q < a.kchunks;
+            const bool in = mine && q < a.kchunks;
 #pragma unroll
             for (int j = 0; j < 2; ++j) pp_dma16(xsrd, b + j * 8192, in ? xo[h][j] + q * 16 : OOB);
         }
     };
     auto stage_w = [&](int g, int kt, int buf) {
-        const int q = kt * 8 + lc;
+        const int q = (kt + kt0) * 8 + lc;
         char* b = lbase + buf * KTB + (g ? RW1 : RW0);
-        const bool in = q * 16 < a.Kp_bytes;
+        const bool in = kt < ks && q * 16 < a.Kp_bytes;
 #pragma unroll
         for (int j = 0; j < 2; ++j) pp_dma16(wsrd, b + j * 8192, in ? wo[g][j] + q * 16 : OOB);
     };
@@ -246,7 +252,6 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
     TLXMI_PP_SYNC();
     if (wr == 1) { TLXMI_PP_SYNC(); }   // group 1 runs one barrier behind
 
-    const int ks = a.ksteps;
     if constexpr (HN == 1) {
         int bc = 0, b2 = 2;      // slots of K tiles kt and kt + 2 (mod 3)
         for (int kt = 0; kt < ks; ++kt) {
@@ -340,6 +345,23 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
     // ---- epilogue from registers: lane (fg, px) owns channels 128g + 32wc + 8fg .. +7 of pixel row
     // 128h + 64wr + 16pi + px (the filter rows are permuted so that two MFMA sub-tiles give 8 neighbours)
     const int px = lane & 15;
+    if (a.kslices > 1) {      // split K: the accumulators as they are, fp32, to this slice's [M][y_ld] plane
+        const __amdgpu_buffer_rsrc_t psrd = pp_srd(a.y + (long long)slice * a.slice_bytes, (unsigned)a.slice_bytes);
+#pragma unroll
+        for (int g = 0; g < HN; ++g) {
+            const int ch0 = bn0 + 128 * g + 32 * wc + 8 * fg;
+#pragma unroll
+            for (int h = 0; h < HM; ++h)
+#pragma unroll
+                for (int pi = 0; pi < 4; ++pi) {
+                    const int m = bm0 + 128 * h + 64 * wr + pi * 16 + px;
+                    const int yo = (m < a.M && ch0 < a.Cout) ? (m * a.y_ld + ch0) * 4 : OOB;
+                    pp_store16_wb(psrd, __builtin_bit_cast(u32x4, acc[2 * g][4 * h + pi]), yo);
+                    pp_store16_wb(psrd, __builtin_bit_cast(u32x4, acc[2 * g + 1][4 * h + pi]), yo + 16);
+                }
+        }
+        return;
+    }
     const bool res_after = (a.flags & TLXMI_EPI_RES_AFTER_ACT) != 0;
     const __amdgpu_buffer_rsrc_t ysrd = pp_srd(a.y, a.y_bytes), rsrd = pp_srd(a.res ? a.res : a.y, a.res ? a.res_bytes : 0u);
     auto epi = [&](auto act_tag) {
@@ -454,7 +476,7 @@ template <typename T, int HM, int HN, bool CONV> static int launch_pp_t(const Ge
         raised = true;
     }
     void* args[] = {&a};
-    hipError_t e = hipLaunchKernel(fn, dim3((unsigned)(a.mtiles * a.ntiles)), dim3(512), args, lds, st);
+    hipError_t e = hipLaunchKernel(fn, dim3((unsigned)(a.mtiles * a.ntiles * (a.kslices > 1 ? a.kslices : 1))), dim3(512), args, lds, st);
     if (e != hipSuccess) return fail(TLXMI_ERR_LAUNCH, "gemm_pp: HIP launch failed: %s", hipGetErrorString(e));
     return TLXMI_OK;
 }

@@ -22,7 +22,8 @@ _options = {"splitk": True,       # classifier heads: K slices side by side (tlx
             "lnfuse": False,      # LayerNorm folded into the next Linear (tlxmi_linear_ln): measured neutral, off
             "attn_comb": True,    # Swin attention with the pre-summed bias + mask table (tlxmi_attention_comb)
             "seam256": True,      # bottleneck seams with a 256-channel conv3 input (ResNet-50 layer3, 14 x 14) fused too
-            "two_streams": True}  # large batches as two half batches on two HIP streams (two_streams(), below)
+            "two_streams": True,  # large batches as two half batches on two HIP streams (two_streams(), below)
+            "conv_splitk": True}  # convs with few pixels and a long K on K slices (tlxmi_conv2d_splitk)
 
 
 def set_option(name, value):
@@ -418,20 +419,55 @@ def conv2d(x, pk, stride=1, padding=0, dilation=1, scale=None, shift=None, res=N
         if not _lib.load().tlxmi_conv2d_maxpool_supported(C.byref(d)):
             return None
         out = torch.empty((N, Ho // 2, Wo // 2, pk.Cout), dtype=x.dtype, device=x.device)
+    M = N * Ho * Wo
+    splits = 0 if maxpool3s2 else _conv_splits(d, M, pk, x, out_ld, y_nstride, res_nstride, res_bcast)
+
+    def launch():
+        if splits:
+            # few output pixels, long K (the 7 x 7 stage of a ResNet, small batches): K slices side by side + a reduction
+            part = torch.empty((splits, M, pk.Cout), dtype=torch.float32, device=x.device)
+            _lib.call("tlxmi_conv2d_splitk", C.byref(d), splits, _p(x), _p(pk.buf), _p(part), _p(scale), _p(shift), _p(res), _p(out), _stream())
+        else:
+            _lib.call("tlxmi_conv2d", C.byref(d), _p(x), _p(pk.buf), _p(scale), _p(shift), _p(res), _p(out), _stream())
     if _probe is None:
-        _lib.call("tlxmi_conv2d", C.byref(d), _p(x), _p(pk.buf), _p(scale), _p(shift), _p(res), _p(out), _stream())
+        launch()
         return out
     es = x.element_size()
-    M = N * Ho * Wo
     alg_bytes = (N * H * W * pk.Cin + (M // 4 if maxpool3s2 else M) * pk.Cout * (2 if res is not None else 1)
                  + pk.Cout * pk.Cin * pk.R * pk.S) * es
     flops = 2 * M * pk.Cout * pk.Cin * pk.R * pk.S
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    _lib.call("tlxmi_conv2d", C.byref(d), _p(x), _p(pk.buf), _p(scale), _p(shift), _p(res), _p(out), _stream())
+    launch()
     e1.record()
     _probe.append((e0, e1, alg_bytes, flops, (N, H, W, pk.Cin, pk.Cout, pk.R, sh, res is not None)))
     return out
+
+
+def _conv_splits(d, M, pk, x, out_ld, y_nstride, res_nstride, res_bcast):
+    """Number of K slices for a convolution whose few tiles each walk a long K in sequence while most CUs idle (0: one launch).
+    The slices cost a second launch (the reduction) and the partial planes, ~20 us: measured (tools/splitk_conv_check.py) the
+    3x3 512 -> 512 convs of ResNet's 7 x 7 stage win up to 32 images (26 tiles x 72 K tiles: 46.9 -> 32.5 us in 8 slices; 4 images
+    32.8 -> 26.7) and lose from 128 (98 tiles: 53.7 -> 64.2 us); 36 K tiles (14 x 14, 256 channels) lose at any batch.
+    set_option("conv_splitk", False) turns the path off (A/B)."""
+    if not _options["conv_splitk"] or y_nstride or res_nstride or res_bcast or out_ld != pk.Cout or pk.Cout < 128:
+        return 0
+    if not (pk.S == 3 or (pk.R == 1 and pk.S == 1 and (d.stride_h > 1 or d.stride_w > 1))):
+        return 0
+    es = x.element_size()
+    ktiles = pk.R * pk.S * pk.Cin_pad * es // 128
+    if ktiles < 64:
+        return 0
+    idx = x.device.index if x.device.index is not None else torch.cuda.current_device()
+    if idx not in _cus:
+        _cus[idx] = torch.cuda.get_device_properties(idx).multi_processor_count
+    tiles = ((M + 127) // 128) * ((pk.Cout + 255) // 256)
+    if tiles * 8 > _cus[idx]:
+        return 0
+    s_ = min(8, _cus[idx] // max(tiles, 1), ktiles // 8)
+    if s_ < 2:
+        return 0
+    return s_ if _lib.load().tlxmi_conv2d_splitk_supported(C.byref(d), s_) else 0
 
 
 def bottleneck_seam_supported(K1, N1, N2, dtype):
