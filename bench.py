@@ -20,7 +20,9 @@ SURVEY.md §8e); scaling is weak.  Prints ONE JSON line (rank 0).  On the same l
                 `traffic`: HBM bytes per forward from separate rocprofv3 --pmc passes (tools/pmc_traffic.sh), only when
                 the file under profiles/ was measured on exactly these kernel sources (sha of csrc/), else null.
   cpu_baseline  the CPU oracle (oracle/functional.py, torch fp32 on the host cores) on a bounded sample — the stand-in
-                for "TensorLayerX torch-CPU backend", which cannot be installed.
+                for "TensorLayerX torch-CPU backend", which cannot be installed.  ResNet-50 at top level, ViT-B/16 inside
+                also[0] (both halves of the headline metric); threads = min(cores the process may use, 16): a GPU box
+                hands one GPU's share of the host, 16 cores, whatever os.cpu_count() says.
 """
 import argparse
 import hashlib
@@ -39,7 +41,7 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 HBM_ACHIEVABLE_GBS = 6290.0      # same guide: 6.29 TB/s measured float4 copy (79 % of spec)
 MFMA_F16_PEAK_TF = 2500.0        # dense fp16 MFMA, spec
 MEASURED_GEMM_F16_TF = 1333.0    # hipBLASLt (torch.matmul) 16384 x 4096 x 4096 on a box of this pool (profiles/r01/roofline_denominators.txt)
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
 
 # SURVEY.md §8d / BASELINE.md §2: algorithmic work per image with every elementwise op fused into its producer
 WORK = {
@@ -317,13 +319,17 @@ def main():
             also = []
             for wl in ("vit_b16", "swin_b"):
                 b = WORK[wl][1]
-                r, _, m2 = measure(wl, b, min(a.steps, 30), min(a.warmup, 5), dev, 0, 1, graph=not a.no_graph)
+                r, p2, m2 = measure(wl, b, min(a.steps, 30), min(a.warmup, 5), dev, 0, 1, graph=not a.no_graph)
                 del m2
                 torch.cuda.empty_cache()
                 also.append({"workload": LABEL[wl].format(b=b), "value": r["value"], "unit": "images/sec",
                              "ms_per_step": r["ms_per_step"], "ms_per_step_median": r["ms_per_step_median"],
                              "steps": min(a.steps, 30), "warmup": min(a.warmup, 5), "roofline": r["roofline"],
                              **({"two_in_flight": r["two_in_flight"]} if "two_in_flight" in r else {})})
+                if wl == "vit_b16" and not a.no_cpu_baseline:
+                    # the other half of the headline metric gets its CPU number in the same run
+                    also[-1]["cpu_baseline"] = cpu_baseline(wl, p2, min_iters=3, min_seconds=8.0)
+                del p2
             line["also"] = also
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.workload, params)

@@ -68,6 +68,14 @@ typedef enum tlxmi_act {
                                      [N][Ho/2][Wo/2][y_ld]; the conv map itself is never stored (resnet.py:287-290).
                                      fp16 stem geometry only: ask tlxmi_conv2d_maxpool_supported() first */
 #define TLXMI_EPI_RES_BCAST_N 2u   /* res has no batch axis (pos_embed, vision_transformer.py:323) */
+/* planning hints (same `flags` word; they choose tiles, never change results beyond a tile shape's summation order): the
+ * launch will SHARE the device with launches of another stream (a caller running two half batches on two streams).
+ * _HALF: workgroup rounds are priced for half the device's CUs (fewer, larger tiles; the other stream fills the rest);
+ * _FULL: priced for the whole device.  Either one: a short last round is not split off into a launch of its own.  The
+ * hint travels with the call: the library keeps no planning state, so concurrent host threads cannot disturb each other.
+ * (The reference has no counterpart: TensorLayerX's backends pick their own launch shapes.) */
+#define TLXMI_PLAN_SHARED_HALF 0x100u
+#define TLXMI_PLAN_SHARED_FULL 0x200u
 
 /* ------------------------------------------------------------------------------------------
  * Library / device
@@ -76,13 +84,6 @@ int tlxmi_version(void);
 const char* tlxmi_last_error(void);
 /* Number of visible HIP devices whose gcnArchName starts with "gfx950"; <0 on HIP error. */
 int tlxmi_device_count(void);
-/* Tile planning of tlxmi_conv2d / tlxmi_linear for launches that will share the device: the dispatcher prices workgroup
- * rounds for `cus` compute units instead of the device's (a caller running two half batches on two streams passes half:
- * fewer, larger tiles per launch, the other stream's launches fill the rest) and does not split a short last round off into
- * a launch of its own (any cus > 0, the device's own count included).  0 restores the single-stream planning.  Affects
- * the choice of tile only, never results beyond the summation order of a tile shape; process-wide, returns the previous
- * value.  (The reference has no counterpart: TensorLayerX's backends pick their own launch shapes.) */
-int tlxmi_set_plan_cus(int cus);
 
 /* ------------------------------------------------------------------------------------------
  * Layout conversion at the model boundary.

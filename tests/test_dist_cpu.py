@@ -144,9 +144,51 @@ def test_two_rank_gather_pipeline_overlaps_steps_without_mixing_them():
 
 
 def test_gather_pipe_without_a_process_group_is_a_one_step_delay():
+    """Single rank: put() still returns a STAGED copy — a replayed hipGraph rewrites its static output in place before the
+    previous step's result is read (the old branch returned the caller's own, already overwritten, tensor)."""
     from tlxcv_amd import dist as D
     pipe = D.GatherPipe()
-    a, b = torch.ones(2, 3), torch.zeros(2, 3)
-    assert pipe.put(a) is None
-    assert pipe.put(b) is a
-    assert pipe.flush() is b and pipe.flush() is None
+    static = torch.empty(2, 3)
+    static.fill_(1.0)
+    assert pipe.put(static) is None
+    static.fill_(2.0)                       # step 1 overwrites the static output ...
+    g0 = pipe.put(static)
+    assert g0 is not static and torch.equal(g0, torch.ones(2, 3))      # ... and step 0's result is still step 0's
+    static.fill_(3.0)
+    g1 = pipe.flush()
+    assert torch.equal(g1, torch.full((2, 3), 2.0)) and pipe.flush() is None
+
+
+def _worker_empty(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from tlxcv_amd import dist as D
+    D.init(backend="gloo")
+    raised = []
+    for kw in (dict(total=None), dict(total=1)):
+        x = torch.zeros((1, 4)) if kw["total"] is None else torch.zeros((1 if rank == 0 else 0, 4))
+        try:
+            D.sharded_forward(lambda t: t, x, **kw)
+            raised.append(False)
+        except ValueError:
+            raised.append(True)
+    q.put((rank, raised))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_batch_smaller_than_the_world_raises_on_every_rank_not_only_the_empty_ones():
+    """1 image over 2 ranks: BOTH ranks raise before any collective (only the empty rank raised and the other one
+    blocked in the all-gather until the backend's timeout)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_empty, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert sorted(r for r, _ in res) == [0, 1] and all(all(v) for _, v in res), res

@@ -60,3 +60,34 @@ def test_two_ranks_on_one_gpu_gather_the_golden_logits(dev, tmp_path):
     a, b = (np.load(os.path.join(str(tmp_path), f"rank{k}.npz")) for k in range(2))
     for k in a.files:
         assert np.array_equal(a[k], b[k]), k                                     # the ranks agree bit for bit
+
+
+def test_bench_py_two_ranks_rehearsal_prints_one_line_with_gathered_logits(dev):
+    """VERDICT r2 #1d: the driver's first multi-GPU run of `bench.py --gpus N` must not be the first run of that code path.
+    Two fresh child ranks (started before any GPU call of theirs) share the box's one GPU over gloo and run the command the
+    driver runs: graph capture -> process group -> GatherPipe -> barrier-bracketed timing -> ONE JSON line from rank 0;
+    bench.py itself asserts that the gathered logits are finite and that each rank's rows are its own logits."""
+    import json
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), TLXMI_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                                       "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    outs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append((o.decode(errors="replace"), e.decode(errors="replace")))
+    for rank, (p, (o, e)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {rank} failed:\n{o[-1500:]}\n{e[-3000:]}"
+    lines = [ln for ln in outs[0][0].splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")]      # rank 0 only, one line
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak" and line["unit"] == "images/sec"
+    assert line["config"]["global_batch"] == 512 and line["value"] > 0 and line["roofline"]["frac"] > 0

@@ -153,6 +153,44 @@ def test_positional_tlx_npz_rejects_a_foreign_model(tmp_path):
         _small_models()["mbv1"]().load_weights(path)
 
 
+def test_a_name_keyed_checkpoint_is_never_unpickled(tmp_path):
+    """only the single-key positional `params` form may run pickle; a name-keyed file that smuggles an object
+    array is refused by numpy (allow_pickle=False) instead of being executed."""
+    m = _small_models()["vit"]()
+    sd = {k: v.numpy() for k, v in m.state_dict().items()}
+    evil = np.empty(1, dtype=object)
+    evil[0] = {"not": "an array"}
+    path = str(tmp_path / "dict_with_object.npz")
+    np.savez(path, **sd, extra=evil)
+    m.load_weights(path)                     # plain arrays load; the object entry is never touched
+    first = next(iter(sd))
+    sd2 = dict(sd)
+    sd2[first] = evil
+    path2 = str(tmp_path / "dict_with_object_weight.npz")
+    np.savez(path2, **sd2)
+    with pytest.raises(ValueError, match="[Oo]bject arrays|allow_pickle"):
+        m.load_weights(path2)
+
+
+def test_compose_keeps_rgba_images_on_the_host_path(monkeypatch):
+    """Pillow premultiplies alpha around a resize of an RGBA image, the device kernel does not: 4-channel images
+    must take the host transforms (here: the device batch() must not be called even when a GPU is reported)."""
+    from tlxcv_amd.tlx.vision import transforms as T
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    c = T.Compose([T.Resize((8, 8)), T.Normalize(mean=(0.5,), std=(0.5,)), T.HWC2CHW()])   # not a device plan at all
+    c2 = T.Compose([T.Resize((8, 8)), T.ToTensor("CHW")])
+    called = []
+    monkeypatch.setattr(T.Compose, "batch", lambda self, *a, **k: called.append(1))
+    rgba = np.random.default_rng(0).integers(0, 255, (16, 16, 4), dtype=np.uint8)
+    try:
+        c2(rgba)
+    except Exception:
+        pass                                  # ToTensor may try to reach the (absent) device: irrelevant here
+    assert not called
+    out = c(rgba)
+    assert out.shape == (4, 8, 8) and not called
+
+
 def test_derived_tensors_follow_parameter_updates():
     """a cached derived tensor must not survive load_state_dict / in-place parameter writes."""
     from tlxcv_amd.tlx import nn

@@ -12,8 +12,10 @@ from util import rnd, q16
 pytestmark = pytest.mark.gpu
 
 # (K1, N1, N2, N, H, W): ResNet-50 layer1 / seam into layer2 / layer2 / seam into layer3 / layer3, small extents
+# ... / layer3 (256 -> 1024 -> 256 at 14 x 14: engine option "seam256", on by default) incl. a ragged row count (3 x 5 x 7 = 105
+# pixels: partial 16-pixel blocks, partial waves, a partial workgroup)
 CASES = [(64, 256, 64, 1, 9, 9), (64, 256, 64, 3, 14, 14), (64, 256, 128, 2, 7, 5), (128, 512, 128, 1, 11, 13),
-         (128, 512, 256, 2, 6, 6)]
+         (128, 512, 256, 2, 6, 6), (256, 1024, 256, 2, 14, 14), (256, 1024, 256, 3, 5, 7)]
 
 
 def _make(K1, N1, N2, N, H, W, seed):

@@ -114,27 +114,72 @@ def test_two_streams_inside_a_captured_graph():
 
 
 @pytest.mark.gpu
-def test_plan_cus_changes_tiles_not_results():
-    """tlxmi_set_plan_cus (include/tlxmi.h): process-wide, returns the previous value; a layer planned for half the CUs
-    gives the same values to fp16 rounding (another tile shape, another summation order at most)."""
-    from tlxcv_amd import _lib
-    lib = _lib.load()
+def test_planning_hint_changes_tiles_not_results():
+    """TLXMI_PLAN_SHARED_HALF in the descriptor's flags (include/tlxmi.h): a layer planned for half the CUs gives the same
+    values to fp16 rounding (another tile shape, another summation order at most); the hint is per call, nothing lingers."""
     dev = torch.device("cuda:0")
     tlxcv_amd.set_precision("fp16")
     try:
         g = torch.Generator().manual_seed(3)
         x = torch.randn((32, 14, 14, 256), generator=g).half().to(dev)
         pk = E.PackedFilter((torch.randn((256, 256, 3, 3), generator=g) * (2 / 2304) ** 0.5).to(dev), torch.float16)
-        assert lib.tlxmi_set_plan_cus(0) == 0
+        assert E.plan_flags() == 0
         y_full = E.conv2d(x, pk, 1, 1, 1, None, None, None, E.ACT_RELU)
-        assert lib.tlxmi_set_plan_cus(128) == 0
-        try:
+        with E.shared_plan("half"):
+            assert E.plan_flags() == 0x100
             y_half = E.conv2d(x, pk, 1, 1, 1, None, None, None, E.ACT_RELU)
-        finally:
-            assert lib.tlxmi_set_plan_cus(0) == 128
-        assert lib.tlxmi_set_plan_cus(-5) == 0 and lib.tlxmi_set_plan_cus(0) == 0      # negative values mean "the device's"
+        assert E.plan_flags() == 0
+        y_again = E.conv2d(x, pk, 1, 1, 1, None, None, None, E.ACT_RELU)
         torch.cuda.synchronize()
         scale = float(y_full.float().abs().max())
         assert float((y_full.float() - y_half.float()).abs().max()) <= 2e-3 * scale
+        assert torch.equal(y_full, y_again)
+    finally:
+        tlxcv_amd.set_precision("fp32")
+
+
+@pytest.mark.gpu
+def test_two_host_threads_enqueue_forwards_without_sharing_planning_state():
+    """tile planning used to be a process-global flipped around every two-stream forward.  Two host
+    threads, each with its own model, stream and batch — one of them inside a two-stream forward most of the time — must
+    give what each gives alone, bit for bit (fp32), and the hint of one thread must never show up in the other."""
+    import threading
+    from tlxcv_amd import models, seeded
+    dev = torch.device("cuda:0")
+    tlxcv_amd.set_precision("fp32")
+    try:
+        ms, xs, wants = [], [], []
+        for seed, batch in ((1, 8), (2, 6)):
+            m = models.resnet18()
+            m.load_dict(seeded.fill(seeded.shapes_of(m), seed))
+            m = m.to(dev).set_eval()
+            x = torch.from_numpy(seeded.image_batch(batch, seed, hw=64)).to(dev)
+            ms.append(m); xs.append(x); wants.append(m(x).clone())
+        torch.cuda.synchronize()
+        errs, seen = [], []
+
+        def work(i):
+            try:
+                st = torch.cuda.Stream(device=dev)
+                with torch.cuda.stream(st):
+                    for it in range(6):
+                        if i == 0:
+                            y = E.run_halves(lambda h: ms[0](h), xs[0], "half")      # the hint is live on THIS thread only
+                        else:
+                            seen.append(E.plan_flags())
+                            y = ms[1](xs[1])
+                        st.synchronize()
+                        if not torch.equal(y, wants[i]):
+                            errs.append((i, it, float((y - wants[i]).abs().max())))
+            except Exception as e:      # noqa: BLE001
+                errs.append((i, repr(e)))
+
+        ths = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        assert not errs, errs
+        assert seen and all(v == 0 for v in seen)
     finally:
         tlxcv_amd.set_precision("fp32")

@@ -14,6 +14,8 @@ F16, F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_RELU6, ACT_LEAKY, ACT_HARDSWISH, ACT_HARDSIGMOID, ACT_GELU, ACT_SIGMOID, ACT_SILU = range(9)
 EPI_RES_AFTER_ACT = 1
 EPI_MAXPOOL_3S2P1 = 4
+PLAN_SHARED_HALF = 0x100      # planning hints in the same flags word (include/tlxmi.h)
+PLAN_SHARED_FULL = 0x200
 
 
 class ConvDesc(C.Structure):
@@ -98,7 +100,6 @@ _SPECIAL = {
     "tlxmi_version": ([], C.c_int),
     "tlxmi_last_error": ([], C.c_char_p),
     "tlxmi_device_count": ([], C.c_int),
-    "tlxmi_set_plan_cus": ([_i], C.c_int),
     "tlxmi_packed_filter_bytes": ([_i, _i, _i, _i, _i], C.c_size_t),
     "tlxmi_packed_group_filter_bytes": ([_i, _i, _i, _i, _i, _i], C.c_size_t),
     "tlxmi_group_conv_chunks": ([_i, _i, _i, _i], C.c_int),

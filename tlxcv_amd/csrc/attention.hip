@@ -160,13 +160,8 @@ template <typename T> static int launch_long(const AttnArgs& a, hipStream_t st) 
 template <typename T> static int launch_rows(const AttnArgs& a, hipStream_t st) {
     const size_t lds = ((size_t)2 * a.N * (a.hd + 1) + 4 * 256 + 4 * 128) * sizeof(float);
     if (lds > 160 * 1024) return fail(TLXMI_ERR_UNSUPPORTED, "attention: N=%d hd=%d needs %zu B of LDS", a.N, a.hd, lds);
-    static thread_local size_t raised = 0;
-    if (lds > 64 * 1024 && lds > raised) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_rows_kernel<T>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return fail(TLXMI_ERR_LAUNCH, "attention: cannot raise LDS limit: %s", hipGetErrorString(e));
-        raised = 160 * 1024;
-    }
+    if (lds > 64 * 1024)
+        if (int rc = raise_lds_limit(reinterpret_cast<const void*>(&attn_rows_kernel<T>), 160 * 1024, "attention")) return rc;
     hipLaunchKernelGGL((attn_rows_kernel<T>), dim3(a.B * a.heads), dim3(256), lds, st, a);
     return check_launch("attention(rows)");
 }

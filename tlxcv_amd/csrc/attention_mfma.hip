@@ -467,15 +467,8 @@ template <int HD, int NT> static int launch_win(const AttnArgs& a, hipStream_t s
 template <int HD, int NT, int ADD, int KF> static int launch_kf(const AttnArgs& a, hipStream_t st) {
     constexpr int SR = HD * 2 + 32;
     const size_t lds = (size_t)2 * 16 * NT * SR + (ADD == 1 ? (size_t)a.N * a.N * sizeof(float) : 0);
-    if (lds > 64 * 1024) {
-        static thread_local bool raised = false;
-        if (!raised) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<HD, NT, ADD, KF>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return fail(TLXMI_ERR_LAUNCH, "attention: cannot raise LDS limit: %s", hipGetErrorString(e));
-            raised = true;
-        }
-    }
+    if (lds > 64 * 1024)
+        if (int rc = raise_lds_limit(reinterpret_cast<const void*>(&attn_mfma_kernel<HD, NT, ADD, KF>), 160 * 1024, "attention")) return rc;
     hipLaunchKernelGGL((attn_mfma_kernel<HD, NT, ADD, KF>), dim3(a.B * a.heads), dim3(256), lds, st, a);
     return check_launch("attention(mfma)");
 }

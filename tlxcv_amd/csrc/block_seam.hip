@@ -343,14 +343,8 @@ template <int K1, int N2, int PW, int NW, bool PROJ = false, int WPS = 0> static
     const size_t lds = (size_t)2 * NP * 64 * 128 + (size_t)(2 * a.N1 + 2 * N2 + (PROJ ? 2 * a.N1 : 0)) * sizeof(float);
     if (lds > 160 * 1024) return fail(TLXMI_ERR_UNSUPPORTED, "block_seam: %zu bytes of LDS", lds);
     const void* fn = reinterpret_cast<const void*>(&seam_kernel<K1, N2, PW, NW, PROJ, WPS>);
-    if (lds > 64 * 1024) {
-        static bool raised = false;
-        if (!raised) {
-            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return fail(TLXMI_ERR_LAUNCH, "block_seam: cannot raise LDS limit: %s", hipGetErrorString(e));
-            raised = true;
-        }
-    }
+    if (lds > 64 * 1024)
+        if (int rc = raise_lds_limit(fn, 160 * 1024, "block_seam")) return rc;
     const long grid = ((long)a.M + NW * 16 * PW - 1) / (NW * 16 * PW);
     if (grid >= (1l << 31)) return fail(TLXMI_ERR_UNSUPPORTED, "block_seam: too many rows");
 #ifdef TLXMI_TUNING

@@ -14,6 +14,8 @@ namespace tlxmi {
 void set_error(const char* fmt, ...);
 int fail(int code, const char* fmt, ...);
 int check_launch(const char* what);
+int device_cus();                                                   // CU count of the CURRENT device (cached per device)
+int raise_lds_limit(const void* fn, int bytes, const char* who);    // hipFuncSetAttribute once per (device, kernel)
 
 #define TLXMI_REQUIRE(cond, code, ...)            \
     do {                                          \

@@ -458,12 +458,7 @@ bool conv_halo_act_ok(int act) {
 template <int R, int S, int PB, int PI, bool RES, bool POOL = false, int PACT = TLXMI_ACT_NONE> static int launch_halo_r(const HaloArgs& a, hipStream_t st, int cus) {
     const void* fn = reinterpret_cast<const void*>(&conv_halo_kernel<R, S, PB, PI, RES, POOL, PACT>);
     const size_t lds = (size_t)a.nring * a.PWp * PB + 512 + (POOL ? 3 * 2 * (16 * PI / 2) * 128 : 0);   // ring + scale / shift table (+ half-resolution rows)
-    static bool raised = false;
-    if (!raised) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return fail(TLXMI_ERR_LAUNCH, "conv_halo: cannot raise LDS limit: %s", hipGetErrorString(e));
-        raised = true;
-    }
+    if (int rc = raise_lds_limit(fn, 160 * 1024, "conv_halo")) return rc;
     const int tiles = a.N * a.tpi;
     int grid = cus & ~7;
     if (grid < 8) grid = 8;

@@ -523,18 +523,7 @@ __global__ __launch_bounds__(WGM * 128) void conv_igemm_kernel(const ConvArgs a0
     }
 }
 
-static int g_plan_cus = 0;      // tlxmi_set_plan_cus: CU count the tile choice is priced for (0: the device's)
-static int g_num_cus = 0;
-static int num_cus() {
-    if (g_num_cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t p;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess)
-            g_num_cus = p.multiProcessorCount;
-        if (g_num_cus <= 0) g_num_cus = 256;
-    }
-    return g_num_cus;
-}
+static int num_cus() { return device_cus(); }      // core.hip: cached per device
 
 // resident blocks per CU for a tile shape: LDS bound (160 KiB) and the register allocation hipcc
 // reports for this kernel (128x128: 156 -> 3 waves/SIMD, others <= 128 -> 4)
@@ -568,14 +557,8 @@ template <typename T, int BM, int BN, int WGM, int STAGES> static int launch(con
     const bool diag = a.diag && !is1x1 && fns_diag[0] != nullptr;
     const void* fn = diag ? fns_diag[resp ? 1 : 0] : fns[which];
     if (diag) which = 4 + (resp ? 1 : 0);
-    if (lds > 64 * 1024) {
-        static bool raised[6] = {false, false, false, false, false, false};
-        if (!raised[which]) {
-            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return fail(TLXMI_ERR_LAUNCH, "conv2d: cannot raise LDS limit: %s", hipGetErrorString(e));
-            raised[which] = true;
-        }
-    }
+    if (lds > 64 * 1024)
+        if (int rc = raise_lds_limit(fn, 160 * 1024, "conv2d")) return rc;
     void* args[] = {&b};
     hipError_t e = hipLaunchKernel(fn, dim3((unsigned)grid, (unsigned)a.nchunk), dim3(WGM * 128), args, lds, st);
     if (e != hipSuccess) return fail(TLXMI_ERR_LAUNCH, "conv2d: HIP launch failed: %s", hipGetErrorString(e));
@@ -696,13 +679,16 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
     // remaining rows to a second launch of the same kernel on 128x256 tiles (gemm_pp128): twice the tiles, about
     // 0.6 of the time, still one round (tail split, below).
     const long t256 = (long)((a.M + 255) / 256) * ((a.Cout + 255) / 256);
-    // tlxmi_set_plan_cus (tuning flavour: TLXMI_PLAN_CUS too): the launch will share the device with another stream's
-    const int cus = tune_int("TLXMI_PLAN_CUS", 0) > 0 ? (int)tune_int("TLXMI_PLAN_CUS", 0) : g_plan_cus > 0 ? g_plan_cus : num_cus();
+    // TLXMI_PLAN_SHARED_* in the descriptor's flags (tuning flavour: TLXMI_PLAN_CUS too): the launch will share the device
+    // with another stream's — a property of THIS call, carried by its descriptor; the library keeps no planning state
+    const bool shared = (a.flags & (TLXMI_PLAN_SHARED_HALF | TLXMI_PLAN_SHARED_FULL)) != 0;
+    const int cus = tune_int("TLXMI_PLAN_CUS", 0) > 0 ? (int)tune_int("TLXMI_PLAN_CUS", 0)
+                    : (a.flags & TLXMI_PLAN_SHARED_HALF) ? (num_cus() / 2 > 0 ? num_cus() / 2 : 1) : num_cus();
     const long full_rounds = t256 / cus;
     // TLXMI_TAIL (A/B): 0 no split, 1 small tiles only (4 * left <= CUs), default: 128 x 256 tiles (2 * left <= CUs)
-    // (a shared device, tlxmi_set_plan_cus: no tail splits — the other stream's launches fill a short last round, the extra
+    // (a shared device, TLXMI_PLAN_SHARED_*: no tail splits — the other stream's launches fill a short last round, the extra
     //  launches only cost: ResNet-50 batch 256 in two halves 3.70 -> 3.59 ms)
-    const int tail_mode = (int)tune_int("TLXMI_TAIL", g_plan_cus > 0 ? 0 : 2);
+    const int tail_mode = (int)tune_int("TLXMI_TAIL", shared ? 0 : 2);
     const bool tail_split = gemm256_ok && allow_split && tail_mode != 0 && full_rounds >= 1 && (t256 % cus) != 0 &&
                             (tail_mode == 1 ? 4 : 2) * (t256 % cus) <= cus;
     int best = 0;
@@ -1000,8 +986,14 @@ static bool conv_splitk_shape_ok(const tlxmi_conv2d_desc* d, int splits) {
     if (tpk & (tpk - 1)) return false;
     const int ktiles = d->R * d->S * tpk;
     if (ktiles / splits < 4) return false;                 // at least 4 K tiles per slice
+    // what the dispatcher's gemm_pp convolution path (pp_conv128_ok) asks on top: no window past the bottom / right edge
+    // (one-sided 'SAME' padding), whole 16-byte chunks on the output and residual rows
+    const int Ho = (d->H + 2 * d->pad_h - (d->R - 1) - 1) / d->stride_h + 1, Wo = (d->W + 2 * d->pad_w - (d->S - 1) - 1) / d->stride_w + 1;
+    if (d->Ho > Ho || d->Wo > Wo) return false;
+    const int vecn = 16 / es;
+    if (d->y_ld % vecn || (d->res_ld > 0 && d->res_ld % vecn)) return false;
     const long long M = (long long)d->N * d->Ho * d->Wo;
-    return M > 0 && M * d->Cout * 4 * splits < (1ll << 31) && d->y_ld >= d->Cout;
+    return M > 0 && M * d->Cout * 4 * splits < (1ll << 31) && d->y_ld >= d->Cout && M * (long long)d->y_ld * es < (1ll << 31);
 }
 }  // namespace tlxmi
 
@@ -1016,7 +1008,7 @@ extern "C" int tlxmi_conv2d_splitk(const tlxmi_conv2d_desc* d, int splits, const
     tlxmi_conv2d_desc dp = *d;
     dp.y_ld = d->Cout;             // the partial planes are dense [M][Cout] floats
     dp.act = TLXMI_ACT_NONE;
-    dp.flags = 0;
+    dp.flags = d->flags & (TLXMI_PLAN_SHARED_HALF | TLXMI_PLAN_SHARED_FULL);
     dp.res_ld = 0;
     const int rc = conv2d_impl(&dp, 1, x, w_packed, nullptr, nullptr, nullptr, partials, stream, false, false, 0, splits);
     if (rc != TLXMI_OK) return rc;
@@ -1029,12 +1021,6 @@ extern "C" int tlxmi_conv2d_splitk(const tlxmi_conv2d_desc* d, int splits, const
         hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3(grid), dim3(256), 0, as_stream(stream), (const float*)partials, splits, (long)M, d->Cout,
                            (long)total, scale, shift, (const float*)res, d->res_ld, d->act, d->act_param, d->flags, (float*)y, d->y_ld);
     return check_launch("conv2d_splitk");
-}
-
-extern "C" int tlxmi_set_plan_cus(int cus) {
-    const int prev = g_plan_cus;
-    g_plan_cus = cus > 0 ? cus : 0;
-    return prev;
 }
 
 extern "C" int tlxmi_conv2d_maxpool_supported(const tlxmi_conv2d_desc* d) {

@@ -1,6 +1,9 @@
 // Library plumbing: status strings, device probing.  No kernels here.
 #include "common.h"
 #include <string.h>
+#include <mutex>
+#include <utility>
+#include <vector>
 
 namespace tlxmi {
 
@@ -21,21 +24,41 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
-// One process drives ONE device (the deployment model: one rank per GPU).  The per-kernel caches of this library —
-// raised dynamic-LDS limits (hipFuncSetAttribute), the CU count persistent grids are sized by — are process-wide, so a
-// second device in the same process is refused instead of silently running with the first device's settings.
-static int g_bound_device = -1;
+// Per-DEVICE caches (one process may drive several GPUs from several host threads): the CU count persistent grids are
+// sized by, and which (device, kernel) pairs already had their dynamic-LDS limit raised (hipFuncSetAttribute is per
+// device).  Both sit behind one mutex; a launch pays an uncontended lock and a short scan.
+static std::mutex g_dev_mutex;
+static int g_dev_cus[64];
+static std::vector<std::pair<int, const void*>> g_raised;
+
+int device_cus() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    std::lock_guard<std::mutex> lk(g_dev_mutex);
+    if (dev < 64 && g_dev_cus[dev] > 0) return g_dev_cus[dev];
+    hipDeviceProp_t p;
+    int n = 0;
+    if (hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+    if (n <= 0) n = 256;
+    if (dev < 64) g_dev_cus[dev] = n;
+    return n;
+}
+
+int raise_lds_limit(const void* fn, int bytes, const char* who) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    std::lock_guard<std::mutex> lk(g_dev_mutex);
+    for (const auto& e : g_raised)
+        if (e.first == dev && e.second == fn) return TLXMI_OK;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return fail(TLXMI_ERR_LAUNCH, "%s: cannot raise the dynamic LDS limit to %d bytes: %s", who, bytes, hipGetErrorString(e));
+    g_raised.emplace_back(dev, fn);
+    return TLXMI_OK;
+}
 
 int check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(TLXMI_ERR_LAUNCH, "%s: HIP launch failed: %s", what, hipGetErrorString(e));
-    int dev = -1;
-    if (hipGetDevice(&dev) == hipSuccess) {
-        if (g_bound_device < 0) g_bound_device = dev;
-        else if (dev != g_bound_device)
-            return fail(TLXMI_ERR_UNSUPPORTED, "%s: this process already runs libtlxmi on device %d; device %d needs its own process "
-                        "(one rank per GPU)", what, g_bound_device, dev);
-    }
     return TLXMI_OK;
 }
 

@@ -208,14 +208,8 @@ extern "C" int tlxmi_multiclass_nms(const float* boxes, const float* scores, int
     const unsigned grid = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     hipLaunchKernelGGL(nms_keys_kernel, dim3(grid), dim3(256), 0, st, scores, keys, cls, N, M, C, MP, score_threshold);
     const size_t lds = (size_t)MP;
-    if (lds > 48 * 1024) {
-        static bool raised = false;
-        if (!raised) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&nms_image_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-            if (e != hipSuccess) return fail(TLXMI_ERR_LAUNCH, "multiclass_nms: cannot raise LDS limit: %s", hipGetErrorString(e));
-            raised = true;
-        }
-    }
+    if (lds > 48 * 1024)
+        if (int rc = raise_lds_limit(reinterpret_cast<const void*>(&nms_image_kernel), 96 * 1024, "multiclass_nms")) return rc;
     hipLaunchKernelGGL(nms_image_kernel, dim3(N), dim3(1024), lds, st, boxes, keys, cls, detections, counts, M, MP, nms_threshold, keep_top_k);
     return check_launch("multiclass_nms");
 }

@@ -252,7 +252,7 @@ __global__ __launch_bounds__(WGN * 128, 2) void gemm256_kernel(const Gemm256Args
 // Called by conv_igemm.hip's dispatcher.  Preconditions (checked there): 1x1, stride 1, no padding, dense
 // batch strides, Cout % 8 == 0, 16-byte aligned y / res rows, every tensor < 2 GiB.  variant 0: 256 x 256,
 // variant 1: 256 x 128.
-template <typename T, int BN, int WGN, int NSLOT> static int launch_v(const Gemm256Args& a0, hipStream_t st, bool& raised) {
+template <typename T, int BN, int WGN, int NSLOT> static int launch_v(const Gemm256Args& a0, hipStream_t st) {
     Gemm256Args a = a0;
     a.debug = (int)tune_int("TLXMI_DEBUG", 0);     // A/B bits: tuning flavour only
     a.mtiles = (a.M + 255) / 256;
@@ -264,11 +264,7 @@ template <typename T, int BN, int WGN, int NSLOT> static int launch_v(const Gemm
     }
     const size_t lds = (size_t)NSLOT * (256 + BN) * 64 + 2 * BN * sizeof(float);
     const void* fn = reinterpret_cast<const void*>(&gemm256_kernel<T, BN, WGN, NSLOT>);
-    if (!raised) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fail(TLXMI_ERR_LAUNCH, "gemm256: cannot raise LDS limit: %s", hipGetErrorString(e));
-        raised = true;
-    }
+    if (int rc = raise_lds_limit(fn, (int)lds, "gemm256")) return rc;
     void* args[] = {&a};
     hipError_t e = hipLaunchKernel(fn, dim3((unsigned)(a.mtiles * a.ntiles)), dim3(WGN * 128), args, lds, st);
     if (e != hipSuccess) return fail(TLXMI_ERR_LAUNCH, "gemm256: HIP launch failed: %s", hipGetErrorString(e));
@@ -276,13 +272,12 @@ template <typename T, int BN, int WGN, int NSLOT> static int launch_v(const Gemm
 }
 
 int launch_gemm256(int dtype, int variant, const Gemm256Args& a, hipStream_t st) {
-    static bool raised[4] = {false, false, false, false};
     if (variant == 0) {
-        if (dtype == TLXMI_F16) return launch_v<half_t, 256, 4, 4>(a, st, raised[0]);
-        return launch_v<float, 256, 4, 4>(a, st, raised[1]);
+        if (dtype == TLXMI_F16) return launch_v<half_t, 256, 4, 4>(a, st);
+        return launch_v<float, 256, 4, 4>(a, st);
     }
-    if (dtype == TLXMI_F16) return launch_v<half_t, 128, 2, 3>(a, st, raised[2]);
-    return launch_v<float, 128, 2, 3>(a, st, raised[3]);
+    if (dtype == TLXMI_F16) return launch_v<half_t, 128, 2, 3>(a, st);
+    return launch_v<float, 128, 2, 3>(a, st);
 }
 
 }  // namespace tlxmi

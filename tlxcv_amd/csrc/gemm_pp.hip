@@ -462,7 +462,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
 }
 
 // Preconditions as launch_gemm256 (checked by conv_igemm.hip's dispatcher); a.ksteps = packed pitch / 128.
-template <typename T, int HM, int HN, bool CONV> static int launch_pp_t(const Gemm256Args& a0, hipStream_t st, bool& raised) {
+template <typename T, int HM, int HN, bool CONV> static int launch_pp_t(const Gemm256Args& a0, hipStream_t st) {
     Gemm256Args a = a0;
     a.debug = (int)tune_int("TLXMI_DEBUG", 0);     // ablation bits: tuning flavour only (TLXMI_DBG is `false` in the product)
     a.mtiles = (a.M + 128 * HM - 1) / (128 * HM);
@@ -470,11 +470,7 @@ template <typename T, int HM, int HN, bool CONV> static int launch_pp_t(const Ge
     a.gn = a.ntiles;
     const size_t lds = (size_t)(HM + HN == 4 ? 8 : 9) * 128 * 128 + 2 * 256 * sizeof(float);
     const void* fn = reinterpret_cast<const void*>(&gemm_pp_kernel<T, HM, HN, CONV>);
-    if (!raised) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fail(TLXMI_ERR_LAUNCH, "gemm_pp: cannot raise LDS limit: %s", hipGetErrorString(e));
-        raised = true;
-    }
+    if (int rc = raise_lds_limit(fn, (int)lds, "gemm_pp")) return rc;
     void* args[] = {&a};
     hipError_t e = hipLaunchKernel(fn, dim3((unsigned)(a.mtiles * a.ntiles * (a.kslices > 1 ? a.kslices : 1))), dim3(512), args, lds, st);
     if (e != hipSuccess) return fail(TLXMI_ERR_LAUNCH, "gemm_pp: HIP launch failed: %s", hipGetErrorString(e));
@@ -482,35 +478,32 @@ template <typename T, int HM, int HN, bool CONV> static int launch_pp_t(const Ge
 }
 
 int launch_gemm_pp(int dtype, const Gemm256Args& a, hipStream_t st) {
-    static bool raised[4] = {false, false, false, false};
     if (a.conv) {
-        if (dtype == TLXMI_F16) return launch_pp_t<half_t, 2, 2, true>(a, st, raised[2]);
-        return launch_pp_t<float, 2, 2, true>(a, st, raised[3]);
+        if (dtype == TLXMI_F16) return launch_pp_t<half_t, 2, 2, true>(a, st);
+        return launch_pp_t<float, 2, 2, true>(a, st);
     }
-    if (dtype == TLXMI_F16) return launch_pp_t<half_t, 2, 2, false>(a, st, raised[0]);
-    return launch_pp_t<float, 2, 2, false>(a, st, raised[1]);
+    if (dtype == TLXMI_F16) return launch_pp_t<half_t, 2, 2, false>(a, st);
+    return launch_pp_t<float, 2, 2, false>(a, st);
 }
 
 // 128 x 256 tiles (same preconditions)
 int launch_gemm_pp128(int dtype, const Gemm256Args& a, hipStream_t st) {
-    static bool raised[4] = {false, false, false, false};
     if (a.conv) {
-        if (dtype == TLXMI_F16) return launch_pp_t<half_t, 1, 2, true>(a, st, raised[2]);
-        return launch_pp_t<float, 1, 2, true>(a, st, raised[3]);
+        if (dtype == TLXMI_F16) return launch_pp_t<half_t, 1, 2, true>(a, st);
+        return launch_pp_t<float, 1, 2, true>(a, st);
     }
-    if (dtype == TLXMI_F16) return launch_pp_t<half_t, 1, 2, false>(a, st, raised[0]);
-    return launch_pp_t<float, 1, 2, false>(a, st, raised[1]);
+    if (dtype == TLXMI_F16) return launch_pp_t<half_t, 1, 2, false>(a, st);
+    return launch_pp_t<float, 1, 2, false>(a, st);
 }
 
 // 256 x 128 tiles (layers with 128 output channels)
 int launch_gemm_pp_n128(int dtype, const Gemm256Args& a, hipStream_t st) {
-    static bool raised[4] = {false, false, false, false};
     if (a.conv) {
-        if (dtype == TLXMI_F16) return launch_pp_t<half_t, 2, 1, true>(a, st, raised[2]);
-        return launch_pp_t<float, 2, 1, true>(a, st, raised[3]);
+        if (dtype == TLXMI_F16) return launch_pp_t<half_t, 2, 1, true>(a, st);
+        return launch_pp_t<float, 2, 1, true>(a, st);
     }
-    if (dtype == TLXMI_F16) return launch_pp_t<half_t, 2, 1, false>(a, st, raised[0]);
-    return launch_pp_t<float, 2, 1, false>(a, st, raised[1]);
+    if (dtype == TLXMI_F16) return launch_pp_t<half_t, 2, 1, false>(a, st);
+    return launch_pp_t<float, 2, 1, false>(a, st);
 }
 
 }  // namespace tlxmi

@@ -438,12 +438,7 @@ template <typename T, int ACT, bool RES, bool ROWAFF = false> static int launch_
     a.gn = a.ntiles;
     const size_t lds = (size_t)8 * 128 * 128 + 4 * 2048;   // two K tiles, channel tables, row tables
     const void* fn = reinterpret_cast<const void*>(&gemm_stream_kernel<T, ACT, RES, ROWAFF>);
-    static bool raised = false;
-    if (!raised) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fail(TLXMI_ERR_LAUNCH, "gemm_stream: cannot raise LDS limit: %s", hipGetErrorString(e));
-        raised = true;
-    }
+    if (int rc = raise_lds_limit(fn, (int)lds, "gemm_stream")) return rc;
     const int tiles = a.mtiles * a.ntiles;
     int grid = cus & ~7;            // one workgroup per CU; a multiple of 8 keeps a virtual block on its XCD
     if (grid < 8) grid = 8;

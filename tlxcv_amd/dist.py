@@ -104,7 +104,13 @@ class GatherPipe:
 
     def put(self, local_logits):
         if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
-            prev, self.pending = self._wait(), (local_logits, None)
+            # single rank: still a staged copy — the caller's next replay rewrites `local_logits` before this result is read
+            k = self.n & 1
+            self.n += 1
+            if self.stage[k] is None or self.stage[k].shape != local_logits.shape or self.stage[k].dtype != local_logits.dtype:
+                self.stage[k] = torch.empty_like(local_logits, memory_format=torch.contiguous_format)
+            self.stage[k].copy_(local_logits)
+            prev, self.pending = self._wait(), (self.stage[k], None)
             return prev
         world = dist.get_world_size(self.group)
         if local_logits.is_cuda and dist.get_backend(self.group) == "gloo":
@@ -133,6 +139,8 @@ def sharded_forward(model, x, total=None):
     the form a data loader that reads per rank uses, no rank ever holds the other ranks' images."""
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
+    if total is not None and total < world:
+        raise ValueError(f"batch of {total} images over {world} ranks leaves empty shards; use fewer ranks")
     if total is None:
         total = x.shape[0]
         xs = shard_batch(x, rank, world)
@@ -141,8 +149,9 @@ def sharded_forward(model, x, total=None):
         if x.shape[0] != hi - lo:
             raise ValueError(f"rank {rank} of {world}: shard has {x.shape[0]} images, shard_bounds({total}) says {hi - lo}")
         xs = x
-    if xs.shape[0] == 0:
-        raise ValueError(f"rank {rank}: empty shard (batch {total} over {world} ranks); use fewer ranks")
+    if total < world:
+        # every rank knows total and world: all of them raise, none is left waiting in the collective
+        raise ValueError(f"batch of {total} images over {world} ranks leaves empty shards; use fewer ranks")
     return all_gather_logits(model(xs), total=total)
 
 

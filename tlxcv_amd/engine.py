@@ -6,6 +6,7 @@ hands `tensor.data_ptr()` and the current HIP stream to libtlxmi.so.  Activation
 parity dtype.  There is deliberately no CPU branch: a CPU tensor raises.
 """
 import ctypes as C
+import threading
 
 import torch
 
@@ -117,12 +118,36 @@ def to_model_device(inputs, model):
 # independent (eval-mode forward, no batch statistics): the result is the concatenation, row for row what the halves give alone.
 _side_streams = {}
 _cache_builds = 0
-_halves_depth = 0        # > 0 while run_halves() enqueues its two half batches
+# Per host THREAD: whether a two-stream forward is being enqueued and which planning hint its launches carry
+# (TLXMI_PLAN_SHARED_* in every conv / linear descriptor).  Nothing process-wide is mutated: two threads — or two models —
+# may enqueue forwards at the same time without changing each other's tile choices.
+_tls = threading.local()
 
 
 def in_halves():
     """True while a two-stream forward is being enqueued (launch-shape choices that count on the other stream's launches)."""
-    return _halves_depth > 0
+    return getattr(_tls, "depth", 0) > 0
+
+
+def plan_flags():
+    """Planning bits for the descriptors of the launches enqueued by this thread right now."""
+    return getattr(_tls, "plan", 0)
+
+
+class shared_plan:
+    """with shared_plan("half" | "full" | None): the conv / linear launches enqueued by this thread carry TLXMI_PLAN_SHARED_*."""
+
+    def __init__(self, plan):
+        self.bits = {"half": _lib.PLAN_SHARED_HALF, "full": _lib.PLAN_SHARED_FULL, None: 0}[plan]
+
+    def __enter__(self):
+        self.prev = getattr(_tls, "plan", 0)
+        _tls.plan = self.bits
+        return self
+
+    def __exit__(self, *exc):
+        _tls.plan = self.prev
+        return False
 
 
 def note_cache_build():
@@ -136,22 +161,19 @@ def run_halves(fn, x, plan=None):
     Derived tensors are built lazily on whichever stream asks first, and the other stream would read them unordered: when a
     build happened during the call (first forward, new weights, new precision) the streams are joined and the two halves are
     done again — the same launches every later call makes, so the first result equals the later ones bit for bit.
-    plan: while the halves are enqueued the conv / linear dispatcher is told that its launches share the device
-    (tlxmi_set_plan_cus) — "half": tiles priced for half the CUs and no tail splits (ResNet-50 batch 256 -3 %; Swin-B +3 %),
-    "full": the device's CU count, no tail splits only (Swin-B batch 128 -1.3 %)."""
+    plan: while the halves are enqueued every conv / linear descriptor carries a planning hint (TLXMI_PLAN_SHARED_*: the
+    launch shares the device) — "half": tiles priced for half the CUs and no tail splits (ResNet-50 batch 256 -3 %; Swin-B
+    +3 %), "full": the device's CU count, no tail splits only (Swin-B batch 128 -1.3 %).  The hint is per call and the
+    bookkeeping per host thread: nothing process-wide changes."""
     cur = torch.cuda.current_stream(x.device)
     idx = x.device.index if x.device.index is not None else torch.cuda.current_device()
     side = _side_streams.get(idx)
     if side is None:
         side = _side_streams[idx] = torch.cuda.Stream(device=x.device)
     n = x.shape[0] // 2
-    lib = _lib.load()
-    if plan is not None:
-        if idx not in _cus:
-            _cus[idx] = torch.cuda.get_device_properties(idx).multi_processor_count
-        prev = lib.tlxmi_set_plan_cus(_cus[idx] // 2 if plan == "half" else _cus[idx])
-    global _halves_depth
-    _halves_depth += 1
+    _tls.depth = getattr(_tls, "depth", 0) + 1
+    hint = shared_plan(plan)
+    hint.__enter__()
     try:
         for _ in range(3):
             builds = _cache_builds
@@ -164,9 +186,8 @@ def run_halves(fn, x, plan=None):
                 y1.record_stream(cur)
                 return torch.cat((y0, y1), 0)
     finally:
-        _halves_depth -= 1
-        if plan is not None:
-            lib.tlxmi_set_plan_cus(prev)
+        _tls.depth -= 1
+        hint.__exit__()
     return fn(x)
 
 
@@ -259,10 +280,15 @@ def preprocess_u8(images, size, mean=None, std=None, layout="CHW", dtype=torch.f
     xb, xk, kw = _resample_table(W, ow, interpolation, images.device)
     yb, yk, kh = _resample_table(H, oh, interpolation, images.device)
     norm = mean is not None
-    m = torch.as_tensor(mean, dtype=torch.float32).reshape(-1).to(images.device).contiguous() if norm else None
-    sd = torch.as_tensor(std, dtype=torch.float32).reshape(-1).to(images.device).contiguous() if norm else None
+    def per_channel(v):      # a scalar or length-1 mean / std broadcasts over the channels, as on the host (numpy)
+        t = torch.as_tensor(v, dtype=torch.float32).reshape(-1)
+        if t.numel() == 1 and Cc > 1:
+            t = t.expand(Cc)
+        return t.to(images.device).contiguous()
+    m = per_channel(mean) if norm else None
+    sd = per_channel(std if std is not None else 1.0) if norm else None
     if norm and (m.numel() != Cc or sd.numel() != Cc):
-        raise RuntimeError(f"preprocess_u8: mean / std must have {Cc} entries")
+        raise RuntimeError(f"preprocess_u8: mean / std must have 1 or {Cc} entries")
     if fold:
         v = vec(dtype)
         cpad = (fold * fold * Cc + v - 1) // v * v
@@ -412,7 +438,7 @@ def conv2d(x, pk, stride=1, padding=0, dilation=1, scale=None, shift=None, res=N
                       x_ld=ld, y_ld=out_ld, res_ld=(res_ld if res_ld is not None else (res.shape[-1] if res is not None else 0)),
                       y_nstride=y_nstride, res_nstride=res_nstride, act=act, act_param=float(act_param),
                       flags=(EPI_RES_AFTER_ACT if res_after_act else 0) | (EPI_RES_BCAST_N if res_bcast else 0)
-                      | (_lib.EPI_MAXPOOL_3S2P1 if maxpool3s2 else 0))
+                      | (_lib.EPI_MAXPOOL_3S2P1 if maxpool3s2 else 0) | plan_flags())
     if res is not None and res.dtype != x.dtype:
         raise RuntimeError("conv2d: residual dtype mismatch")
     if maxpool3s2:
@@ -535,7 +561,7 @@ def group_conv2d(x, pk, stride=1, padding=0, dilation=1, scale=None, shift=None,
                       stride_h=sh, stride_w=sw, pad_h=ph, pad_w=pw, dil_h=dh, dil_w=dw, Ho=Ho, Wo=Wo,
                       x_ld=ld, y_ld=pk.Cout, res_ld=(res.shape[-1] if res is not None else 0),
                       y_nstride=0, res_nstride=0, act=act, act_param=float(act_param),
-                      flags=(EPI_RES_AFTER_ACT if res_after_act else 0))
+                      flags=(EPI_RES_AFTER_ACT if res_after_act else 0) | plan_flags())
     args = (C.byref(d), pk.groups, _p(x), _p(pk.buf), _p(scale), _p(shift), _p(res), _p(out), _stream())
     if _probe is None:
         _lib.call("tlxmi_group_conv2d", *args)

@@ -184,7 +184,13 @@ class Module(torch.nn.Module):
         save_weights('x.npz') writes — assigned to tlx_weights() in order, every shape checked — or a name-keyed
         npz_dict (in_order=False semantics; `skip` tolerates missing names).  predict.py:19."""
         self._adopt_lists()
-        data = np.load(file_path, allow_pickle=True)
+        # Name-keyed files hold plain arrays: opened WITHOUT pickle.  Only TensorLayerX's positional form — the single
+        # object array `params` — needs the unpickler, so the file is re-opened with it for that form alone: loading such a
+        # checkpoint runs pickle, i.e. it must come from a source you trust (as with TensorLayerX's own load_weights).
+        data = np.load(file_path, allow_pickle=False)
+        if list(data.files) == ["params"]:
+            data.close()
+            data = np.load(file_path, allow_pickle=True)
         with torch.no_grad():
             if "params" in data.files and len(data.files) == 1:
                 params = list(data["params"])

@@ -49,8 +49,10 @@ class Compose:
                                layout=tt.data_format, dtype=dtype, interpolation=rs.interpolation, fold=fold)
 
     def __call__(self, data):
+        # the device path takes 1- and 3-channel uint8 images only: on RGBA Pillow premultiplies alpha around the resize,
+        # which tlxmi_preprocess_u8 does not restate — those (and every other input) run the host transforms below
         a = data if isinstance(data, np.ndarray) else None
-        if (a is not None and a.dtype == np.uint8 and a.ndim == 3 and a.shape[-1] in (1, 3, 4) and torch.cuda.is_available()
+        if (a is not None and a.dtype == np.uint8 and a.ndim == 3 and a.shape[-1] in (1, 3) and torch.cuda.is_available()
                 and self._device_plan() is not None and self.transforms[0].interpolation in ("bilinear", "bicubic")):
             return self.batch(a)[0]
         for t in self.transforms:

@@ -53,8 +53,9 @@ def run(streams, parts=2):
 
 
 def timeit(streams, plan):
-    lib = tlxcv_amd._lib.load()
-    lib.tlxmi_set_plan_cus(plan)
+    from tlxcv_amd import engine as E
+    hint = E.shared_plan("half" if plan == 128 else "full" if plan else None)     # per-call planning hint (TLXMI_PLAN_SHARED_*)
+    hint.__enter__()
     for _ in range(3):
         run(streams)
     torch.cuda.synchronize()
@@ -65,7 +66,7 @@ def timeit(streams, plan):
             run(streams)
         torch.cuda.synchronize()
         ts.append((time.perf_counter() - t0) / 10 * 1e3)
-    lib.tlxmi_set_plan_cus(0)
+    hint.__exit__()
     return sorted(ts)[2]
 
 
