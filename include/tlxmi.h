@@ -364,6 +364,13 @@ int tlxmi_row_stats(const void* x, int dtype, int64_t rows, int C, int x_ld, flo
 int tlxmi_linear_ln(int dtype, int64_t rows, int K, int Cout, int x_ld, int y_ld, const void* x,
                     const void* w_packed, const float* c1, const float* c2, const float* rowstats, int act,
                     void* y, void* stream);
+/* The same in ONE launch, without tlxmi_row_stats: the GEMM kernel sums x and x^2 of the rows it multiplies (from the
+ * fragments it feeds the MFMAs) and derives (rstd, -mean * rstd) with `eps` itself — the variance as E[x^2] - mean^2 in
+ * fp32 over the fp16 inputs.  fp16 only, Cout >= 256; other shapes / dtypes return TLXMI_ERR_UNSUPPORTED and the caller
+ * keeps tlxmi_layernorm + tlxmi_conv2d.  Wg / c1 / c2 as above. */
+int tlxmi_layernorm_linear(int dtype, int64_t rows, int K, int Cout, int x_ld, int y_ld, const void* x,
+                           const void* w_packed, const float* c1, const float* c2, float eps, int act,
+                           void* y, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused multi-head self attention on a packed qkv matrix (the output of the qkv Linear):

@@ -465,7 +465,7 @@ template <typename T> static int launch_gs_t(const Gemm256Args& a, hipStream_t s
 }
 
 bool gemm_stream_ok(int dtype, const Gemm256Args& a) {
-    if (a.ksteps < 2) return false;
+    if (a.ksteps < 2 || a.ln_fused) return false;      // in-kernel LayerNorm statistics: gemm_pp.hip only
     if (a.act != TLXMI_ACT_NONE && a.act != TLXMI_ACT_RELU && !(a.act == TLXMI_ACT_GELU && dtype == TLXMI_F16 && !a.res)) return false;
     if (a.rowstats && (dtype != TLXMI_F16 || a.act != TLXMI_ACT_NONE || a.res)) return false;
     if (a.res && (dtype != TLXMI_F16 || a.scale != nullptr || (a.flags & TLXMI_EPI_RES_AFTER_ACT) || a.ksteps < 11)) return false;

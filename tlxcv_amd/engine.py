@@ -20,7 +20,9 @@ _precision = torch.float16
 
 # Host-side A/B switches (tools/ only; no environment variable is read on the product path).
 _options = {"splitk": True,       # classifier heads: K slices side by side (tlxmi_linear_splitk)
-            "lnfuse": False,      # LayerNorm folded into the next Linear (tlxmi_linear_ln): measured neutral, off
+            "lnfuse": False,      # LayerNorm folded into the next Linear (tlxmi_layernorm_linear / tlxmi_linear_ln): measured
+                                  # neutral to slower in both forms, off
+            "lnfuse_pass": False, # with lnfuse: the two-launch form (row statistics pass + tlxmi_linear_ln) instead of in-kernel statistics
             "attn_comb": True,    # Swin attention with the pre-summed bias + mask table (tlxmi_attention_comb)
             "seam256": True,      # bottleneck seams with a 256-channel conv3 input (ResNet-50 layer3, 14 x 14) fused too
             "two_streams": True,  # large batches as two half batches on two HIP streams (two_streams(), below)
@@ -634,16 +636,16 @@ def _linear_splits(rows, K, pk, x):
 
 
 def linear_ln_supported(K, Cout, dtype, rows=None, device=None):
-    """Whether a layer takes the fused LayerNorm + Linear path (tlxmi_linear_ln).  OFF unless set_option("lnfuse", True):
-    measured on ViT-B/16 (same box, hipGraph replay) the fused qkv is -1 % end to end and fused qkv + fc1 -1..+1 %
-    — the statistics pass (28 us) plus the row-affine epilogue cost what the LayerNorm pass (46 us) saved.  fp16
-    only: the fp32 parity mode keeps the reference's order of operations.  With `rows` given, also requires the
-    one-workgroup-per-CU launch to fill its last round (the fused call has no tail split)."""
+    """Whether a layer takes the fused LayerNorm + Linear path (set_option("lnfuse", False) turns it off).  fp16 only: the
+    fp32 parity mode keeps the reference's order of operations.  Default form: tlxmi_layernorm_linear — ONE launch, the GEMM
+    kernel sums x and x^2 of its own rows (ViT-B/16: the 36-us LayerNorm pass in front of qkv and fc1 is gone).  With
+    set_option("lnfuse_pass", True): round 2's tlxmi_row_stats + tlxmi_linear_ln (the statistics pass cost what the LayerNorm
+    pass saved); that form has no tail split, so with `rows` given it also requires a well-filled last round."""
     if not _options["lnfuse"]:
         return False
     if not (dtype == torch.float16 and Cout % 8 == 0 and Cout >= 256 and K % 8 == 0 and K * 2 >= 256):
         return False
-    if rows is not None:
+    if rows is not None and _options["lnfuse_pass"]:
         idx = torch.cuda.current_device() if device is None or device.index is None else device.index
         if idx not in _cus:
             _cus[idx] = torch.cuda.get_device_properties(idx).multi_processor_count
@@ -668,21 +670,30 @@ class LinearLN:
         self.K, self.Cout = w.shape[1], w.shape[0]
 
 
-def linear_ln(x, prep, eps, act=ACT_NONE):
-    """act(Linear(LayerNorm(x))) for x (..., K): row statistics kernel + one GEMM on the raw rows."""
+def linear_ln(x, prep, eps, act=ACT_NONE, in_kernel=None):
+    """act(Linear(LayerNorm(x))) for x (..., K) on the raw rows.  in_kernel (default: not option "lnfuse_pass"): one launch,
+    statistics gathered inside the GEMM (tlxmi_layernorm_linear); else a row statistics kernel + tlxmi_linear_ln."""
     need_gpu(x, "input")
     shp = x.shape
     if not x.is_contiguous():
         x = x.contiguous()
     rows = x.numel() // shp[-1]
-    stats = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
+    if in_kernel is None:
+        in_kernel = not _options["lnfuse_pass"]
     y = torch.empty((*shp[:-1], prep.Cout), dtype=x.dtype, device=x.device)
-    _lib.call("tlxmi_row_stats", _p(x), dt_code(x.dtype), rows, prep.K, prep.K, C.c_float(eps), _p(stats), _stream())
+    stats = None
+    if not in_kernel:
+        stats = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
+        _lib.call("tlxmi_row_stats", _p(x), dt_code(x.dtype), rows, prep.K, prep.K, C.c_float(eps), _p(stats), _stream())
     if _probe is not None:      # bench.py's roofline pass: the GEMM launch alone, like conv2d()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.call("tlxmi_linear_ln", dt_code(x.dtype), rows, prep.K, prep.Cout, prep.K, prep.Cout, _p(x), _p(prep.pk.buf),
-              _p(prep.c1), _p(prep.c2), _p(stats), act, _p(y), _stream())
+    if in_kernel:
+        _lib.call("tlxmi_layernorm_linear", dt_code(x.dtype), rows, prep.K, prep.Cout, prep.K, prep.Cout, _p(x), _p(prep.pk.buf),
+                  _p(prep.c1), _p(prep.c2), C.c_float(eps), act, _p(y), _stream())
+    else:
+        _lib.call("tlxmi_linear_ln", dt_code(x.dtype), rows, prep.K, prep.Cout, prep.K, prep.Cout, _p(x), _p(prep.pk.buf),
+                  _p(prep.c1), _p(prep.c2), _p(stats), act, _p(y), _stream())
     if _probe is not None:
         e1.record()
         es = x.element_size()

@@ -9,6 +9,8 @@ change of arithmetic):
   * Attention (:112-123) = qkv GEMM(+bias) -> one fused softmax(q k^T * scale) v kernel on the
     packed qkv matrix -> proj GEMM with bias and the residual add of Block.forward (:173) fused.
   * Mlp (:81-87) = fc1 GEMM with bias+exact-erf GELU epilogue -> fc2 GEMM with bias + residual (:174).
+  * norm1 / norm2 (:172-174) are folded into the qkv / fc1 GEMMs in fp16 mode (tlxmi_layernorm_linear: the kernel sums x and
+    x^2 of its own rows; W * gamma is packed once); fp32 parity mode keeps LayerNorm then Linear.
   * final LayerNorm only on the cls rows (x[:, 0] commutes with a per-row norm, :327-328).
 """
 import numpy as np
@@ -113,8 +115,8 @@ class Block(nn.Module):
 
     def run_inplace(self, x):
         """x (B, N, C) engine dtype, updated in place: x += attn(norm1(x)); x += mlp(norm2(x))."""
-        self.attn.run(x, res=x, norm=self.norm1)       # norm1 -> qkv: folded into the GEMM only with engine.set_option('lnfuse', True)
-        self.mlp.run(self.norm2(x), res=x)             # (engine.linear_ln_supported: measured neutral to -1 %)
+        self.attn.run(x, res=x, norm=self.norm1)       # norm1 -> qkv and norm2 -> fc1 folded into the GEMMs (fp16: the kernels
+        self.mlp.run(x, res=x, norm=self.norm2)        # gather the row statistics themselves, engine.linear_ln_supported)
         return x
 
     def forward(self, x):
