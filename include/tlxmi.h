@@ -165,6 +165,9 @@ int tlxmi_conv2d_maxpool_supported(const tlxmi_conv2d_desc* d);
  *   detections [N][keep_top_k][6] (zero filled), counts [N].  M <= 65536 boxes per image; workspace:
  *   tlxmi_multiclass_nms_workspace_bytes(N, M).
  * ---------------------------------------------------------------------------------------- */
+/* IoU-aware objectness of the YOLOv3 head (yolov3.py:355-376): x [pixels][A*(6+C)] NHWC (A IoU channels first) ->
+ * y [pixels][A*(5+C)] with obj' = de_sigmoid(sigmoid(obj)^(1 - factor) * sigmoid(iou)^factor); box / class entries copied. */
+int tlxmi_yolo_iou_aware(const void* x, void* y, int dtype, int64_t pixels, int A, int C, float factor, void* stream);
 int tlxmi_yolo_box(const void* x, int dtype, int N, int A, int C, int H, int W, int channels_last, const int32_t* img_size,
                    const float* anchors, float conf_thresh, int downsample_ratio, int clip_bbox, float scale_x_y,
                    float* boxes, float* scores, int Mtot, int m_offset, void* stream);
@@ -198,6 +201,17 @@ size_t tlxmi_preprocess_u8_workspace_bytes(const tlxmi_preproc_desc* d);
 int tlxmi_preprocess_u8(const tlxmi_preproc_desc* d, const void* images, const int32_t* xbounds, const int32_t* xk,
                         const int32_t* ybounds, const int32_t* yk, const float* mean, const float* std_, void* workspace,
                         void* out, void* stream);
+
+/* The detection demo's pipeline (demo/object_detection/transforms.py:96-246, predict-YOLOv3.py:54-61):
+ * Resize(size, max_size, auto_divide) = cv2.resize(image, (ow, oh), INTER_LINEAR) on the uint8 image, then Normalize
+ * ((v / 255 - mean) / std).  OpenCV's 8-bit bilinear resize restated: two taps per axis, 11-bit fixed-point weights.
+ *   images: [N][H][W][C] uint8 (one size per call);  xidx / yidx: [out][2] source index of the two taps (already clamped
+ *   to the image);  xcoef / ycoef: [out][2] weights (sum 2048), built by the caller as OpenCV's coefficient loop does
+ *   (tlxcv_amd/tlx/vision/transforms/detection.py);  d->kh / kw / fold_b / cpad unused;  layout 0 ("CHW") or 1 ("HWC");
+ *   without `normalize` the value is v / 255.  UNPINNED: OpenCV is not available to check against. */
+int tlxmi_preprocess_linear_u8(const tlxmi_preproc_desc* d, const void* images, const int32_t* xidx, const int32_t* xcoef,
+                               const int32_t* yidx, const int32_t* ycoef, const float* mean, const float* std_, void* out,
+                               void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * The seam between two ResNet bottleneck blocks in one launch (resnet.py:142-156 of block b, :143-145 of block b + 1):

@@ -90,3 +90,96 @@ def multiclass_nms(bboxes, scores, score_threshold=0.7, nms_threshold=0.45, keep
         det = det[order]
         out.append(torch.cat([det[:, 5:6], det[:, 4:5], det[:, :4]], 1))                    # :320-322
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# The detection demo's input pipeline (demo/object_detection/transforms.py:96-246): Resize(size, max_size, auto_divide)
+# through cv2.resize(INTER_LINEAR), then Normalize.  cv2 is not in this image: its 8-bit bilinear resize is restated from
+# OpenCV's published source (modules/imgproc/src/resize.cpp: the coefficient loop of resize(), HResizeLinear,
+# VResizeLinear<uchar>) — per-pixel Python / numpy scalar arithmetic, deliberately written differently from the table
+# builder of the product (tlxcv_amd/tlx/vision/transforms/detection.py).  UNPINNED.
+# ---------------------------------------------------------------------------------------------
+def cv2_resize_linear_u8(img, dsize):
+    """img (H, W, C) uint8, dsize (width, height) as cv2.resize takes it -> (height, width, C) uint8."""
+    import numpy as np
+    H, W, C = img.shape
+    ow, oh = int(dsize[0]), int(dsize[1])
+
+    def coeffs(n_in, n_out):
+        scale = n_in / n_out                                   # scale_x = 1. / inv_scale_x, double
+        out = []
+        for d in range(n_out):
+            fx = np.float32((d + 0.5) * scale - 0.5)
+            s = int(np.floor(fx))
+            fx = np.float32(fx - np.float32(s))
+            if s < 0:
+                fx, s = np.float32(0), 0
+            if s >= n_in - 1:
+                fx, s = np.float32(0), n_in - 1
+            c0 = int(np.rint(np.float32(np.float32(1.0) - fx) * np.float32(2048.0)))          # saturate_cast<short>(cvRound(.))
+            c1 = int(np.rint(fx * np.float32(2048.0)))
+            out.append((s, min(s + 1, n_in - 1), c0, c1))
+        return out
+    cx, cy = coeffs(W, ow), coeffs(H, oh)
+    src = img.astype(np.int64)
+    dst = np.zeros((oh, ow, C), dtype=np.uint8)
+    for y, (y0, y1, b0, b1) in enumerate(cy):
+        for x, (x0, x1, a0, a1) in enumerate(cx):
+            for c in range(C):
+                s0 = int(src[y0, x0, c]) * a0 + int(src[y0, x1, c]) * a1
+                s1 = int(src[y1, x0, c]) * a0 + int(src[y1, x1, c]) * a1
+                v = (((b0 * (s0 >> 4)) >> 16) + ((b1 * (s1 >> 4)) >> 16) + 2) >> 2
+                dst[y, x, c] = min(max(v, 0), 255)
+    return dst
+
+
+def detection_resize_size(image_shape, size, max_size=None, auto_divide=None):
+    """Resize._resize's size arithmetic, transforms.py:114-152, kept in the reference's own swapped (w, h) terms:
+    returns the (width, height) pair it hands to cv2.resize."""
+    def with_aspect(image_shape, shape, max_shape=None):
+        h, w = image_shape
+        if max_shape is not None:
+            lo, hi = float(min((w, h))), float(max((w, h)))
+            if hi / lo * shape > max_shape:
+                shape = int(round(max_shape * lo / hi))
+        if (w <= h and w == shape) or (h <= w and h == shape):
+            return (h, w)
+        if w < h:
+            ow = shape
+            oh = int(shape * h / w)
+        else:
+            oh = shape
+            ow = int(shape * w / h)
+        return (oh, ow)
+    if isinstance(size, (list, tuple)):
+        out = tuple(size)
+    else:
+        out = with_aspect(tuple(image_shape)[::-1], size, max_size)      # :143-148: every argument reversed
+    if auto_divide:
+        out = tuple(i + (auto_divide - i % auto_divide if i % auto_divide else 0) for i in out)
+    return out
+
+
+def detection_preprocess(img, size, max_size, auto_divide, mean, std):
+    """Compose([Resize(size, max_size, auto_divide), Normalize(mean, std)]) of predict-YOLOv3.py:54-61 on one uint8 image."""
+    import numpy as np
+    dsize = detection_resize_size(img.shape[:2], size, max_size, auto_divide)
+    r = cv2_resize_linear_u8(img, dsize)
+    return (r.astype(np.float32) / 255.0 - np.asarray(mean, np.float32)) / np.asarray(std, np.float32)
+
+
+def yolo_iou_aware(out, na, factor):
+    """YOLOv3Head.forward with iou_aware, yolov3.py:355-376 (+ _de_sigmoid :113-119), one NCHW head map (b, na*(6+C), h, w)."""
+    ioup, x = out[:, 0:na, :, :], out[:, na:, :, :]
+    b, c, h, w = x.shape
+    no = c // na
+    x = x.reshape((b, na, no, h * w))
+    ioup = torch.sigmoid(ioup.reshape((b, na, 1, h * w)))
+    obj = torch.sigmoid(x[:, :, 4:5, :])
+    obj_t = obj ** (1 - factor) * ioup ** factor
+    eps = 1e-07
+    t = torch.clamp(obj_t, eps, 1.0 / eps)
+    t = torch.clamp(1.0 / t - 1.0, eps, 1.0 / eps)
+    obj_t = -torch.log(t)
+    y = torch.cat([x[:, :, :4, :], obj_t, x[:, :, 5:, :]], dim=2)
+    return y.reshape((b, c, h, w))

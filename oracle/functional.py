@@ -413,6 +413,9 @@ SWIN_CFG = {  # _swin_transformer, swin_transformer.py:628-650
     "swintransformer_tiny_patch4_window7_224": dict(img=224, dim=96, depths=[2, 2, 6, 2], heads=[3, 6, 12, 24], ws=7),
     "swintransformer_small_patch4_window7_224": dict(img=224, dim=96, depths=[2, 2, 18, 2], heads=[3, 6, 12, 24], ws=7),
     "swintransformer_base_patch4_window7_224": dict(img=224, dim=128, depths=[2, 2, 18, 2], heads=[4, 8, 16, 32], ws=7),
+    "swintransformer_base_patch4_window12_384": dict(img=384, dim=128, depths=[2, 2, 18, 2], heads=[4, 8, 16, 32], ws=12),
+    "swintransformer_large_patch4_window7_224": dict(img=224, dim=192, depths=[2, 2, 18, 2], heads=[6, 12, 24, 48], ws=7),
+    "swintransformer_large_patch4_window12_384": dict(img=384, dim=192, depths=[2, 2, 18, 2], heads=[6, 12, 24, 48], ws=12),
 }
 LN_EPS = 1e-5  # nn.LayerNorm default [TLX-recalled]; swin passes no epsilon (swin_transformer.py:258,279)
 

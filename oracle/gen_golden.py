@@ -121,20 +121,20 @@ def gen_resnet(depth, batch, wseed, xseed, fname):
         param_names=np.array(list(shapes.keys())), torch_version=torch.__version__)
 
 
-def gen_vit(arch, batch, wseed, xseed, fname):
+def gen_vit(arch, batch, wseed, xseed, fname, hw=224):
     ref = import_reference("tlxcv/models/classification/vision_transformer.py", "ref_vit")
     model = getattr(ref, arch)()
     shapes = seeded.shapes_of(model)
     params = seeded.fill(shapes, wseed)
     model.load_dict(params)
     model.set_eval()
-    x = torch.from_numpy(seeded.image_batch(batch, xseed))
+    x = torch.from_numpy(seeded.image_batch(batch, xseed, hw=hw))
     with torch.no_grad():
         ref_out = model(x)
         re_out = OF.vit({k: torch.from_numpy(v) for k, v in params.items()}, x, arch)
     d = _check(arch, ref_out, re_out)
     np.savez_compressed(
-        os.path.join(OUT, fname), arch=arch, weight_seed=wseed, input_seed=xseed, batch=batch,
+        os.path.join(OUT, fname), arch=arch, weight_seed=wseed, input_seed=xseed, batch=batch, hw=hw,
         logits=ref_out.numpy().astype(np.float32), argmax=ref_out.argmax(-1).numpy().astype(np.int64),
         restatement_max_abs_diff=np.float64(d), pinned_by="reference-file-on-tlx_cpu",
         param_names=np.array(list(shapes.keys())), torch_version=torch.__version__)
@@ -477,11 +477,14 @@ def main(only=()):
     job(gen_resnet, 18, 2, 11, 10, "resnet18_b2.npz")
     job(gen_vit, "vit_base_patch16_224", 2, 2, 0, "vit_b16_b2.npz")       # BASELINE.json configs[2] graph
     job(gen_vit, "vit_small_patch16_224", 1, 12, 3, "vit_small_b1.npz")   # no qkv bias, qk_scale override, hd=96
+    job(gen_vit, "vit_base_patch16_384", 1, 21, 19, "vit_b16_384_b1.npz", hw=384)      # 577 tokens: the long-sequence attention
     swin = "tlxcv/models/classification/swin_transformer.py"
     job(gen_paddle_converted, swin, "swintransformer_base_patch4_window7_224",
                          lambda p, x: OF.swin(p, x, "swintransformer_base_patch4_window7_224"), 2, 3, 0, "swin_b_b2.npz")   # BASELINE.json configs[3] graph
     job(gen_paddle_converted, swin, "swintransformer_tiny_patch4_window7_224",
                          lambda p, x: OF.swin(p, x, "swintransformer_tiny_patch4_window7_224"), 1, 13, 4, "swin_t_b1.npz")
+    job(gen_paddle_converted, swin, "swintransformer_base_patch4_window12_384",            # 144-token windows, 384 x 384
+                         lambda p, x: OF.swin(p, x, "swintransformer_base_patch4_window12_384"), 1, 22, 20, "swin_b_w12_384_b1.npz", hw=384)
     job(gen_paddle_converted, "tlxcv/models/classification/mobilenetv2.py", "mobilenet_v2", lambda p, x: OF.mobilenetv2(p, x),
                          2, 7, 5, "mobilenetv2_b2.npz", hw=128)
     mbv3 = "tlxcv/models/classification/mobilenetv3.py"

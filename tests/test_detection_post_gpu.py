@@ -83,3 +83,48 @@ def test_yolov3_forward_ends_in_detections(dev, fp32_mode):
     assert out["labels"].tolist() == want[:, 0].int().tolist()
     np.testing.assert_allclose(out["scores"], want[:, 1].numpy(), rtol=1e-4, atol=1e-5)
     assert np.abs(out["boxes"] - want[:, 2:].numpy().astype(int)).max() <= 1          # integer pixel boxes (cvt_results)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["fp32", "fp16"])
+def test_iou_aware_objectness(dev, dtype):
+    """tlxmi_yolo_iou_aware against the reference lines restated (yolov3.py:355-376): IoU channels in front, dropped on output."""
+    rng = np.random.default_rng(31)
+    A, C, H, W = 3, 7, 5, 6
+    x = torch.from_numpy(rng.standard_normal((2, A * (6 + C), H, W)).astype(np.float32) * 2.0)
+    x[0, 0, 0, 0], x[0, A + 4, 0, 0] = 40.0, 40.0                    # saturated sigmoid: the clip of _de_sigmoid decides
+    x[0, 1, 0, 1], x[0, A + (5 + C) + 4, 0, 1] = -40.0, -40.0
+    if dtype == torch.float16:
+        x = x.half().float()
+    want = OD.yolo_iou_aware(x, A, 0.4)
+    got = E.yolo_iou_aware(x.permute(0, 2, 3, 1).contiguous().to(dtype).to(dev), A, C, 0.4)
+    assert got.shape == (2, H, W, A * (5 + C))
+    tol = dict(atol=2e-5, rtol=2e-5) if dtype == torch.float32 else dict(atol=1e-2, rtol=2e-3)
+    torch.testing.assert_close(got.float().cpu().permute(0, 3, 1, 2), want, **tol)
+
+
+def test_yolov3_head_iou_aware_and_neck_for_mot(dev, fp32_mode):
+    from tlxcv_amd import models
+    from oracle import functional as OF
+    rng = np.random.default_rng(32)
+    head = models.YOLOv3Head(in_channels=[64, 32], anchors=[[10, 13], [16, 30], [33, 23], [30, 61]], anchor_masks=[[2, 3], [0, 1]],
+                             num_classes=5, iou_aware=True, iou_aware_factor=0.3)
+    params = seeded.fill(seeded.shapes_of(head), 9)
+    head.load_dict(params)
+    head = head.to(dev).set_eval()
+    feats = [torch.from_numpy(rng.standard_normal((1, 64, 4, 4)).astype(np.float32)), torch.from_numpy(rng.standard_normal((1, 32, 8, 8)).astype(np.float32))]
+    outs = head([f.to(dev) for f in feats])
+    assert [tuple(o.shape) for o in outs] == [(1, 2 * 10, 4, 4), (1, 2 * 10, 8, 8)]
+    for i, (f, o) in enumerate(zip(feats, outs)):
+        w, b = torch.from_numpy(params[f"yolo_outputs_{i}.filters"]), torch.from_numpy(params[f"yolo_outputs_{i}.biases"])
+        want = OD.yolo_iou_aware(torch.nn.functional.conv2d(f, w, b), 2, 0.3)
+        torch.testing.assert_close(o.cpu(), want, atol=1e-4, rtol=1e-4)
+    # neck with for_mot (yolov3.py:243-257): same tips, plus one route map per level
+    fpn = models.YOLOv3FPN(in_channels=[64, 128, 256])
+    fpn.load_dict(seeded.fill(seeded.shapes_of(fpn), 10))
+    fpn = fpn.to(dev).set_eval()
+    body = [torch.from_numpy(rng.standard_normal(s).astype(np.float32)).to(dev) for s in ((1, 64, 16, 16), (1, 128, 8, 8), (1, 256, 4, 4))]
+    plain = fpn(body)
+    mot = fpn(body, for_mot=True)
+    assert set(mot) == {"yolo_feats", "emb_feats"} and len(mot["emb_feats"]) == 3
+    assert all(torch.equal(a, b) for a, b in zip(plain, mot["yolo_feats"]))
+    assert [tuple(t.shape[1:]) for t in mot["emb_feats"]] == [(512, 4, 4), (256, 8, 8), (128, 16, 16)]      # the blocks' route maps (YoloDetBlock width 512 / 256 / 128)

@@ -1,7 +1,8 @@
 """End-to-end parity of the remaining hot-path model families on the MI355X against the committed
 golden fixtures (tests/golden/, produced by oracle/gen_golden.py):
-  MobileNetV1, DarkNet-53   pinned by the reference's own model files run on the oracle's tlx stand-in;
-  Swin-T/B, YOLOv3 neck+head restatement-only (their reference files need Paddle / torchvision)."""
+every fixture written by the reference's OWN model file running unmodified on the oracle's tlx stand-in (MobileNetV1,
+DarkNet-53 directly; Swin-T/B incl. the window-12 / 384 x 384 model, MobileNetV2/V3, YOLOv3 through the paddle / paddle2tlx /
+torchvision import shims of oracle/shims)."""
 import os
 
 import numpy as np
@@ -24,9 +25,10 @@ def build(ctor, seed, dev, **kw):
 
 CLASSIFIERS = [("swin_b_b2.npz", "swintransformer_base_patch4_window7_224"),
                ("swin_t_b1.npz", "swintransformer_tiny_patch4_window7_224"),
+               ("swin_b_w12_384_b1.npz", "swintransformer_base_patch4_window12_384"),      # 144-token windows (swin_transformer.py:641-645)
                ("mobilenetv1_b2.npz", "MobileNetV1"), ("mobilenetv2_b2.npz", "mobilenet_v2"),
                ("mobilenetv3_small_b2.npz", "mobilenet_v3_small"), ("mobilenetv3_large_b1.npz", "mobilenet_v3_large")]
-HW = {"mobilenetv2_b2.npz": 128, "mobilenetv3_small_b2.npz": 128, "mobilenetv3_large_b1.npz": 128}
+HW = {"mobilenetv2_b2.npz": 128, "mobilenetv3_small_b2.npz": 128, "mobilenetv3_large_b1.npz": 128, "swin_b_w12_384_b1.npz": 384}
 
 
 @pytest.mark.parametrize("fname,ctor", CLASSIFIERS)

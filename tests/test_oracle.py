@@ -158,7 +158,7 @@ def test_every_fixture_is_pinned_by_a_reference_file():
     oracle/shims.  A restatement-only fixture would be a regression."""
     import glob
     names = sorted(glob.glob(os.path.join(GOLDEN, "*.npz")))
-    assert len(names) >= 21
+    assert len(names) >= 23
     for f in names:
         g = np.load(f)
         assert str(g["pinned_by"]).startswith("reference-file-on-tlx_cpu"), (f, str(g["pinned_by"]))
@@ -170,6 +170,8 @@ def test_swin_and_mobilenet_restatements_reproduce_golden():
     for fname, ctor, fn, hw in (
             ("swin_t_b1.npz", "swintransformer_tiny_patch4_window7_224",
              lambda p, x: OF.swin(p, x, "swintransformer_tiny_patch4_window7_224"), 224),
+            ("swin_b_w12_384_b1.npz", "swintransformer_base_patch4_window12_384",
+             lambda p, x: OF.swin(p, x, "swintransformer_base_patch4_window12_384"), 384),
             ("mobilenetv2_b2.npz", "mobilenet_v2", OF.mobilenetv2, 128),
             ("mobilenetv3_small_b2.npz", "mobilenet_v3_small", lambda p, x: OF.mobilenetv3(p, x, OF.MBV3_SMALL), 128)):
         g = np.load(os.path.join(GOLDEN, fname))

@@ -20,11 +20,12 @@ def build(arch, seed, dev):
     return m.to(dev).set_eval()
 
 
-@pytest.mark.parametrize("fname", ["vit_b16_b2.npz", "vit_small_b1.npz"])
+@pytest.mark.parametrize("fname", ["vit_b16_b2.npz", "vit_small_b1.npz", "vit_b16_384_b1.npz"])
 def test_fp32_matches_golden_1e4_and_argmax_exact(dev, fp32_mode, fname):
     g = np.load(os.path.join(GOLDEN, fname))
     m = build(str(g["arch"]), int(g["weight_seed"]), dev)
-    x = torch.from_numpy(seeded.image_batch(int(g["batch"]), int(g["input_seed"]))).to(dev)
+    hw = int(g["hw"]) if "hw" in g.files else 224
+    x = torch.from_numpy(seeded.image_batch(int(g["batch"]), int(g["input_seed"]), hw=hw)).to(dev)
     y = m(x)
     err = np.abs(y.cpu().numpy() - g["logits"]).max()
     assert err <= 1e-4, err
@@ -39,6 +40,15 @@ def test_fp16_tracks_golden(dev, fp16_mode):
     y = m(x).float().cpu().numpy()
     ref = g["logits"]
     check_fp16_logits(y, ref, g["argmax"], "vit_b16_b2")
+
+
+def test_fp16_384_tracks_golden(dev, fp16_mode):
+    """vit_base_patch16_384 (vision_transformer.py:358-, 577 tokens) in the throughput mode against the reference-file fixture."""
+    g = np.load(os.path.join(GOLDEN, "vit_b16_384_b1.npz"))
+    m = build("vit_base_patch16_384", int(g["weight_seed"]), dev)
+    x = torch.from_numpy(seeded.image_batch(1, int(g["input_seed"]), hw=384)).to(dev)
+    y = m(x).float().cpu().numpy()
+    check_fp16_logits(y, g["logits"], g["argmax"], "vit_b16_384_b1")
 
 
 def test_wrong_image_size_asserts(dev, fp16_mode):

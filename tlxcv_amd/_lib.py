@@ -67,6 +67,8 @@ PROTOTYPES = {
     "tlxmi_bottleneck_seam": [C.POINTER(SeamDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "tlxmi_bottleneck_seam_proj": [C.POINTER(SeamDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "tlxmi_preprocess_u8": [C.POINTER(PreprocDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "tlxmi_preprocess_linear_u8": [C.POINTER(PreprocDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "tlxmi_yolo_iou_aware": [_vp, _vp, _i, _l, _i, _i, _f, _vp],
     "tlxmi_yolo_box": [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _f, _i, _i, _f, _vp, _vp, _i, _i, _vp],
     "tlxmi_multiclass_nms": [_vp, _vp, _i, _i, _i, _f, _f, _i, _vp, _vp, _vp, _vp],
     "tlxmi_linear_splitk": [_i, _l, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _u, _vp, _i, _vp],

@@ -495,6 +495,7 @@ template <int HD> static int launch_hd(const AttnArgs& a, hipStream_t st) {
     if (nt <= 2) return launch_one<HD, 2>(a, st);
     if (nt <= 4) return launch_one<HD, 4>(a, st);
     if (nt <= 8) return launch_one<HD, 8>(a, st);
+    if (nt <= 10) return launch_one<HD, 10>(a, st);      // 144-token windows (Swin window 12, swin_transformer.py:641-650)
     if (nt <= 14) return launch_one<HD, 14>(a, st);
     return launch_one<HD, 16>(a, st);
 }

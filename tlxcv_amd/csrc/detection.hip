@@ -21,6 +21,31 @@ namespace tlxmi {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// IoU-aware head (YOLOv3Head.forward, yolov3.py:355-376): the head map carries A IoU predictions in front of the A * (5 + C)
+// box entries; objectness becomes obj' = de_sigmoid(sigmoid(obj)^(1 - f) * sigmoid(ioup)^f) and the IoU channels are dropped:
+// x [N][H*W][A*(6+C)] (NHWC: channel a = ioup of anchor a, channel A + a*(5+C) + e = entry e) -> y [N][H*W][A*(5+C)].
+// _de_sigmoid (:113-119): x clipped to [eps, 1/eps], then -log(clip(1/x - 1, eps, 1/eps)), eps = 1e-7.
+template <typename T>
+__global__ void iou_aware_kernel(const T* __restrict__ x, T* __restrict__ y, long pixels, int A, int C, float factor) {
+    const int E5 = 5 + C, cin = A * (6 + C), cout = A * E5;
+    const long total = pixels * cout;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % cout);
+        const long p = i / cout;
+        const int a = ch / E5, e = ch - a * E5;
+        float v = (float)x[p * cin + A + ch];
+        if (e == 4) {
+            const float obj = sigmoidf_(v), iou = sigmoidf_((float)x[p * cin + a]);
+            float t = powf(obj, 1.f - factor) * powf(iou, factor);
+            const float eps = 1e-7f;
+            t = fminf(fmaxf(t, eps), 1.f / eps);
+            t = fminf(fmaxf(1.f / t - 1.f, eps), 1.f / eps);
+            v = -logf(t);
+        }
+        y[i] = (T)v;
+    }
+}
+
 template <typename T>
 __global__ void yolo_box_kernel(const T* __restrict__ x, const int* __restrict__ img_size, const float* __restrict__ anchors,
                                 float* __restrict__ boxes, float* __restrict__ scores, int N, int A, int C, int H, int W,
@@ -165,6 +190,16 @@ __global__ __launch_bounds__(1024) void nms_image_kernel(const float* __restrict
 }  // namespace tlxmi
 
 using namespace tlxmi;
+
+extern "C" int tlxmi_yolo_iou_aware(const void* x, void* y, int dtype, int64_t pixels, int A, int C, float factor, void* stream) {
+    TLXMI_REQUIRE(x && y && pixels > 0 && A > 0 && C >= 0, TLXMI_ERR_BAD_ARG, "yolo_iou_aware: bad argument");
+    TLXMI_REQUIRE(dtype == TLXMI_F16 || dtype == TLXMI_F32, TLXMI_ERR_BAD_ARG, "yolo_iou_aware: bad dtype");
+    const long total = (long)pixels * A * (5 + C);
+    const unsigned grid = (unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    if (dtype == TLXMI_F16) hipLaunchKernelGGL((iou_aware_kernel<half_t>), dim3(grid), dim3(256), 0, as_stream(stream), (const half_t*)x, (half_t*)y, (long)pixels, A, C, factor);
+    else hipLaunchKernelGGL((iou_aware_kernel<float>), dim3(grid), dim3(256), 0, as_stream(stream), (const float*)x, (float*)y, (long)pixels, A, C, factor);
+    return check_launch("yolo_iou_aware");
+}
 
 extern "C" int tlxmi_yolo_box(const void* x, int dtype, int N, int A, int C, int H, int W, int channels_last, const int32_t* img_size,
                               const float* anchors, float conf_thresh, int downsample_ratio, int clip_bbox, float scale_x_y,

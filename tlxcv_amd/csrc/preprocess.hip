@@ -94,9 +94,75 @@ __global__ void resize_v_norm_kernel(const PreArgs a) {
     }
 }
 
+// ---- the detection demo's pipeline (demo/object_detection/transforms.py:96-246, called at predict-YOLOv3.py:54-61):
+// Resize(size, max_size, auto_divide) -> cv2.resize(..., INTER_LINEAR) on the uint8 image, then Normalize
+// ((v / 255 - mean) / std in fp32).  OpenCV's 8-bit bilinear resize restated (resize.cpp, HResizeLinear /
+// VResizeLinear<uchar>): two taps per axis with 11-bit fixed-point weights (no anti-aliasing when shrinking),
+//     row(y)[x] = S[y][x0] * a0 + S[y][x0 + 1] * a1                                   (int, scale 2^11)
+//     out       = ((b0 * (row(y0)[x] >> 4)) >> 16) + ((b1 * (row(y1)[x] >> 4)) >> 16) + 2) >> 2
+// with the tap indices / weights of both axes built by the caller (tlx/vision/transforms/detection.py: the same
+// float arithmetic as OpenCV's coefficient loop).  One pass, one thread per output pixel: HBM-bound byte work.
+// UNPINNED: OpenCV is not in this image and the reference holds no vector for it (an OpenCV built with IPP / a HAL
+// may differ in the last bit); the oracle restates the same published algorithm independently.
+struct PreLinArgs {
+    const uint8_t* src;                       // [N][H][W][C]
+    const int* xi;  const int* xa;            // [OW][2] source columns (clamped), [OW][2] weights
+    const int* yi;  const int* yb;            // [OH][2], [OH][2]
+    const float* mean;  const float* std_;
+    void* out;
+    int N, H, W, OH, OW, C, layout, normalize;
+};
+
+template <typename TD>
+__global__ void resize_linear_norm_kernel(const PreLinArgs a) {
+    TD* out = reinterpret_cast<TD*>(a.out);
+    const long total = (long)a.N * a.OH * a.OW;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % a.OW);
+        const long r = i / a.OW;
+        const int yy = (int)(r % a.OH);
+        const long n = r / a.OH;
+        const int x0 = a.xi[2 * x], x1 = a.xi[2 * x + 1], a0 = a.xa[2 * x], a1 = a.xa[2 * x + 1];
+        const int y0 = a.yi[2 * yy], y1 = a.yi[2 * yy + 1], b0 = a.yb[2 * yy], b1 = a.yb[2 * yy + 1];
+        const uint8_t* r0 = a.src + (n * a.H + y0) * (long)a.W * a.C;
+        const uint8_t* r1 = a.src + (n * a.H + y1) * (long)a.W * a.C;
+        for (int c = 0; c < a.C; ++c) {
+            const int h0 = (int)r0[x0 * a.C + c] * a0 + (int)r0[x1 * a.C + c] * a1;
+            const int h1 = (int)r1[x0 * a.C + c] * a0 + (int)r1[x1 * a.C + c] * a1;
+            int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            v = v < 0 ? 0 : (v > 255 ? 255 : v);
+            float f = __fdiv_rn((float)v, 255.0f);                                   // image.astype(float32) / 255.0
+            if (a.normalize) f = __fdiv_rn(__fsub_rn(f, a.mean[c]), a.std_[c]);     // (. - mean) / std
+            if (a.layout == 0) out[((n * a.C + c) * a.OH + yy) * (long)a.OW + x] = (TD)f;
+            else out[i * a.C + c] = (TD)f;
+        }
+    }
+}
+
 }  // namespace tlxmi
 
 using namespace tlxmi;
+
+extern "C" int tlxmi_preprocess_linear_u8(const tlxmi_preproc_desc* d, const void* images, const int32_t* xidx, const int32_t* xcoef,
+                                          const int32_t* yidx, const int32_t* ycoef, const float* mean, const float* std_, void* out,
+                                          void* stream) {
+    TLXMI_REQUIRE(d && images && xidx && xcoef && yidx && ycoef && out, TLXMI_ERR_BAD_ARG, "preprocess_linear_u8: null argument");
+    TLXMI_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->C >= 1 && d->C <= 4 && d->out_h > 0 && d->out_w > 0, TLXMI_ERR_BAD_ARG,
+                  "preprocess_linear_u8: bad extent");
+    TLXMI_REQUIRE(d->out_dtype == TLXMI_F16 || d->out_dtype == TLXMI_F32, TLXMI_ERR_BAD_ARG, "preprocess_linear_u8: bad output dtype");
+    TLXMI_REQUIRE(d->layout == 0 || d->layout == 1, TLXMI_ERR_BAD_ARG, "preprocess_linear_u8: layout must be 0 (NCHW) or 1 (NHWC)");
+    TLXMI_REQUIRE(!d->normalize || (mean && std_), TLXMI_ERR_BAD_ARG, "preprocess_linear_u8: normalize needs mean and std");
+    TLXMI_REQUIRE((long long)d->N * d->H * d->W * d->C < (1ll << 40) && (long long)d->N * d->out_h * d->out_w * d->C < (1ll << 40),
+                  TLXMI_ERR_UNSUPPORTED, "preprocess_linear_u8: batch too large");
+    PreLinArgs a;
+    a.src = (const uint8_t*)images; a.xi = xidx; a.xa = xcoef; a.yi = yidx; a.yb = ycoef; a.mean = mean; a.std_ = std_; a.out = out;
+    a.N = d->N; a.H = d->H; a.W = d->W; a.OH = d->out_h; a.OW = d->out_w; a.C = d->C; a.layout = d->layout; a.normalize = d->normalize;
+    const long total = (long)d->N * d->out_h * d->out_w;
+    const unsigned grid = (unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    if (d->out_dtype == TLXMI_F16) hipLaunchKernelGGL((resize_linear_norm_kernel<half_t>), dim3(grid), dim3(256), 0, as_stream(stream), a);
+    else hipLaunchKernelGGL((resize_linear_norm_kernel<float>), dim3(grid), dim3(256), 0, as_stream(stream), a);
+    return check_launch("preprocess_linear_u8");
+}
 
 extern "C" size_t tlxmi_preprocess_u8_workspace_bytes(const tlxmi_preproc_desc* d) {
     if (!d || d->N <= 0 || d->H <= 0 || d->out_w <= 0 || d->C <= 0) return 0;

@@ -954,6 +954,18 @@ def yolo_box(heads_nhwc, anchors, num_classes, img_size, conf_thresh=0.005, down
     return boxes, scores
 
 
+def yolo_iou_aware(head_nhwc, num_anchors, num_classes, factor):
+    """YOLOv3Head's IoU-aware objectness (yolov3.py:355-376) on one NHWC head map (N,H,W,A*(6+C)) -> (N,H,W,A*(5+C))."""
+    need_gpu(head_nhwc, "head map")
+    N, H, W, Cc = head_nhwc.shape
+    if Cc != num_anchors * (6 + num_classes) or not head_nhwc.is_contiguous():
+        raise RuntimeError(f"yolo_iou_aware: a dense (N,H,W,{num_anchors * (6 + num_classes)}) map is expected")
+    y = torch.empty((N, H, W, num_anchors * (5 + num_classes)), dtype=head_nhwc.dtype, device=head_nhwc.device)
+    _lib.call("tlxmi_yolo_iou_aware", _p(head_nhwc), _p(y), dt_code(head_nhwc.dtype), N * H * W, int(num_anchors), int(num_classes),
+              C.c_float(factor), _stream())
+    return y
+
+
 def multiclass_nms(boxes, scores, score_threshold=0.05, nms_threshold=0.5, keep_top_k=100):
     """tlx_multiclass_nms (detection/utils/ops.py:255-329) on the device: boxes (N,M,4), scores (N,M,C) fp32 ->
     (detections (N, keep_top_k, 6) rows (class, score, x1, y1, x2, y2), counts (N,) int32)."""

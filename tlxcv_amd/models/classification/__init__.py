@@ -5,7 +5,8 @@ from .vision_transformer import (VisionTransformer, vit_small_patch16_224, vit_b
                                  vit_large_patch16_384, vit_large_patch32_384)
 from .swin_transformer import (SwinTransformer, swintransformer_tiny_patch4_window7_224,  # noqa: F401
                                swintransformer_small_patch4_window7_224, swintransformer_base_patch4_window7_224,
-                               swintransformer_large_patch4_window7_224)
+                               swintransformer_large_patch4_window7_224, swintransformer_base_patch4_window12_384,
+                               swintransformer_large_patch4_window12_384)
 from .mobilenetv1 import MobileNetV1  # noqa: F401
 from .mobilenetv2 import (MobileNetV2, mobilenet_v2, MobileNetV3Small, MobileNetV3Large, mobilenet_v3_small,  # noqa: F401
                           mobilenet_v3_large)

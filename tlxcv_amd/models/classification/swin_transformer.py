@@ -23,7 +23,8 @@ from ...tlx import nn
 from ...tlx.nn import as_nhwc
 
 __all__ = ["SwinTransformer", "swintransformer_tiny_patch4_window7_224", "swintransformer_small_patch4_window7_224",
-           "swintransformer_base_patch4_window7_224", "swintransformer_large_patch4_window7_224"]
+           "swintransformer_base_patch4_window7_224", "swintransformer_large_patch4_window7_224",
+           "swintransformer_base_patch4_window12_384", "swintransformer_large_patch4_window12_384"]
 
 trunc_normal_ = nn.initializers.TruncatedNormal(stddev=0.02)
 
@@ -265,6 +266,11 @@ _CFG = {
     'swintransformer_small_patch4_window7_224': dict(embed_dim=96, depths=[2, 2, 18, 2], num_heads=[3, 6, 12, 24], window_size=7),
     'swintransformer_base_patch4_window7_224': dict(embed_dim=128, depths=[2, 2, 18, 2], num_heads=[4, 8, 16, 32], window_size=7, drop_path_rate=0.5),
     'swintransformer_large_patch4_window7_224': dict(embed_dim=192, depths=[2, 2, 18, 2], num_heads=[6, 12, 24, 48], window_size=7),
+    # 384 x 384 input, 12 x 12 windows = 144 tokens per window (swin_transformer.py:641-650); stage 4 is one window (no shift)
+    'swintransformer_base_patch4_window12_384': dict(img_size=384, embed_dim=128, depths=[2, 2, 18, 2], num_heads=[4, 8, 16, 32],
+                                                     window_size=12, drop_path_rate=0.5),
+    'swintransformer_large_patch4_window12_384': dict(img_size=384, embed_dim=192, depths=[2, 2, 18, 2], num_heads=[6, 12, 24, 48],
+                                                      window_size=12),
 }
 
 
@@ -288,3 +294,11 @@ def swintransformer_base_patch4_window7_224(pretrained=False, use_ssld=False, **
 
 def swintransformer_large_patch4_window7_224(pretrained=False, use_ssld=False, **kwargs):
     return _swin('swintransformer_large_patch4_window7_224', pretrained, use_ssld, **kwargs)
+
+
+def swintransformer_base_patch4_window12_384(pretrained=False, use_ssld=False, **kwargs):
+    return _swin('swintransformer_base_patch4_window12_384', pretrained, use_ssld, **kwargs)
+
+
+def swintransformer_large_patch4_window12_384(pretrained=False, use_ssld=False, **kwargs):
+    return _swin('swintransformer_large_patch4_window12_384', pretrained, use_ssld, **kwargs)

@@ -70,7 +70,7 @@ class YOLOv3FPN(nn.Module):
                 self.routes.append(ConvBNLayer(ch_in=512 // 2 ** i, ch_out=256 // 2 ** i, filter_size=1, stride=1,
                                                padding=0, data_format=data_format, name="yolo_transition.{}".format(i)))
 
-    def run_nhwc(self, feats):
+    def _run(self, feats, emb=None):
         assert len(feats) == self.num_blocks
         feats = feats[::-1]
         out, route = [], None
@@ -84,14 +84,22 @@ class YOLOv3FPN(nn.Module):
                 x = cat
             route, tip = self.yolo_blocks[i].run_nhwc(x)
             out.append(tip)
+            if emb is not None:
+                emb.append(route)                       # :250-251, the block's route BEFORE the transition conv
             if i < self.num_blocks - 1:
                 route = self.routes[i].run_nhwc(route)
         return out
 
+    def run_nhwc(self, feats, emb=None):
+        return self._run(feats, emb)
+
     def forward(self, X, for_mot=False):
+        """for_mot (:243-257): also the per-level route maps, as {"yolo_feats": [...], "emb_feats": [...]}."""
+        emb = [] if for_mot else None
+        tips = [from_nhwc(t, self.data_format) for t in self._run([as_nhwc(x, self.data_format) for x in X], emb)]
         if for_mot:
-            raise NotImplementedError("for_mot (embedding outputs) is out of scope")
-        return [from_nhwc(t, self.data_format) for t in self.run_nhwc([as_nhwc(x, self.data_format) for x in X])]
+            return {"yolo_feats": tips, "emb_feats": [from_nhwc(t, self.data_format) for t in emb]}
+        return tips
 
 
 class YOLOv3Head(nn.Module):
@@ -101,15 +109,14 @@ class YOLOv3Head(nn.Module):
                  iou_aware=False, iou_aware_factor=0.4, data_format="channels_first"):
         super().__init__()
         assert len(in_channels) > 0, "in_channels length should > 0"
-        if iou_aware:
-            raise NotImplementedError("iou_aware head is out of scope")
+        self.iou_aware, self.iou_aware_factor = bool(iou_aware), float(iou_aware_factor)
         self.in_channels, self.num_classes, self.data_format = in_channels, num_classes, data_format
         self.parse_anchor(anchors, anchor_masks)
         self.num_outputs = len(self.anchors)
         self.yolo_outputs = []
         for i, anc in enumerate(self.anchors):
             self.yolo_outputs.append(nn.GroupConv2d(
-                in_channels=self.in_channels[i], out_channels=len(anc) * (self.num_classes + 5), kernel_size=1, stride=1,
+                in_channels=self.in_channels[i], out_channels=len(anc) * (self.num_classes + (6 if self.iou_aware else 5)), kernel_size=1, stride=1,
                 padding=0, data_format=data_format, b_init=nn.initializers.xavier_uniform(),
                 W_init=nn.initializers.HeNormal(), name="yolo_output.{}".format(i)))
 
@@ -124,7 +131,10 @@ class YOLOv3Head(nn.Module):
 
     def run_nhwc(self, feats):
         assert len(feats) == len(self.anchors)
-        return [fn.run_nhwc(f) for fn, f in zip(self.yolo_outputs, feats)]
+        outs = [fn.run_nhwc(f) for fn, f in zip(self.yolo_outputs, feats)]
+        if self.iou_aware:                              # :355-376: IoU-weighted objectness, the IoU channels dropped
+            outs = [E.yolo_iou_aware(o.contiguous(), len(anc), self.num_classes, self.iou_aware_factor) for o, anc in zip(outs, self.anchors)]
+        return outs
 
     def forward(self, outputs, targets=None):
         if targets is not None:
@@ -180,10 +190,15 @@ class YOLOv3(nn.Module):
         self._require_eval()
         v = as_nhwc(inputs["images"], self.data_format)
         body = self.backbone.run_nhwc(v)
-        neck = self.neck.run_nhwc(body)
+        emb = [] if self.for_mot else None
+        neck = self.neck.run_nhwc(body, emb)
         head = self.yolo_head.run_nhwc(neck)
         conv = lambda ts: [from_nhwc(t, self.data_format) for t in ts]
         out = {"images": inputs["images"], "body_feats": conv(body), "neck_feats": conv(neck), "yolo_head_outs": conv(head)}
+        if self.for_mot:
+            # :64-65: the embedding maps of a tracker (JDE); the reference's for_mot post-process additionally returns the NMS
+            # keep indices (boxes_idx / nms_keep_idx, :70-78) through an index-returning NMS that is not part of this engine
+            out["emb_feats"] = conv(emb)
         # :67-103: decode + NMS -> labels / scores / boxes / bbox_num
         img = inputs["images"]
         n, (h, w) = img.shape[0], (img.shape[2:4] if self.data_format == "channels_first" else img.shape[1:3])
