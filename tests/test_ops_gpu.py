@@ -141,6 +141,24 @@ def test_attention_with_presummed_table(dev, B, N, heads, hd, masked):
     torch.testing.assert_close(got.float().cpu(), want, atol=4e-3, rtol=4e-3)
 
 
+@pytest.mark.parametrize("B,N,heads,hd", [(2, 577, 3, 64), (1, 257, 2, 64), (3, 300, 4, 32), (1, 1025, 2, 64), (2, 640, 1, 32)])
+def test_long_sequence_attention_on_the_chunked_online_softmax_kernel(dev, B, N, heads, hd):
+    """More than 256 tokens (ViT at 384 x 384: 577, vision_transformer.py:358-): keys in chunks of 128 through LDS, running
+    maximum / sum per query tile.  577 = 4 chunks + 65 keys, 257 = one key in the last chunk, 640 = whole chunks only."""
+    rng = np.random.default_rng(60 + N)
+    qkv = rnd(rng, (B, N, 3 * heads * hd))
+    # a dominant key far into the sequence for some queries: the running maximum jumps in a LATER chunk (the rescale path)
+    qkv[0, 3, :hd] = 4.0
+    qkv[0, N - 2, heads * hd:heads * hd + hd] = 5.0
+    qkv[0, 200, :hd] = -3.0
+    qkv = q16(qkv)
+    want = _ref_attention(qkv, heads, hd ** -0.5)
+    got = E.attention(qkv.half().to(dev), heads, hd ** -0.5)
+    assert torch.isfinite(got).all()
+    torch.testing.assert_close(got.float().cpu(), want, atol=4e-3, rtol=4e-3)
+    assert torch.equal(E.attention(qkv.half().to(dev), heads, hd ** -0.5), got)
+
+
 def test_attention_softmax_is_stable_for_large_scores(dev):
     """Forces the max-subtraction path: one key dominates with a score ~ +80 (exp overflows in fp16)."""
     rng = np.random.default_rng(7)

@@ -167,6 +167,8 @@ template <typename T> static int launch_rows(const AttnArgs& a, hipStream_t st) 
 }
 
 int launch_attn_mfma(const AttnArgs& a, hipStream_t st);  // attention_mfma.hip
+bool attn_flash_ok(const AttnArgs& a);                     // attention_mfma.hip: chunked online-softmax kernel (long sequences)
+int launch_attn_flash(const AttnArgs& a, hipStream_t st);
 
 // General multi-head attention: separate, strided Q / K / V (sequence-first or batch-first, packed or not), query and
 // key lengths may differ (cross attention), optional additive mask, optional head-averaged weights.
@@ -271,7 +273,10 @@ extern "C" int tlxmi_attention(const tlxmi_attn_desc* d, const void* qkv, const 
     a.B = d->B; a.N = d->Ntok; a.heads = d->heads; a.hd = d->hd; a.nW = mask ? d->nW : 0; a.scale = d->scale;
     a.comb = nullptr;
     hipStream_t st = as_stream(stream);
-    if (d->Ntok > 256) return d->dtype == TLXMI_F32 ? launch_long<float>(a, st) : launch_long<half_t>(a, st);
+    if (d->Ntok > 256) {
+        if (d->dtype == TLXMI_F16 && attn_flash_ok(a) && aligned16(qkv) && aligned16(out)) return launch_attn_flash(a, st);   // ViT at 384 x 384
+        return d->dtype == TLXMI_F32 ? launch_long<float>(a, st) : launch_long<half_t>(a, st);
+    }
     if (d->dtype == TLXMI_F32) return launch_rows<float>(a, st);
     if ((d->hd == 64 || d->hd == 32 || d->hd == 96) && aligned16(qkv) && aligned16(out)) return launch_attn_mfma(a, st);
     return launch_rows<half_t>(a, st);

@@ -267,6 +267,178 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const AttnArgs a) {
     }
 }
 
+// Long sequences (more than 256 tokens: ViT at 384 x 384 = 577 tokens, vision_transformer.py:358-): the same S^T = K . Q^T /
+// O^T = V^T . P^T fragments as attn_mfma_kernel, but the keys go through LDS in chunks of 16 * NTC and the softmax is
+// the online one — per query tile a running maximum m, a running sum l and the output accumulators, rescaled by
+// exp2((m - m') * c) when a chunk raises the maximum — so neither the score row nor K / V need fit anywhere at once.
+// One workgroup (4 waves) per (batch, head, group of 4 * QPW query tiles): every wave owns QPW query tiles, all of whose
+// state stays in registers while the chunks pass (QPW * (4 * DT + 2) registers); a chunk is staged by all 256 threads
+// (loads of chunk c + 1 issued into registers before chunk c is computed, written to LDS after the barrier that retires its
+// readers).  No bias / mask (ViT): the scale is folded into the exponent.  K / V are re-read once per query group (L2).
+template <int HD, int NTC, int QPW>
+__global__ __launch_bounds__(256, 2) void attn_flash_kernel(const AttnArgs a) {
+    constexpr int SR = HD * 2 + 32;
+    constexpr int CK = 16 * NTC;             // keys per chunk
+    constexpr int KS = HD / 32;
+    constexpr int DT = HD / 16;
+    constexpr int CPR = HD / 8;
+    constexpr int ITEMS = CK * CPR, PER = (ITEMS + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;
+    char* Vs = smem + CK * SR;
+
+    const int N = a.N, heads = a.heads;
+    const int nqt = (N + 15) >> 4, ngroups = (nqt + 4 * QPW - 1) / (4 * QPW);
+    const int bh = blockIdx.x / ngroups, qg = blockIdx.x - bh * ngroups;
+    const int b = bh / heads, h = bh - b * heads;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const size_t tok_ld = (size_t)3 * heads * HD;
+    const half_t* qbase = reinterpret_cast<const half_t*>(a.qkv) + (size_t)b * N * tok_ld + (size_t)h * HD;
+    const half_t* kbase = qbase + (size_t)heads * HD;
+    const half_t* vbase = qbase + (size_t)2 * heads * HD;
+    half_t* obase = reinterpret_cast<half_t*>(a.out) + (size_t)b * N * heads * HD + (size_t)h * HD;
+    const int nchunks = (N + CK - 1) / CK;
+
+    // ---- Q fragments of this wave's tiles (tile j: query tile qg * 4 * QPW + 4 * j + wv)
+    u32x4 qf[QPW][KS];
+#pragma unroll
+    for (int j = 0; j < QPW; ++j) {
+        const int query = (qg * 4 * QPW + 4 * j + wv) * 16 + li;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            qf[j][ks] = u32x4{0u, 0u, 0u, 0u};
+            if (query < N) qf[j][ks] = *reinterpret_cast<const u32x4*>(qbase + (size_t)query * tok_ld + ks * 32 + g * 8);
+        }
+    }
+    f32x4 o[QPW][DT];
+    float mrun[QPW], lrun[QPW];
+#pragma unroll
+    for (int j = 0; j < QPW; ++j) {
+        mrun[j] = -INFINITY;
+        lrun[j] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[j][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    u32x4 kreg[PER], vreg[PER];
+    auto fetch = [&](int c) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int i = t + u * 256;
+            const int key = c * CK + i / CPR, cc = i % CPR;
+            kreg[u] = u32x4{0u, 0u, 0u, 0u};
+            vreg[u] = u32x4{0u, 0u, 0u, 0u};
+            if (i < ITEMS && key < N) {
+                kreg[u] = *reinterpret_cast<const u32x4*>(kbase + (size_t)key * tok_ld + cc * 8);
+                vreg[u] = *reinterpret_cast<const u32x4*>(vbase + (size_t)key * tok_ld + cc * 8);
+            }
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int i = t + u * 256;
+            if (i < ITEMS) {
+                *reinterpret_cast<u32x4*>(Ks + (i / CPR) * SR + (i % CPR) * 16) = kreg[u];
+                *reinterpret_cast<u32x4*>(Vs + (i / CPR) * SR + (i % CPR) * 16) = vreg[u];
+            }
+        }
+    };
+    const int vlane = (4 * g + (li >> 2)) * SR + (li & 3) * 8;
+    const int klane = li * SR + g * 16;
+    const float ec = a.scale * 1.44269504088896340736f;
+
+    fetch(0);
+#pragma unroll 1
+    for (int c = 0; c < nchunks; ++c) {
+        commit();
+        __syncthreads();
+        if (c + 1 < nchunks) fetch(c + 1);           // in flight under this chunk's arithmetic
+        const bool tail = (c + 1) * CK > N;         // wave-uniform: only the last chunk can hold padded keys
+#pragma unroll
+        for (int j = 0; j < QPW; ++j) {
+            // ---- scores of query tile j against the chunk's keys
+            float s[NTC][4];
+            float mx = mrun[j];
+#pragma unroll
+            for (int kt = 0; kt < NTC; ++kt) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const u32x4 kf = *reinterpret_cast<const u32x4*>(Ks + kt * 16 * SR + klane + ks * 64);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8v, kf), __builtin_bit_cast(half8v, qf[j][ks]), acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[r];
+                    if (tail && c * CK + kt * 16 + 4 * g + r >= N) v = -INFINITY;
+                    s[kt][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            // every chunk holds at least one real key, so mx is finite from the first chunk on; mrun = -inf gives alpha = 0
+            const float alpha = __builtin_amdgcn_exp2f((mrun[j] - mx) * ec);
+            mrun[j] = mx;
+            float sum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < NTC; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(fmaf(s[kt][r], ec, -mx * ec));
+                    s[kt][r] = p;
+                    sum += p;
+                }
+            lrun[j] = lrun[j] * alpha + sum;      // per-lane partial sums: alpha is the same in the 4 lanes of a query
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) o[j][dt] *= alpha;
+            // ---- O^T += V^T . P^T
+#pragma unroll
+            for (int pr = 0; pr < NTC / 2; ++pr) {
+                half8v pf;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pf[r] = (half_t)s[2 * pr][r];
+                    pf[4 + r] = (half_t)s[2 * pr + 1][r];
+                }
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const char* a0 = Vs + pr * 32 * SR + vlane + dt * 32;
+                    const fp16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16x4*)(a0));
+                    const fp16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16x4*)(a0 + 16 * SR));
+                    half8v vf;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        vf[r] = (half_t)lo[r];
+                        vf[4 + r] = (half_t)hi[r];
+                    }
+                    o[j][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, o[j][dt], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                             // every wave is done with this chunk before the next one overwrites it
+    }
+#pragma unroll
+    for (int j = 0; j < QPW; ++j) {
+        float l = lrun[j];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.f / l;
+        const int query = (qg * 4 * QPW + 4 * j + wv) * 16 + li;
+        if (query < N) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                half4v ov;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ov[r] = (half_t)(o[j][dt][r] * inv);
+                *reinterpret_cast<half4v*>(obase + (size_t)query * heads * HD + dt * 16 + 4 * g) = ov;
+            }
+        }
+    }
+}
+
 // Persistent variant for windows of at most 64 tokens (Swin: 49 tokens, thousands of (window, head) items per
 // launch).  With one workgroup per item the launch was latency-bound — time proportional to the item count,
 // 175 / 92 / 51 / 29 us for 32768 / 16384 / 8192 / 4096 items — every workgroup paying its own global-memory
@@ -498,6 +670,24 @@ template <int HD> static int launch_hd(const AttnArgs& a, hipStream_t st) {
     if (nt <= 10) return launch_one<HD, 10>(a, st);      // 144-token windows (Swin window 12, swin_transformer.py:641-650)
     if (nt <= 14) return launch_one<HD, 14>(a, st);
     return launch_one<HD, 16>(a, st);
+}
+
+// fp16, no bias / mask, scale > 0, hd 64 or 32: the chunked online-softmax kernel for sequences of more than 256 tokens
+bool attn_flash_ok(const AttnArgs& a) {
+    return (a.hd == 64 || a.hd == 32) && !a.bias && !(a.mask && a.nW > 0) && !a.comb && a.scale > 0.f;
+}
+template <int HD> static int launch_flash_hd(const AttnArgs& a, hipStream_t st) {
+    constexpr int NTC = 8, QPW = HD == 64 ? 2 : 4;      // registers: QPW * (4 * DT + 2) state + Q fragments (hd 64 spills at 4)
+    constexpr int SR = HD * 2 + 32;
+    const size_t lds = (size_t)2 * 16 * NTC * SR;
+    const int nqt = (a.N + 15) / 16, ngroups = (nqt + 4 * QPW - 1) / (4 * QPW);
+    const long grid = (long)a.B * a.heads * ngroups;
+    if (grid >= (1l << 31)) return fail(TLXMI_ERR_UNSUPPORTED, "attention: too many (batch, head, query group) items");
+    hipLaunchKernelGGL((attn_flash_kernel<HD, NTC, QPW>), dim3((unsigned)grid), dim3(256), lds, st, a);
+    return check_launch("attention(flash)");
+}
+int launch_attn_flash(const AttnArgs& a, hipStream_t st) {
+    return a.hd == 64 ? launch_flash_hd<64>(a, st) : launch_flash_hd<32>(a, st);
 }
 
 int launch_attn_mfma(const AttnArgs& a, hipStream_t st) {
