@@ -446,8 +446,13 @@ __global__ __launch_bounds__(256, 2) void attn_flash_kernel(const AttnArgs a) {
 // the Q fragments and the bias-table values of the NEXT item are fetched into registers while the current
 // item computes, so only the first item of a workgroup waits for memory.  Each wave owns one 16-query tile.
 // Scores: scale * q.k + comb (a.comb, pre-summed bias + mask, or nothing).
-template <int HD, int NT, int KF>
-__global__ __launch_bounds__(256) void attn_win_kernel(const AttnArgs a, const int nitems) {
+// TAB (round 3): the table stays in LDS.  Read per item it is 16 KB (64 x 64 fp32) against 9 KB of q, k, v — 20 % of the kernel's
+// time at 56 x 56 — and every item of one (window position, head) uses the same one.  A workgroup is therefore bound to one
+// (window position w, head or head pair): it copies that table into LDS once, re-ordered so that wave wv's fragment kt is the
+// 1 KiB run ((wv * NT + kt) * 64 + lane) * 16 (conflict-free ds_read_b128), and walks the images img = j, j + S, ... of its
+// share (item b = img * nW + w); `spc` = S, the workgroups per (w, head pair).
+template <int HD, int NT, int KF, bool TAB = false>
+__global__ __launch_bounds__(256) void attn_win_kernel(const AttnArgs a, const int nitems, const int spc) {
     constexpr int SR = HD * 2 + 32;
     constexpr int NP = 16 * NT;
     constexpr int KS = HD / 32;
@@ -457,6 +462,8 @@ __global__ __launch_bounds__(256) void attn_win_kernel(const AttnArgs a, const i
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;
     char* Vs = smem + NP * SR;
+    char* Ts = smem + 2 * NP * SR;          // TAB: G tables of [4 waves][NT][64 lanes][16 bytes]
+    constexpr int TBYTES = 4 * NT * 1024;
 
     const int N = a.N, heads = a.heads;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -493,7 +500,7 @@ __global__ __launch_bounds__(256) void attn_win_kernel(const AttnArgs a, const i
         }
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) treg[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (a.comb && live && wv < nqt) {      // rows / columns up to npc exist in the padded table
+        if (!TAB && a.comb && live && wv < nqt) {      // rows / columns up to npc exist in the padded table
             const float* crow = a.comb + (((size_t)(a.nW > 0 ? b % a.nW : 0) * heads + h) * npc + query) * npc + 4 * g;
 #pragma unroll
             for (int kt = 0; kt < NT; ++kt)
@@ -508,10 +515,36 @@ __global__ __launch_bounds__(256) void attn_win_kernel(const AttnArgs a, const i
     // line in this CU's cache; with one item per workgroup the two halves went to workgroups on different XCDs (two L2s fetched
     // every line).  G = 1: item = blockIdx + n * grid.
     constexpr int G = HD == 32 ? 2 : 1;
+    const bool pairs = G == 2 && !(heads & 1);
+    // TAB: combo = (window position w, head group hg) = blockIdx % combos, j = blockIdx / combos
+    const int nWe = a.nW > 0 ? a.nW : 1;
+    const int hgs = pairs ? heads >> 1 : heads, combos = nWe * hgs;
+    const int combo = TAB ? (int)blockIdx.x % combos : 0, tj = TAB ? (int)blockIdx.x / combos : 0;
+    const int tw = combo / hgs, thg = combo - tw * hgs;
+    const int nimg = a.B / nWe;
     auto item_at = [&](int n) -> int {
+        if constexpr (TAB) {
+            const int img = tj + (pairs ? n >> 1 : n) * spc;
+            if (img >= nimg) return nitems;
+            return (img * nWe + tw) * heads + (pairs ? 2 * thg + (n & 1) : thg);
+        }
         if (G == 1 || (heads & 1)) return (int)blockIdx.x + n * (int)gridDim.x;
         return 2 * ((int)blockIdx.x + (n >> 1) * (int)gridDim.x) + (n & 1);
     };
+    if constexpr (TAB) {
+        // the table(s) of this workgroup: row-major [npc][npc] fp32 in memory -> fragment order in LDS, zeros beyond npc
+        const int ntab = pairs ? 2 : 1;
+        for (int tb = 0; tb < ntab; ++tb) {
+            const float* src = a.comb + ((size_t)tw * heads + (pairs ? 2 * thg + tb : thg)) * npc * npc;
+            for (int i = t; i < 64 * NT * 4; i += 256) {
+                const int row = i / (NT * 4), c4 = i - row * (NT * 4);
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (row < npc && 4 * c4 < npc) v = *reinterpret_cast<const f32x4*>(src + (size_t)row * npc + 4 * c4);
+                const int fl = ((c4 & 3) << 4) | (row & 15);
+                *reinterpret_cast<f32x4*>(Ts + tb * TBYTES + ((((row >> 4) * NT + (c4 >> 2)) * 64 + fl) << 4)) = v;
+            }
+        }
+    }
     fetch(item_at(0));
     for (int n = 0, item = item_at(0); item < nitems; item = item_at(++n)) {
         // ---- this item's K / V rows from the prefetch registers to LDS (zero rows for padded keys)
@@ -532,6 +565,11 @@ __global__ __launch_bounds__(256) void attn_win_kernel(const AttnArgs a, const i
         for (int kt = 0; kt < NT; ++kt) tb[kt] = treg[kt];
         __syncthreads();
         fetch(item_at(n + 1));         // travels while this item computes
+        if constexpr (TAB) {
+            const char* tp = Ts + (pairs ? (n & 1) * TBYTES : 0) + ((wv * NT * 64 + lane) << 4);
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) tb[kt] = *reinterpret_cast<const f32x4*>(tp + kt * 1024);
+        }
 
         if (wv < nqt) {
             const int b = item / heads, h = item - b * heads;
@@ -619,16 +657,29 @@ __global__ __launch_bounds__(256) void attn_win_kernel(const AttnArgs a, const i
 template <int HD, int NT, int KF> static int launch_win_kf(const AttnArgs& a, hipStream_t st) {
     constexpr int SR = HD * 2 + 32;
     const size_t lds = (size_t)2 * 16 * NT * SR;
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t p;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
-    }
+    const int cus = device_cus();
     const long nitems = (long)a.B * a.heads;
-    const long units = (HD == 32 && !(a.heads & 1)) ? nitems / 2 : nitems;      // head pairs (kernel: item_at)
+    const bool pairs = HD == 32 && !(a.heads & 1);
+    if (a.comb) {
+        // table-resident form: workgroups bound to one (window position, head / head pair).  Grid = what is resident at once
+        // (44 KB of LDS with two tables: 3 workgroups per CU; measured at half batch 64, stage 1..4: 66.6 / 34.9 / 20.7 / 11.0 us
+        // streaming -> 45.4 / 27.3 / 17.0 / 10.7 us; 2, 4 or 6 per CU lose 10 - 25 % to a partial second round).  A workgroup
+        // with a single image still reads no more table bytes than the streaming form does for its items.
+        const int nWe = a.nW > 0 ? a.nW : 1, nimg = a.B / nWe;
+        const long combos = (long)nWe * (pairs ? a.heads / 2 : a.heads);
+        const int wpc = (int)tune_int("TLXMI_WIN_WPC", 3);
+        long spc = ((long)cus * wpc) / combos;
+        if (spc < 1) spc = 1;
+        if (spc > nimg) spc = nimg;
+        const size_t tlds = lds + (size_t)(pairs ? 2 : 1) * 4 * NT * 1024;
+        if (combos * spc < (1l << 31) && !tune_int("TLXMI_WIN_STREAM", 0)) {
+            hipLaunchKernelGGL((attn_win_kernel<HD, NT, KF, true>), dim3((unsigned)(combos * spc)), dim3(256), tlds, st, a, (int)nitems, (int)spc);
+            return check_launch("attention(windows, resident table)");
+        }
+    }
+    const long units = pairs ? nitems / 2 : nitems;      // head pairs (kernel: item_at)
     const long grid = units < (long)cus * 6 ? units : (long)cus * 6;
-    hipLaunchKernelGGL((attn_win_kernel<HD, NT, KF>), dim3((unsigned)grid), dim3(256), lds, st, a, (int)nitems);
+    hipLaunchKernelGGL((attn_win_kernel<HD, NT, KF, false>), dim3((unsigned)grid), dim3(256), lds, st, a, (int)nitems, 0);
     return check_launch("attention(windows)");
 }
 template <int HD, int NT> static int launch_win(const AttnArgs& a, hipStream_t st) {
