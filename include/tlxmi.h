@@ -257,6 +257,12 @@ int tlxmi_pack_group_filter(const float* src_oihw, void* dst, int Cout, int Cin,
                             int dtype, void* stream);
 int tlxmi_group_conv2d(const tlxmi_conv2d_desc* d, int groups, const void* x, const void* w_packed,
                        const float* scale, const float* shift, const void* res, void* y, void* stream);
+/* 1 when the small-block MFMA kernel (group_conv.hip: v_mfma_f32_4x4x4_16b_f16, sixteen 4x4x4 products per
+ * instruction, so no MFMA work on the zero blocks of the block-diagonal filter) can run this layer (without a
+ * residual): fp16, C == Cout a multiple of 64, 4 / 8 / 16 / 32 channels per group, 3x3, padding 1, stride 1 or 2,
+ * dilation 1, dense output, W <= 104.  tlxmi_group_conv2d takes it where it measured faster (4 and 8 channels per
+ * group, 16 at stride 1).  Same operands and results (to fp32 summation order) as the general path. */
+int tlxmi_group_conv2d_small_supported(const tlxmi_conv2d_desc* d, int groups);
 
 /* ------------------------------------------------------------------------------------------
  * nn.Linear with few rows and a large filter — the classifier heads: resnet.py:234-237, vgg.py:42-50 (25088 -> 4096),

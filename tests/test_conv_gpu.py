@@ -4,12 +4,14 @@ Every unique conv shape of ResNet-50 at batch 1-2, plus the e
 has: pixel-tile tails, channel tails that force the scalar store path (Cout 1000, 291, 3), padded
 input channels (3 -> 8/4), dilation, asymmetric stride/padding, every epilogue combination.
 """
+import ctypes
+
 import numpy as np
 import pytest
 import torch
 
 from oracle import functional as OF
-from tlxcv_amd import engine as E
+from tlxcv_amd import engine as E, _lib
 from tlxcv_amd._lib import tuning      # the tuning flavour of the library: honours TLXMI_TILE / TLXMI_HALO per call
 from util import rnd, q16, nchw_to_engine, engine_to_nchw, tol
 
@@ -241,6 +243,56 @@ def test_group_conv(dev, dtype, cfg):
     torch.cuda.synchronize()
     assert got.shape == (N, Ho, Wo, Cout)
     torch.testing.assert_close(engine_to_nchw(got), want, **tol(dtype))
+
+
+# ---- the small-block MFMA kernel (group_conv.hip: v_mfma_f32_4x4x4_16b_f16, no products with the zero blocks of the
+# block-diagonal filter) takes fp16 3x3 / padding 1 / stride 1 or 2 layers with 4, 8, 16 or 32 channels per group: every group
+# width x stride, images taller than one LDS tile (several row tiles per image, a ragged last one), widths that are not a
+# multiple of the 4-pixel run, a single column, every activation family, no BatchNorm — against the oracle AND against the
+# block-diagonal path (TLXMI_GCONV=0 in the tuning flavour) on the same inputs.
+GCONV_CASES = [
+    # (N, C, groups, stride, H, W, act, with_bn)
+    (2, 128, 32, 1, 56, 56, 1, True),      # resnext.py:83-91 stage 1 (32x4d): 14 row tiles of 4 rows
+    (1, 128, 32, 2, 57, 55, 1, True),      # stride 2, odd extents
+    (2, 256, 32, 1, 28, 28, 1, True),      # stage 2: 8 per group
+    (1, 256, 32, 2, 56, 56, 3, True),      # stage 2 entry, leaky
+    (3, 512, 32, 1, 14, 14, 1, True),      # stage 3: 16 per group
+    (1, 512, 32, 2, 28, 28, 0, False),     # no BatchNorm, no activation
+    (5, 1024, 32, 1, 7, 7, 1, True),       # stage 4: 32 per group; 49 pixels = 12 runs + 1
+    (1, 1024, 32, 2, 14, 14, 4, True),     # hardswish
+    (1, 256, 64, 1, 9, 13, 2, True),       # 64x4d, relu6, odd extents
+    (2, 64, 16, 1, 5, 1, 1, True),         # one column
+    (1, 192, 24, 2, 11, 6, 7, True),       # three chunks of 8 per group, silu
+    (1, 128, 32, 1, 120, 90, 1, True),     # 92 padded columns: 4-row tiles, 30 of them
+]
+
+
+@pytest.mark.parametrize("cfg", GCONV_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_group_conv_on_the_small_block_mfma(dev, cfg):
+    N, C, groups, stride, H, W, act, with_bn = cfg
+    rng = np.random.default_rng(31 + C + H)
+    cg = C // groups
+    x = q16(rnd(rng, (N, C, H, W)))
+    w = q16(rnd(rng, (C, cg, 3, 3), (2.0 / (cg * 9)) ** 0.5))
+    scale = torch.from_numpy(rng.uniform(0.5, 1.5, C).astype(np.float32)) if with_bn else None
+    shift = rnd(rng, (C,), 0.1) if with_bn else None
+    want = OF.conv_bn_act(x, w, scale, shift, None, act, 0.1, (stride, stride), (1, 1), 1, groups, False)
+    pk = E.PackedGroupFilter(w.to(dev), groups, torch.float16)
+    xe = x.permute(0, 2, 3, 1).contiguous().half().to(dev)
+    sc, sh = (scale.to(dev) if with_bn else None), (shift.to(dev) if with_bn else None)
+    d = _lib.ConvDesc(dtype=E.dt_code(torch.float16), N=N, H=H, W=W, C=C, Cout=C, R=3, S=3, stride_h=stride, stride_w=stride, pad_h=1, pad_w=1,
+                      dil_h=1, dil_w=1, Ho=(H - 1) // stride + 1, Wo=(W - 1) // stride + 1, x_ld=C, y_ld=C, res_ld=0, y_nstride=0,
+                      res_nstride=0, act=act, act_param=0.1, flags=0)
+    assert _lib.load().tlxmi_group_conv2d_small_supported(ctypes.byref(d), groups) == 1       # the kernel under test is the one that runs
+    with tuning(TLXMI_GCONV="255"):          # every supported layer on the kernel under test (the product picks it where it is faster)
+        got = E.group_conv2d(xe, pk, stride, 1, 1, sc, sh, None, act, 0.1)
+    with tuning(TLXMI_GCONV="0"):
+        old = E.group_conv2d(xe, pk, stride, 1, 1, sc, sh, None, act, 0.1)
+    dflt = E.group_conv2d(xe, pk, stride, 1, 1, sc, sh, None, act, 0.1)     # the product library's own choice
+    torch.cuda.synchronize()
+    torch.testing.assert_close(engine_to_nchw(got), want, **tol(torch.float16))
+    torch.testing.assert_close(engine_to_nchw(dflt), want, **tol(torch.float16))
+    torch.testing.assert_close(got.float(), old.float(), atol=4e-3, rtol=4e-3)       # same fp32 accumulation of fp16 products, another order
 
 
 def test_group_conv_rejects_unmergeable_channel_counts(dev):

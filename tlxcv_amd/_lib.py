@@ -106,6 +106,7 @@ _SPECIAL = {
     "tlxmi_packed_filter_bytes": ([_i, _i, _i, _i, _i], C.c_size_t),
     "tlxmi_packed_group_filter_bytes": ([_i, _i, _i, _i, _i, _i], C.c_size_t),
     "tlxmi_group_conv_chunks": ([_i, _i, _i, _i], C.c_int),
+    "tlxmi_group_conv2d_small_supported": ([C.POINTER(ConvDesc), _i], C.c_int),
     "tlxmi_conv2d_maxpool_supported": ([C.POINTER(ConvDesc)], C.c_int),
     "tlxmi_conv2d_splitk_supported": ([C.POINTER(ConvDesc), _i], C.c_int),
     "tlxmi_preprocess_u8_workspace_bytes": ([C.POINTER(PreprocDesc)], C.c_size_t),

@@ -30,6 +30,7 @@
 #include <stdio.h>
 #include "gemm256.h"
 #include "conv_halo.h"
+#include "group_conv.h"
 #include <stdlib.h>
 #include <string.h>
 
@@ -1037,6 +1038,7 @@ extern "C" int tlxmi_conv2d_maxpool_supported(const tlxmi_conv2d_desc* d) {
 // The zero blocks cost MFMA work (x m), not HBM bytes: the layer stays bound by its activation traffic.
 // ------------------------------------------------------------------------------------------
 namespace tlxmi {
+static int kpad_elems_of(int Cin, int R, int S, int dtype);      // = kpad_elems (defined with the filter packing below)
 static int group_chunks(int Cin, int Cout, int groups, int dtype) {
     if (groups <= 1 || Cin <= 0 || Cout <= 0 || Cin % groups || Cout % groups) return 0;
     const int es = (int)elt_size(dtype);
@@ -1074,6 +1076,10 @@ extern "C" int tlxmi_group_conv_chunks(int Cin, int Cout, int groups, int dtype)
     return group_chunks(Cin, Cout, groups, dtype);
 }
 
+extern "C" int tlxmi_group_conv2d_small_supported(const tlxmi_conv2d_desc* d, int groups) {
+    return d && gconv_small_ok(d, groups, nullptr) && group_chunks(d->C, d->Cout, groups, d->dtype) == d->C / 64 ? 1 : 0;
+}
+
 extern "C" int tlxmi_group_conv2d(const tlxmi_conv2d_desc* d, int groups, const void* x, const void* w_packed,
                                   const float* scale, const float* shift, const void* res, void* y, void* stream) {
     TLXMI_REQUIRE(d, TLXMI_ERR_BAD_ARG, "group_conv2d: null descriptor");
@@ -1089,6 +1095,16 @@ extern "C" int tlxmi_group_conv2d(const tlxmi_conv2d_desc* d, int groups, const 
     TLXMI_REQUIRE(!res || (d->res_ld * (int)elt_size(d->dtype)) % 16 == 0, TLXMI_ERR_ALIGNMENT, "group_conv2d: res_ld=%d", d->res_ld);
     TLXMI_REQUIRE((d->y_ld * (int)elt_size(d->dtype)) % 16 == 0, TLXMI_ERR_ALIGNMENT, "group_conv2d: y_ld=%d", d->y_ld);
     const int cgi = d->C / groups, cgo = d->Cout / groups;
+    // 3x3 with few channels per group: the small-block MFMA kernel (group_conv.hip) — no products with the zero blocks.  Where it
+    // wins (batch 256, tools/gconv_micro.py, us, block-diagonal -> 4x4x4): 4 per group 56 x 56 183 -> 129 (64x4d: 374 -> 211),
+    // 8 per group 28 x 28 89 -> 61 and stride 2 from 56 x 56 140 -> 113, 16 per group 14 x 14 51 -> 49; it loses at 16 per group
+    // with stride 2 (66 -> 80) and at 32 per group (38 -> 72, 35 -> 58: two real products in four there, and 7 x 7 tiles are
+    // all prologue), which stay on the block-diagonal path.  TLXMI_GCONV (tuning flavour): bit (log2(cg / 4) + 4 * (stride - 1)).
+    if (gconv_small_ok(d, groups, res) && nchunk == d->C / 64 && aligned16(x) && aligned16(w_packed) && ((uintptr_t)y & 7u) == 0) {
+        const int qi = cgi == 4 ? 0 : cgi == 8 ? 1 : cgi == 16 ? 2 : 3;
+        if ((tune_int("TLXMI_GCONV", 0x37) >> (qi + 4 * (d->stride_h - 1))) & 1)
+            return launch_gconv_small(d, groups, x, w_packed, scale, shift, y, kpad_elems_of(d->C / nchunk, d->R, d->S, d->dtype) * 2, as_stream(stream));
+    }
     return conv2d_impl(d, nchunk, x, w_packed, scale, shift, res, y, stream, cgi == cgo && 32 % cgi == 0);
 }
 
@@ -1257,6 +1273,8 @@ extern "C" int tlxmi_layernorm_linear(int dtype, int64_t rows, int K, int Cout, 
 // ------------------------------------------------------------------------------------------
 namespace tlxmi {
 static inline int cin_pad(int Cin, int dtype) { const int v = 16 / (int)elt_size(dtype); return (Cin + v - 1) / v * v; }
+static inline int kpad_elems(int Cin, int R, int S, int dtype);
+static int kpad_elems_of(int Cin, int R, int S, int dtype) { return kpad_elems(Cin, R, S, dtype); }
 static inline int kpad_elems(int Cin, int R, int S, int dtype) {
     const int es = (int)elt_size(dtype);
     const int kbytes = R * S * cin_pad(Cin, dtype) * es;
