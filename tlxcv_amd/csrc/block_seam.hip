@@ -338,6 +338,214 @@ __global__ __launch_bounds__(64 * NW, WPS ? WPS : 1) void seam_kernel(const Seam
     }
 }
 
+// The same seam for wide filters (256 -> 1024 -> 256 at 14 x 14: 1 MB of filters per 128 pixels), two waves per 32 pixels.
+// With 16 pixels a wave every MFMA above needs a fresh A fragment from LDS (64 x ds_read_b128 per wave and step: as many LDS
+// cycles as MFMA cycles, and they add).  Here the waves 2p and 2p + 1 share 32 pixels (two pixel blocks: every fragment read
+// feeds two MFMAs) and split the CHANNELS: wave h computes the sub-tiles ci = 2h, 2h + 1 of GEMM1 — with the row permutation
+// above that is exactly the 8-channel half h of every lane's 16 channels, i.e. GEMM2's k-step h — stores that half of y, hands
+// it to its partner through LDS (2 KB a wave), and accumulates the row tiles 8h .. 8h + 7 of GEMM2 (channels 128h .. of t1)
+// over both k-steps.  Per wave and step: 16 + 16 fragment reads for 32 + 32 MFMAs, half the skip registers; one more barrier
+// per step (the exchange).
+template <int K1, int N2, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void seam_pair_kernel(const SeamArgs a) {
+    static_assert(N2 % 128 == 0 && NW % 2 == 0, "pairs of waves split N2 in halves of whole 64-channel blocks");
+    constexpr int NT = 64 * NW;
+    constexpr int IPT = 512 / NT;
+    constexpr int PW = 2;
+    constexpr int KS = K1 / 32;
+    constexpr int CB = K1 / 64;
+    constexpr int Q2 = N2 / 64;
+    constexpr int NP = CB + Q2;
+    constexpr int T2H = N2 / 32;         // row tiles of GEMM2 per wave (half of N2 / 16)
+    constexpr int PANEL = 64 * 128;
+    constexpr int OOB = (int)0x80000000;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const wbuf = smem;
+    float* const tab3 = reinterpret_cast<float*>(smem + 2 * NP * PANEL);
+    float* const tab1 = tab3 + 2 * a.N1;
+    char* const ybuf = reinterpret_cast<char*>(tab1 + 2 * N2);                  // [wave][pw][64 lanes][16 bytes]
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int hh = wid & 1, pp = wid >> 1;
+    const int fr = lane & 15, g = lane >> 4;
+
+    const __amdgpu_buffer_rsrc_t xsrd = bs_srd(a.x, a.x_bytes), w3srd = bs_srd(a.w3, a.w3_bytes), w1srd = bs_srd(a.w1, a.w1_bytes);
+    const __amdgpu_buffer_rsrc_t rsrd = bs_srd(a.res, a.res_bytes), ysrd = bs_srd(a.y, a.y_bytes), zsrd = bs_srd(a.z, a.z_bytes);
+
+    auto stage_load = [&](int c, u32x4 (&st)[NP][IPT]) {
+#pragma unroll
+        for (int k = 0; k < IPT; ++k) {
+            const int idx = k * NT + t, srow = idx >> 3, sslot = idx & 7;
+            const int sl1 = sslot ^ bs_f1(srow), sl2 = sslot ^ bs_f2(srow);
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) st[cb][k] = bs_load16(w3srd, ((64 * c + srow) * K1 + 64 * cb + 8 * sl1) * 2);
+#pragma unroll
+            for (int q = 0; q < Q2; ++q) st[CB + q][k] = bs_load16(w1srd, ((64 * q + srow) * a.N1 + 64 * c + 8 * sl2) * 2);
+        }
+    };
+    auto stage_write = [&](int buf, const u32x4 (&st)[NP][IPT]) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j)
+#pragma unroll
+            for (int k = 0; k < IPT; ++k) *reinterpret_cast<u32x4*>(wbuf + (buf * NP + j) * PANEL + (k * NT + t) * 16) = st[j][k];
+    };
+
+    const int m0 = ((int)blockIdx.x * (NW / 2) + pp) * (16 * PW);
+    int pix[PW];
+    bool pok[PW];
+#pragma unroll
+    for (int pw = 0; pw < PW; ++pw) {
+        pix[pw] = m0 + 16 * pw + fr;
+        pok[pw] = pix[pw] < a.M;
+    }
+    u32x4 xf[KS][PW];
+#pragma unroll
+    for (int pw = 0; pw < PW; ++pw)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            xf[ks][pw] = bs_load16(xsrd, pok[pw] ? (pix[pw] * a.x_ld + 32 * ks + 8 * g) * 2 : OOB);
+    auto skip_load = [&](int c, u32x4 (&sk)[PW]) {
+#pragma unroll
+        for (int pw = 0; pw < PW; ++pw) sk[pw] = bs_load16(rsrd, pok[pw] ? (pix[pw] * a.res_ld + 64 * c + 16 * g + 8 * hh) * 2 : OOB);
+    };
+    u32x4 sk[PW];
+    skip_load(0, sk);
+    {
+        u32x4 st[NP][IPT];
+        stage_load(0, st);
+        for (int i = t; i < a.N1; i += NT) {
+            tab3[i] = a.scale3 ? a.scale3[i] : 1.f;
+            tab3[a.N1 + i] = a.shift3 ? a.shift3[i] : 0.f;
+        }
+        for (int i = t; i < N2; i += NT) {
+            tab1[i] = a.scale1 ? a.scale1[i] : 1.f;
+            tab1[N2 + i] = a.shift1 ? a.shift1[i] : 0.f;
+        }
+        stage_write(0, st);
+    }
+    __syncthreads();
+
+    const int arow = 16 * (fr >> 2) + (fr & 3);
+    int a1off[2], a2off[4];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int r = arow + 4 * (2 * hh + e);
+        a1off[e] = r * 128 + ((g ^ bs_f1(r)) << 4);
+    }
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci) {
+        const int r = arow + 4 * ci;
+        a2off[ci] = r * 128 + (((2 * g) ^ bs_f2(r)) << 4);
+    }
+    char* const ymine = ybuf + (wid * PW * 64 + lane) * 16;
+    const char* const ypart = ybuf + ((wid ^ 1) * PW * 64 + lane) * 16;
+
+    f32x4 acc2[T2H][PW];
+#pragma unroll
+    for (int tt = 0; tt < T2H; ++tt)
+#pragma unroll
+        for (int pw = 0; pw < PW; ++pw) acc2[tt][pw] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nch = a.N1 >> 6;
+#pragma unroll 1
+    for (int c = 0; c < nch; ++c) {
+        const char* const wb = wbuf + (c & 1) * NP * PANEL;
+        const bool more = c + 1 < nch;
+        u32x4 st[NP][IPT], skn[PW];
+        if (more) {
+            stage_load(c + 1, st);
+            skip_load(c + 1, skn);
+        }
+        // ---- GEMM1: this wave's 32 of the step's 64 expand channels, both pixel blocks
+        f32x4 acc1[2][PW];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+#pragma unroll
+            for (int pw = 0; pw < PW; ++pw) acc1[e][pw] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const u32x4 af = *reinterpret_cast<const u32x4*>(wb + (ks >> 1) * PANEL + (a1off[e] ^ ((ks & 1) << 6)));
+#pragma unroll
+                for (int pw = 0; pw < PW; ++pw) acc1[e][pw] = bs_mma(af, xf[ks][pw], acc1[e][pw]);
+            }
+        }
+        // ---- epilogue 1 of the half: BN, + skip, ReLU; stored to y and handed to the partner wave
+        u32x4 yf[PW][2];
+        {
+            const float* sc = tab3 + 64 * c + 16 * g + 8 * hh;
+            const float* sh = sc + a.N1;
+            const f32x4 s0 = *reinterpret_cast<const f32x4*>(sc), s1 = *reinterpret_cast<const f32x4*>(sc + 4);
+            const f32x4 h0 = *reinterpret_cast<const f32x4*>(sh), h1 = *reinterpret_cast<const f32x4*>(sh + 4);
+#pragma unroll
+            for (int pw = 0; pw < PW; ++pw) {
+                const half8v rv = __builtin_bit_cast(half8v, sk[pw]);
+                const u32x2 o0 = bs_bn_skip_relu4(acc1[0][pw], s0, h0, half4v{rv[0], rv[1], rv[2], rv[3]});
+                const u32x2 o1 = bs_bn_skip_relu4(acc1[1][pw], s1, h1, half4v{rv[4], rv[5], rv[6], rv[7]});
+                const u32x4 o = u32x4{o0[0], o0[1], o1[0], o1[1]};
+                bs_store16(ysrd, o, pok[pw] ? (pix[pw] * a.y_ld + 64 * c + 16 * g + 8 * hh) * 2 : OOB);
+                *reinterpret_cast<u32x4*>(ymine + pw * 1024) = o;
+                if (hh == 0) yf[pw][0] = o; else yf[pw][1] = o;
+            }
+        }
+        __syncthreads();          // both halves of the step's y chunk are in LDS
+#pragma unroll
+        for (int pw = 0; pw < PW; ++pw) {
+            const u32x4 o = *reinterpret_cast<const u32x4*>(ypart + pw * 1024);
+            if (hh == 0) yf[pw][1] = o; else yf[pw][0] = o;
+        }
+        // ---- GEMM2: row tiles 8 hh .. of the reduce conv, both k-steps of the step's 64 channels
+#pragma unroll
+        for (int tt = 0; tt < T2H; ++tt) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const u32x4 af = *reinterpret_cast<const u32x4*>(wb + (CB + hh * (Q2 / 2) + (tt >> 2)) * PANEL + (a2off[tt & 3] ^ (s << 4)));
+#pragma unroll
+                for (int pw = 0; pw < PW; ++pw) acc2[tt][pw] = bs_mma(af, yf[pw][s], acc2[tt][pw]);
+            }
+        }
+        if (more) {
+            stage_write((c + 1) & 1, st);
+#pragma unroll
+            for (int pw = 0; pw < PW; ++pw) sk[pw] = skn[pw];
+        }
+        __syncthreads();          // done with this step's filter buffer and exchange slots; the next step's filters are written
+    }
+
+    // ---- epilogue 2: this wave's half of t1
+#pragma unroll
+    for (int q = 0; q < Q2 / 2; ++q) {
+        const float* sc = tab1 + 64 * (hh * (Q2 / 2) + q) + 16 * g;
+        const float* sh = sc + N2;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const f32x4 s0 = *reinterpret_cast<const f32x4*>(sc + 8 * h), s1 = *reinterpret_cast<const f32x4*>(sc + 8 * h + 4);
+            const f32x4 h0 = *reinterpret_cast<const f32x4*>(sh + 8 * h), h1 = *reinterpret_cast<const f32x4*>(sh + 8 * h + 4);
+#pragma unroll
+            for (int pw = 0; pw < PW; ++pw) {
+                const u32x2 o0 = bs_bn_relu4(acc2[4 * q + 2 * h][pw], s0, h0), o1 = bs_bn_relu4(acc2[4 * q + 2 * h + 1][pw], s1, h1);
+                const u32x4 o = u32x4{o0[0], o0[1], o1[0], o1[1]};
+                bs_store16(zsrd, o, pok[pw] ? (pix[pw] * a.z_ld + 64 * (hh * (Q2 / 2) + q) + 16 * g + 8 * h) * 2 : OOB);
+            }
+        }
+    }
+}
+
+template <int K1, int N2, int NW> static int launch_seam_pair_t(const SeamArgs& a, hipStream_t st) {
+    constexpr int NP = K1 / 64 + N2 / 64;
+    const size_t lds = (size_t)2 * NP * 64 * 128 + (size_t)(2 * a.N1 + 2 * N2) * sizeof(float) + (size_t)NW * 2 * 1024;
+    if (lds > 160 * 1024) return fail(TLXMI_ERR_UNSUPPORTED, "block_seam: %zu bytes of LDS", lds);
+    const void* fn = reinterpret_cast<const void*>(&seam_pair_kernel<K1, N2, NW>);
+    if (int rc = raise_lds_limit(fn, 160 * 1024, "block_seam")) return rc;
+    const long grid = ((long)a.M + NW * 16 - 1) / (NW * 16);
+    if (grid >= (1l << 31)) return fail(TLXMI_ERR_UNSUPPORTED, "block_seam: too many rows");
+    SeamArgs b = a;
+    void* args[] = {&b};
+    hipError_t e = hipLaunchKernel(fn, dim3((unsigned)grid), dim3(64 * NW), args, lds, st);
+    if (e != hipSuccess) return fail(TLXMI_ERR_LAUNCH, "block_seam: HIP launch failed: %s", hipGetErrorString(e));
+    return TLXMI_OK;
+}
+
 template <int K1, int N2, int PW, int NW, bool PROJ = false, int WPS = 0> static int launch_seam_t(const SeamArgs& a, hipStream_t st) {
     constexpr int NP = K1 / 64 + N2 / 64 + (PROJ ? K1 / 64 : 0);
     const size_t lds = (size_t)2 * NP * 64 * 128 + (size_t)(2 * a.N1 + 2 * N2 + (PROJ ? 2 * a.N1 : 0)) * sizeof(float);
@@ -391,7 +599,10 @@ int launch_block_seam(const SeamArgs& a0, int K1, int N2, hipStream_t st) {
     //  vs 185 / 266 with 4 — the 128-channel filters are 256 - 384 KB per pass and want more pixels per staging)
     if (K1 == 128 && N2 == 128) return v ? launch_seam_t<128, 128, 2, 4>(a, st) : launch_seam_t<128, 128, 2, 8>(a, st);
     if (K1 == 128 && N2 == 256) return v ? launch_seam_t<128, 256, 1, 4>(a, st) : launch_seam_t<128, 256, 1, 8>(a, st);
-    if (K1 == 256 && N2 == 256) return v ? launch_seam_t<256, 256, 1, 4>(a, st) : launch_seam_t<256, 256, 1, 8>(a, st);
+    if (K1 == 256 && N2 == 256) {
+        if (!(vv & 32)) return launch_seam_pair_t<256, 256, 8>(a, st);      // TLXMI_SEAM bit 5 (A/B): the one-wave-per-16-pixels form
+        return v ? launch_seam_t<256, 256, 1, 4>(a, st) : launch_seam_t<256, 256, 1, 8>(a, st);
+    }
     return fail(TLXMI_ERR_UNSUPPORTED, "block_seam: no instantiation for %d -> N1 -> %d channels", K1, N2);
 }
 
