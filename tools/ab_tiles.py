@@ -6,7 +6,8 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
-from tlxcv_amd import engine as E  # noqa: E402
+from tlxcv_amd import engine as E, _lib  # noqa: E402
+_lib.tuning().__enter__()      # the flavour of the library that reads TLXMI_TILE per call
 from tools.conv_micro_shapes import SHAPES  # noqa: E402
 
 names = sys.argv[1].split(",")
