@@ -122,6 +122,30 @@ def test_auto_dispatch_tail_split(dev, force_tile):
 # ---- LayerNorm folded into the following Linear: statistics inside the GEMM (tlxmi_layernorm_linear) and the two-launch form
 # (tlxmi_row_stats + tlxmi_linear_ln).  (197 * 67, 768, 3072) = 52 M tiles x 12 = 624 tiles: 2 full rounds + a tail launch of
 # half-height tiles on a 256-CU device for the GELU layer, and several tiles per workgroup of the persistent kernel.
+# ---- K = 128 on many rows: the filter-in-registers streaming kernel (gemm_wreg.hip; Swin-B stage 1, swin_transformer.py:192-229,
+# 37-50): every compiled width (128 / 256 / 384 / 512 output channels), a ragged last row tile, every epilogue family, against
+# the oracle and against the tiled kernels (TLXMI_WREG=0) on the same inputs
+@pytest.mark.parametrize("epi", ["bias", "gelu", "res", "bn_relu_res", "nobias"])
+@pytest.mark.parametrize("Cout", [128, 256, 384, 512])
+def test_linear_k128_filter_in_registers(dev, Cout, epi):
+    from tlxcv_amd._lib import tuning
+    M, K = 16384 + 16 * 5 + 3, 128          # 129 / 257 row tiles, the last one with 19 / 83 rows
+    kw = dict(bias=epi != "nobias", scale=epi == "bn_relu_res", res=epi in ("res", "bn_relu_res"),
+              act={"gelu": E.ACT_GELU, "bn_relu_res": E.ACT_RELU}.get(epi, E.ACT_NONE), seed=Cout)
+    run_linear(dev, torch.float16, M, K, Cout, **kw)                      # the product's choice: the streaming kernel
+    rng = np.random.default_rng(7)
+    x = q16(rnd(rng, (M, K))).half().to(dev).view(M, 1, 1, K)
+    w = q16(rnd(rng, (Cout, K), (1.0 / K) ** 0.5))
+    b = rnd(rng, (Cout,), 0.2).to(dev)
+    r = q16(rnd(rng, (M, Cout))).half().to(dev).view(M, 1, 1, Cout) if kw["res"] else None
+    pk = E.PackedFilter(w.reshape(Cout, K, 1, 1).to(dev), torch.float16)
+    got = E.conv2d(x, pk, 1, 0, 1, None, b, r, kw["act"])
+    with tuning(TLXMI_WREG="0"):
+        old = E.conv2d(x, pk, 1, 0, 1, None, b, r, kw["act"])
+    torch.cuda.synchronize()
+    torch.testing.assert_close(got.float(), old.float(), atol=2e-3, rtol=2e-3)
+
+
 @pytest.mark.parametrize("in_kernel", [True, False], ids=["in_kernel", "stats_pass"])
 @pytest.mark.parametrize("act", [E.ACT_NONE, E.ACT_GELU], ids=["none", "gelu"])
 @pytest.mark.parametrize("shape", [(197 * 3, 768, 2304), (300, 192, 576), (1000, 128, 512), (77, 384, 1536), (197 * 67, 768, 3072),

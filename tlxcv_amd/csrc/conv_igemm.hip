@@ -656,6 +656,20 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
                                a.vec_io && a.Cout % 8 == 0 && a.Cout >= 128 && a.y_bytes != 0 && a.cpt % 8 == 0 && (tpk & (tpk - 1)) == 0 &&
                                (!a.res || (long long)a.M * a.res_ld * (long long)sizeof(T) < (1ll << 31));
     const bool pp_conv_ok = pp_conv128_ok && a.Cout >= 256;
+    // K = 128 (two K tiles) and up to 512 output channels on many rows: HBM-bound; the filter-in-registers kernel reads every
+    // activation row once and writes every output row once (gemm_wreg.hip).  TLXMI_WREG=0 (tuning flavour): the tiled kernels.
+    if (gemm128_ok && sizeof(T) == 2 && a.kchunks == 16 && a.M >= 16384 && a.pp_slices <= 1 && !a.out_f32 && tune_int("TLXMI_WREG", 1) &&
+        tune_int("TLXMI_TILE", -1) < 0) {
+        Gemm256Args g;
+        g.debug = 0; g.conv = 0; g.rowstats = nullptr;
+        g.x = a.x; g.w = a.w; g.y = a.y; g.scale = a.scale; g.shift = a.shift; g.res = a.res;
+        g.M = a.M; g.Cout = a.Cout; g.x_ld = a.x_ld; g.y_ld = a.y_ld; g.res_ld = a.res_ld;
+        g.kchunks = a.kchunks; g.ksteps = a.Kp_bytes / 128; g.Kp_bytes = a.Kp_bytes;
+        g.act = a.act; g.act_param = a.act_param; g.flags = a.flags; g.mtiles = g.ntiles = 0; g.gn = 1;
+        g.x_bytes = a.x_bytes; g.w_bytes = a.w_bytes; g.y_bytes = a.y_bytes;
+        g.res_bytes = a.res ? (unsigned)((long long)a.M * a.res_ld * (long long)sizeof(T)) : 0u;
+        if (gemm_wreg_ok(TLXMI_F16, g)) return launch_gemm_wreg(g, st);
+    }
     if (!gemm256_ok) cands[5].eff = cands[6].eff = cands[8].eff = 0.f;
     if (!gemm256_ok && !pp_conv_ok) cands[7].eff = 0.f;
     // 128 x 256 tiles for plain GEMM rows too (few row tiles: 7 x 7 stage, 2048 -> 512); TLXMI_PP128=0: convs only (A/B)

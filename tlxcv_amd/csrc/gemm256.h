@@ -49,4 +49,8 @@ int launch_gemm_pp_n128(int dtype, const Gemm256Args& a, hipStream_t st); // 256
 bool gemm_stream_ok(int dtype, const Gemm256Args& a);
 int launch_gemm_stream(int dtype, const Gemm256Args& a, hipStream_t st, int cus);
 
+// gemm_wreg.hip: K = 128 rows, all N channels per workgroup, the filter in registers (HBM-bound pointwise layers)
+bool gemm_wreg_ok(int dtype, const Gemm256Args& a);
+int launch_gemm_wreg(const Gemm256Args& a, hipStream_t st);
+
 }  // namespace tlxmi
