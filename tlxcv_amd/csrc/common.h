@@ -36,10 +36,13 @@ inline long tune_int(const char* name, long dflt) {
     return (e && *e) ? atol(e) : dflt;
 }
 #define TLXMI_DBG(args, bit) (((args).debug & (bit)) != 0)
-// A/B (TLXMI_DEBUG bit 0x4000): flips the store policy of the half-line quadrant stores — gemm_pp (plain GEMM) / gemm256 to
-// write-back, conv_halo to non-temporal.  Product: convolution outputs (conv_halo, gemm_pp in CONV mode) are written back
-// through L2 — the next launch reads them at once, and the two 64-byte halves of a line merge before they leave; Linear outputs
-// stay non-temporal.
+// Output store policy.  Product: every GEMM / convolution output is written back through L2 (plain stores) — the next launch
+// reads it at once from L2 / the Infinity Cache, and the 64-byte halves of a line that two waves store phases apart merge
+// before they leave.  Round 3 measured it again on the hipGraph replay of the whole two-stream forwards: write-back instead
+// of non-temporal for gemm_pp (plain GEMM), gemm256 and gemm_stream: Swin-B 7.86 -> 7.64 ms, ResNet-50 3.51 -> 3.48, ViT-B/16
+// 11.35 -> 11.30 (the round-1 per-layer sweep that chose non-temporal timed each launch alone, re-writing one buffer).
+// A/B (tuning flavour): TLXMI_DEBUG bit 0x4000 flips gemm_pp (plain GEMM) / gemm256 to non-temporal, bit 4 gemm_stream,
+// bit 0x8000 conv_halo.
 #define TLXMI_WB_STORES(args) (((args).debug & 0x4000) != 0)
 #else
 constexpr long tune_int(const char*, long dflt) { return dflt; }

@@ -237,7 +237,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const HaloArgs a) {
                             if (jrow > 0) m = ch_pkmax4(m, *reinterpret_cast<const u32x4*>(rp + off));
                         }
                         const int opix = (tj.n * a.tpi + jrow) * (16 * PI / 2) + xh;     // pooled pixel index (N, Ho/2, Wo/2)
-                        if (!TLXMI_WB_STORES(a)) ch_store16_wb(ysrd, m, (in && st_ok && ch * 8 < a.Cout && !TLXMI_DBG(a, 2)) ? (opix * a.y_ld + a.nt * 64 + ch * 8) * 2 : OOB);
+                        if (!TLXMI_DBG(a, 0x8000)) ch_store16_wb(ysrd, m, (in && st_ok && ch * 8 < a.Cout && !TLXMI_DBG(a, 2)) ? (opix * a.y_ld + a.nt * 64 + ch * 8) * 2 : OOB);
                         else ch_store16_nt(ysrd, m, (in && st_ok && ch * 8 < a.Cout && !TLXMI_DBG(a, 2)) ? (opix * a.y_ld + a.nt * 64 + ch * 8) * 2 : OOB);
                     }
                 }
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const HaloArgs a) {
                     half8v hv;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) hv[e] = (half_t)v[e];
-                    if (!TLXMI_WB_STORES(a)) ch_store16_wb(ysrd, __builtin_bit_cast(u32x4, hv), (ok && !TLXMI_DBG(a, 2)) ? (mg * a.y_ld + ch0) * 2 : OOB);
+                    if (!TLXMI_DBG(a, 0x8000)) ch_store16_wb(ysrd, __builtin_bit_cast(u32x4, hv), (ok && !TLXMI_DBG(a, 2)) ? (mg * a.y_ld + ch0) * 2 : OOB);
                     else ch_store16_nt(ysrd, __builtin_bit_cast(u32x4, hv), (ok && !TLXMI_DBG(a, 2)) ? (mg * a.y_ld + ch0) * 2 : OOB);
                 }
             }

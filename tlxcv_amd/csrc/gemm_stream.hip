@@ -252,7 +252,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
                 half8v hv;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) hv[e] = (half_t)v[e];
-                if TLXMI_DBG(a, 4) gs_store16_wb(ysrd, __builtin_bit_cast(u32x4, hv), yo);
+                if (!TLXMI_DBG(a, 4)) gs_store16_wb(ysrd, __builtin_bit_cast(u32x4, hv), yo);      // (bit 4, A/B: non-temporal)
                 else gs_store16_nt(ysrd, __builtin_bit_cast(u32x4, hv), yo);
             } else {
                 f32x4 f0, f1;
