@@ -122,27 +122,32 @@ def test_auto_dispatch_tail_split(dev, force_tile):
 # ---- LayerNorm folded into the following Linear: statistics inside the GEMM (tlxmi_layernorm_linear) and the two-launch form
 # (tlxmi_row_stats + tlxmi_linear_ln).  (197 * 67, 768, 3072) = 52 M tiles x 12 = 624 tiles: 2 full rounds + a tail launch of
 # half-height tiles on a 256-CU device for the GELU layer, and several tiles per workgroup of the persistent kernel.
-# ---- K = 128 on many rows: the filter-in-registers streaming kernel (gemm_wreg.hip; Swin-B stage 1, swin_transformer.py:192-229,
-# 37-50): every compiled width (128 / 256 / 384 / 512 output channels), a ragged last row tile, every epilogue family, against
-# the oracle and against the tiled kernels (TLXMI_WREG=0) on the same inputs
+# ---- K = 128 / 256 on many rows: the filter-in-registers streaming kernel (gemm_wreg.hip; Swin-B stages 1 and 2,
+# swin_transformer.py:192-229, 37-50): every compiled width (K = 128: 128 / 256 / 384 / 512 output channels; K = 256: 256 / 512 / 768 /
+# 1024, the last two as two column slices), a ragged last row tile, every epilogue family (the residual ones stay on the tiled
+# kernels), against the oracle and against the tiled kernels (TLXMI_WREG=0) on the same inputs
 @pytest.mark.parametrize("epi", ["bias", "gelu", "res", "bn_relu_res", "nobias"])
-@pytest.mark.parametrize("Cout", [128, 256, 384, 512])
-def test_linear_k128_filter_in_registers(dev, Cout, epi):
+@pytest.mark.parametrize("K,Cout", [(128, 128), (128, 256), (128, 384), (128, 512), (256, 256), (256, 512), (256, 768), (256, 1024)])
+def test_linear_k128_filter_in_registers(dev, K, Cout, epi):
     from tlxcv_amd._lib import tuning
-    M, K = 16384 + 16 * 5 + 3, 128          # 129 / 257 row tiles, the last one with 19 / 83 rows
+    M = (16384 if K == 128 else 32768) + 16 * 5 + 3          # the last row tile ragged (19 / 83 rows)
     kw = dict(bias=epi != "nobias", scale=epi == "bn_relu_res", res=epi in ("res", "bn_relu_res"),
               act={"gelu": E.ACT_GELU, "bn_relu_res": E.ACT_RELU}.get(epi, E.ACT_NONE), seed=Cout)
-    run_linear(dev, torch.float16, M, K, Cout, **kw)                      # the product's choice: the streaming kernel
+    run_linear(dev, torch.float16, M, K, Cout, **kw)                      # the product's own choice of kernel, vs the oracle
     rng = np.random.default_rng(7)
-    x = q16(rnd(rng, (M, K))).half().to(dev).view(M, 1, 1, K)
+    x = q16(rnd(rng, (M, K)))
     w = q16(rnd(rng, (Cout, K), (1.0 / K) ** 0.5))
-    b = rnd(rng, (Cout,), 0.2).to(dev)
-    r = q16(rnd(rng, (M, Cout))).half().to(dev).view(M, 1, 1, Cout) if kw["res"] else None
+    b = rnd(rng, (Cout,), 0.2)
+    want = OF.conv_bn_act(x.t().reshape(1, K, M, 1), w.reshape(Cout, K, 1, 1), None, b, None, kw["act"], 0.0, (1, 1), (0, 0), 1, 1,
+                          False).reshape(Cout, M).t()
+    xe = x.half().to(dev).view(M, 1, 1, K)
     pk = E.PackedFilter(w.reshape(Cout, K, 1, 1).to(dev), torch.float16)
-    got = E.conv2d(x, pk, 1, 0, 1, None, b, r, kw["act"])
+    with tuning(TLXMI_WREG="3"):             # every compiled width on the kernel under test (the product keeps 256 -> 256 / 512 tiled)
+        got = E.conv2d(xe, pk, 1, 0, 1, None, b.to(dev), None, kw["act"])
     with tuning(TLXMI_WREG="0"):
-        old = E.conv2d(x, pk, 1, 0, 1, None, b, r, kw["act"])
+        old = E.conv2d(xe, pk, 1, 0, 1, None, b.to(dev), None, kw["act"])
     torch.cuda.synchronize()
+    torch.testing.assert_close(got.view(M, Cout).float().cpu(), want, **tol(torch.float16))
     torch.testing.assert_close(got.float(), old.float(), atol=2e-3, rtol=2e-3)
 
 

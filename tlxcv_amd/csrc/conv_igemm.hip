@@ -657,8 +657,13 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
                                (!a.res || (long long)a.M * a.res_ld * (long long)sizeof(T) < (1ll << 31));
     const bool pp_conv_ok = pp_conv128_ok && a.Cout >= 256;
     // K = 128 (two K tiles) and up to 512 output channels on many rows: HBM-bound; the filter-in-registers kernel reads every
-    // activation row once and writes every output row once (gemm_wreg.hip).  TLXMI_WREG=0 (tuning flavour): the tiled kernels.
-    if (gemm128_ok && sizeof(T) == 2 && a.kchunks == 16 && a.M >= 16384 && a.pp_slices <= 1 && !a.out_f32 && tune_int("TLXMI_WREG", 1) &&
+    // activation row once and writes every output row once (gemm_wreg.hip).  K = 256: only the wide layers (768 / 1024 channels:
+    // qkv / fc1 of Swin-B stage 2, 60 -> 55 and 112 -> 87 us at batch 128; 256 / 512 channels measure equal or slower — 128 filter
+    // registers a wave leave one workgroup of <= 8 waves per CU).  TLXMI_WREG (tuning flavour): 0 the tiled kernels, 2 K = 128 only,
+    // 3 every K = 256 width.
+    const long wreg = tune_int("TLXMI_WREG", 1);
+    const bool wreg_k256 = a.kchunks == 32 && wreg != 2 && a.M >= 32768 && (a.Cout >= 768 || wreg == 3);
+    if (gemm128_ok && sizeof(T) == 2 && (a.kchunks == 16 || wreg_k256) && a.M >= 16384 && a.pp_slices <= 1 && !a.out_f32 && wreg &&
         tune_int("TLXMI_TILE", -1) < 0) {
         Gemm256Args g;
         g.debug = 0; g.conv = 0; g.rowstats = nullptr;

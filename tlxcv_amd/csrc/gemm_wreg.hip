@@ -29,13 +29,13 @@ static __device__ __forceinline__ f32x4 wr_mma(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8v, a), __builtin_bit_cast(half8v, b), c, 0, 0, 0);
 }
 
-// K: input channels (128); NCG: column groups of 64 output channels (N = 64 * NCG); NRG: row groups; a wave = (cg, rg) owns
+// K: input channels (128 or 256); NCG: column groups of 64 output channels (N = 64 * NCG); NRG: row groups; a wave = (cg, rg) owns
 // 64 channels x PB 16-row blocks of every tile; tile = 16 * PB * NRG rows.
 // Registers: 64 filter + 16 X fragments + 16 accumulators + the epilogue values = 152 VGPRs (three waves per SIMD; the budget of
 // four spills).  No residual input: with loads in flight next to the LDS-DMAs hipcc drains vmcnt(0) before every DMA
 // (pitfall 2) and the layer runs slower than on the tiled kernels, which keep those layers.
 template <int K, int NCG, int NRG, int PB>
-__global__ __launch_bounds__(64 * NCG * NRG, 3) void gemm_wreg_kernel(const Gemm256Args a, const int ntiles) {
+__global__ __launch_bounds__(64 * NCG * NRG, K == 128 ? 3 : 2) void gemm_wreg_kernel(const Gemm256Args a, const int ntiles) {
     constexpr int NW = NCG * NRG, NT = 64 * NW;
     constexpr int KS = K / 32;                  // k-steps
     constexpr int RB = K * 2;                   // bytes of an X row
@@ -50,6 +50,7 @@ __global__ __launch_bounds__(64 * NCG * NRG, 3) void gemm_wreg_kernel(const Gemm
     const int t = threadIdx.x, lane = t & 63;
     const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
     const int cg = wid % NCG, rg = wid / NCG;
+    const int cbase = (int)blockIdx.y * N;      // wide layers: column slices of N channels as blockIdx.y (X is re-read per slice, from L2)
     const int fr = lane & 15, g = lane >> 4;
     const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.x), 0, a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t ysrd = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.y_bytes, 0x00020000);
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(64 * NCG * NRG, 3) void gemm_wreg_kernel(const Gemm
     // halves, and each of the two stores of a 16-row block writes 64 contiguous bytes per row (four lanes x 16 bytes)
     u32x4 wf[4][KS];
     {
-        const int chbase = 64 * cg + 8 * (fr >> 2) + (fr & 3);
+        const int chbase = cbase + 64 * cg + 8 * (fr >> 2) + (fr & 3);
 #pragma unroll
         for (int ci = 0; ci < 4; ++ci)
 #pragma unroll
@@ -84,8 +85,8 @@ __global__ __launch_bounds__(64 * NCG * NRG, 3) void gemm_wreg_kernel(const Gemm
                 wf[ci][ks] = *reinterpret_cast<const u32x4*>(a.w + (size_t)(chbase + 32 * (ci >> 1) + 4 * (ci & 1)) * a.Kp_bytes + (32 * ks + 8 * g) * 2);
     }
     for (int i = t; i < N; i += NT) {
-        tab[i] = a.scale ? a.scale[i] : 1.f;
-        tab[N + i] = a.shift ? a.shift[i] : 0.f;
+        tab[i] = a.scale ? a.scale[cbase + i] : 1.f;
+        tab[N + i] = a.shift ? a.shift[cbase + i] : 0.f;
     }
     const int ch0 = 64 * cg + 8 * g;            // this lane's channels: ch0 .. ch0 + 7 and ch0 + 32 .. ch0 + 39
 
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(64 * NCG * NRG, 3) void gemm_wreg_kernel(const Gemm
                 half8v o0, o1;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { o0[e] = (half_t)v[e]; o1[e] = (half_t)v[8 + e]; }
-                const int yo = m < a.M ? (m * a.y_ld + ch0) * 2 : OOB;
+                const int yo = m < a.M ? (m * a.y_ld + cbase + ch0) * 2 : OOB;
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), ysrd, yo, 0, WR_AUX);
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o1), ysrd, yo, 64, WR_AUX);
             }
@@ -152,15 +153,22 @@ __global__ __launch_bounds__(64 * NCG * NRG, 3) void gemm_wreg_kernel(const Gemm
 // fp16 dense rows, K = 128 (one 256-byte packed filter row), N = 64 * {2 .. 8}, 16-byte aligned rows
 bool gemm_wreg_ok(int dtype, const Gemm256Args& a) {
     if (dtype != TLXMI_F16 || a.rowstats || a.ln_fused || a.conv || a.kslices > 1 || a.res) return false;
-    if (a.kchunks != 16 || a.Kp_bytes != 256) return false;
-    if (a.Cout % 64 || a.Cout < 128 || a.Cout > 512 || (a.Cout / 64 != 2 && a.Cout / 64 != 4 && a.Cout / 64 != 6 && a.Cout / 64 != 8)) return false;
+    const int n64 = a.Cout / 64;
+    if (a.Cout % 64) return false;
+    if (a.kchunks == 16 && a.Kp_bytes == 256) {               // K = 128
+        if (n64 != 2 && n64 != 4 && n64 != 6 && n64 != 8) return false;
+    } else if (a.kchunks == 32 && a.Kp_bytes == 512) {        // K = 256: 128 filter registers a wave, slices of <= 512 channels
+        if (n64 != 4 && n64 != 8 && n64 != 12 && n64 != 16) return false;
+    } else {
+        return false;
+    }
     if (a.x_ld % 8 || a.y_ld % 8) return false;
     if (((uintptr_t)a.x | (uintptr_t)a.y | (uintptr_t)a.w) & 15u) return false;
     if (a.y_bytes == 0 || (long long)a.M * a.y_ld * 2 >= (1ll << 31)) return false;
     return a.M >= 1 && (long long)a.M * a.x_ld * 2 < (1ll << 31);
 }
 
-template <int K, int NCG, int NRG, int PB> static int launch_wreg_t(const Gemm256Args& a, hipStream_t st) {
+template <int K, int NCG, int NRG, int PB> static int launch_wreg_t(const Gemm256Args& a, hipStream_t st, int slices = 1) {
     constexpr int TR = 16 * PB * NRG, NT = 64 * NCG * NRG;
     const size_t lds = (size_t)2 * TR * K * 2 + (size_t)2 * 64 * NCG * sizeof(float);
     const int ntiles = (a.M + TR - 1) / TR;
@@ -169,17 +177,25 @@ template <int K, int NCG, int NRG, int PB> static int launch_wreg_t(const Gemm25
         if (int rc = raise_lds_limit(fn, 160 * 1024, "linear (filter in registers)")) return rc;
     // one persistent workgroup per CU measured best (qkv of Swin-B stage 1 at batch 128: 80.5 / 81.5 / 84.9 us with 1 / 2 / 3)
     long per_cu = tune_int("TLXMI_WREG_WGS", 1);
-    long grid = (long)device_cus() * per_cu;
+    long grid = ((long)device_cus() * per_cu + slices - 1) / slices;
     if (grid > ntiles) grid = ntiles;
     Gemm256Args b = a;
     int nt = ntiles;
     void* args[] = {&b, &nt};
-    hipError_t e = hipLaunchKernel(fn, dim3((unsigned)grid), dim3(NT), args, lds, st);
+    hipError_t e = hipLaunchKernel(fn, dim3((unsigned)grid, (unsigned)slices), dim3(NT), args, lds, st);
     if (e != hipSuccess) return fail(TLXMI_ERR_LAUNCH, "linear (filter in registers): HIP launch failed: %s", hipGetErrorString(e));
     return check_launch("linear (filter in registers)");
 }
 
 int launch_gemm_wreg(const Gemm256Args& a, hipStream_t st) {
+    if (a.kchunks == 32) {
+        switch (a.Cout / 64) {
+            case 4: return launch_wreg_t<256, 4, 2, 2>(a, st);          // 256 channels
+            case 8: return launch_wreg_t<256, 8, 1, 4>(a, st);          // 512
+            case 12: return launch_wreg_t<256, 6, 1, 4>(a, st, 2);      // 768 (qkv of Swin-B stage 2): two slices of 384
+            default: return launch_wreg_t<256, 8, 1, 4>(a, st, 2);      // 1024 (fc1): two slices of 512
+        }
+    }
     switch (a.Cout / 64) {
         case 2: return launch_wreg_t<128, 2, 4, 2>(a, st);      // 128 channels: 2 column groups x 4 row groups, 128-row tiles
         case 4: return launch_wreg_t<128, 4, 2, 4>(a, st);      // 256
