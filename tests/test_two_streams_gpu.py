@@ -93,6 +93,39 @@ def test_resnet50_batch_128_in_two_halves_equals_the_halves_alone(prec):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+def test_vit_batch_64_in_two_halves_equals_the_halves_alone(prec):
+    """vision_transformer.py:313-334 under the two-stream decorator (round 3): every token row depends on its own image only."""
+    dev = torch.device("cuda:0")
+    tlxcv_amd.set_precision(prec)
+    try:
+        m = models.vit_small_patch16_224()
+        m.load_dict(seeded.fill(seeded.shapes_of(m), 1))
+        m = m.to(dev).set_eval()
+        x = torch.from_numpy(seeded.image_batch(32, 0)).to(dev).repeat(2, 1, 1, 1).contiguous()
+        x[32:] = x[32:].flip(3)
+        y = m(x)                                                         # 64 images: split
+        E.set_option("two_streams", False)
+        try:
+            y0, y1 = m(x[:32]), m(x[32:])
+            whole = m(x)
+        finally:
+            E.set_option("two_streams", True)
+        torch.cuda.synchronize()
+        alone = torch.cat((y0, y1), 0)
+        if prec == "fp32":
+            assert torch.equal(y, alone)
+        else:
+            sc = max(1.0, float(alone.float().abs().max()))
+            assert float((y.float() - alone.float()).abs().max()) <= 3e-3 * sc
+        tol = 1e-4 if prec == "fp32" else 3e-3
+        scale = max(1.0, float(whole.float().abs().max()))
+        assert float((y.float() - whole.float()).abs().max()) <= tol * scale
+    finally:
+        tlxcv_amd.set_precision("fp32")
+
+
+@pytest.mark.gpu
 def test_two_streams_inside_a_captured_graph():
     from tlxcv_amd.graph import GraphedForward
     dev = torch.device("cuda:0")

@@ -194,7 +194,8 @@ def run_halves(fn, x, plan=None):
 
 
 def two_streams(min_batch, plan=None):
-    """Decorator of a model's forward(self, x): batches of at least `min_batch` (even) images run as run_halves()."""
+    """Decorator of a model's forward(self, x): batches of at least `min_batch` (even) images run as run_halves().
+    plan: None / "half" / "full" (run_halves), or a callable batch -> one of these."""
     def deco(fwd):
         import functools
 
@@ -202,7 +203,7 @@ def two_streams(min_batch, plan=None):
         def wrapper(self, x, *args, **kwargs):
             if (_options["two_streams"] and not args and not kwargs and isinstance(x, torch.Tensor) and x.is_cuda
                     and x.dim() == 4 and x.shape[0] >= min_batch and x.shape[0] % 2 == 0 and _probe is None):
-                return run_halves(lambda h: fwd(self, h), x, plan)
+                return run_halves(lambda h: fwd(self, h), x, plan(x.shape[0]) if callable(plan) else plan)
             return fwd(self, x, *args, **kwargs)
         return wrapper
     return deco

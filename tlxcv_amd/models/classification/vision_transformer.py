@@ -200,6 +200,9 @@ class VisionTransformer(nn.Module):
                                self.norm.epsilon)                                                         # :327-328
         return cls
 
+    # two half batches on two streams (round 3, hipGraph replay of ViT-B/16 on one box): batch 256 11.05 -> 10.76 ms with
+    # the tiles planned for half the CUs, batch 128 6.14 -> 5.56 ms and batch 64 3.45 -> 3.35 ms with the device's own plan
+    @E.two_streams(64, plan=lambda n: "half" if n >= 256 else None)
     def forward(self, x):
         x = self.forward_features(x)
         if isinstance(self.head, nn.Linear):
