@@ -693,7 +693,10 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
     else if (obi >= 0.0015) { cands[0].eff = 0.85f; cands[1].eff = 0.90f; cands[2].eff = 1.00f; cands[3].eff = 0.90f; }
     if (!allow_stream) cands[7].eff = cands[8].eff = 0.f;
     // the persistent kernel hides the plain epilogue but not the GELU arithmetic (measured: fc1 of ViT-B)
-    if (a.act == TLXMI_ACT_GELU && !tune_int("TLXMI_GELU_STREAM", 0)) cands[8].eff = 0.f;
+    // (except with few row tiles inside a two-stream forward planned for the whole device — Swin-B stage 3, fc1 12544 x 512 ->
+    //  2048 at half batch 64: forward 7.88 -> 7.78 ms with the persistent kernel, tools/tile_search.py; ViT-B/16's fc1: equal)
+    const bool gelu_stream_ok = (a.flags & TLXMI_PLAN_SHARED_FULL) && a.M < 16384 && a.ktiles >= 8;
+    if (a.act == TLXMI_ACT_GELU && !gelu_stream_ok && !tune_int("TLXMI_GELU_STREAM", 0)) cands[8].eff = 0.f;
     // One workgroup per CU: the last round of a 256x256 launch runs a whole tile time however few tiles it
     // has.  When it would be at most half full, the rows of the full rounds go to the 256x256 kernel and the
     // remaining rows to a second launch of the same kernel on 128x256 tiles (gemm_pp128): twice the tiles, about
@@ -729,6 +732,11 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
         const long rounds = (blocks + slots - 1) / slots;
         float quant = (float)blocks / (float)(rounds * slots);
         if ((i == 7 || i == 8) && tail_split) quant = (float)blocks / (((float)full_rounds + 0.6f) * slots);   // the tail round: ~0.6 of a tile time
+        // a two-stream forward planned for the whole device: the CUs a persistent launch leaves idle serve the other stream, and
+        // on long K loops the K-tile stream beats half-height tiles even when it fills under half a round — Swin-B stage 3 at
+        // half batch 64, qkv 12544 x 512 -> 1536 and fc2 2048 -> 512: forward 7.88 -> 7.67 ms (tools/tile_search.py on the graph
+        // replay; the 512 -> 512 proj and every other layer shape measured no gain and keep their price)
+        if (i == 8 && (a.flags & TLXMI_PLAN_SHARED_FULL) && a.ktiles >= 8 && (a.Cout >= 1024 || a.ktiles >= 32) && quant < 0.7f) quant = 0.7f;
         // 3x3 convs on the antiphase kernel: a short last round is cut off along the image axis (below)
         if ((i == 7 || i >= 9) && as_conv && allow_split && tail_mode != 0 && blocks / slots >= 1 &&
             blocks % slots != 0 && 4 * (blocks % slots) <= slots)
