@@ -27,8 +27,9 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             if "to_nhwc_s2d" in row["Kernel_Name"]:
                 f += 1          # one layout transform per forward and stream: counts the forwards of the run
     tot[c] = s; n[c] = k; fwd[c] = f
-# ResNet-50 (batch 256) and Swin-B (batch 128) run as two half batches on two streams (engine.two_streams): two transforms a forward
-parts = 2 if wl in ("resnet50", "swin_b") else 1
+# ResNet-50 / ViT-B/16 (batch 256) and Swin-B (batch 128) run as two half batches on two streams (engine.two_streams): two
+# transforms a forward
+parts = 2
 forwards = max(fwd["FETCH_SIZE"] // parts, 1)
 fetch_kb, write_kb = tot["FETCH_SIZE"] / forwards, tot["WRITE_SIZE"] / max(fwd["WRITE_SIZE"] // parts, 1)
 res = {"workload": wl, "kernel": "every kernel of a forward", "csrc_sha": bench.csrc_sha(),
