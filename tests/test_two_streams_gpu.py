@@ -54,6 +54,37 @@ def test_split_rules_on_the_device():
         E.set_option("two_streams", True)
 
 
+class _GraphOnly:
+    calls = []
+
+    @E.two_streams(4, eager=False)
+    def forward(self, x):
+        _GraphOnly.calls.append(tuple(x.shape))
+        return x * 2
+
+
+@pytest.mark.gpu
+def test_graph_only_models_split_only_while_a_graph_is_captured():
+    """eager=False (MobileNetV3, EfficientNet: host-bound kernel by kernel): one pass when launched eagerly, two halves inside
+    a hipGraph capture."""
+    dev = torch.device("cuda:0")
+    p = _GraphOnly()
+    x = torch.randn((8, 3, 4, 4), device=dev)
+    _GraphOnly.calls.clear()
+    y = p.forward(x)
+    assert _GraphOnly.calls == [(8, 3, 4, 4)] and torch.equal(y, x * 2)
+    p.forward(x)
+    torch.cuda.synchronize()
+    _GraphOnly.calls.clear()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        y = p.forward(x)
+    assert _GraphOnly.calls == [(4, 3, 4, 4), (4, 3, 4, 4)]
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y, x * 2)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("prec", ["fp32", "fp16"])
 def test_resnet50_batch_128_in_two_halves_equals_the_halves_alone(prec):

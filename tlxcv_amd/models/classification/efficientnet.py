@@ -208,7 +208,7 @@ class EfficientNet(nn.Module):
                       b_init="zeros", in_features=lastconv_output_channels),
         )
 
-    @E.two_streams(128, plan="full")
+    @E.two_streams(128, plan="full", eager=False)      # ~250 tiny launches, host-bound kernel by kernel
     def forward(self, x):
         feats = list(self.features)
         first = list(feats[0])

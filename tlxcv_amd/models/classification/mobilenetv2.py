@@ -209,7 +209,7 @@ class MobileNetV3(nn.Module):
                 nn.Linear(in_features=self.lastconv_out_channels, out_features=self.last_channel), nn.Hardswish(),
                 nn.Dropout(p=0.2), nn.Linear(in_features=self.last_channel, out_features=num_classes)])
 
-    @E.two_streams(128, plan="full")
+    @E.two_streams(128, plan="full", eager=False)      # MobileNetV3: ~200 tiny launches, host-bound kernel by kernel
     def forward(self, x):
         v = self.conv.run_nhwc(as_nhwc(x, 'channels_first'))
         for b in self.blocks:
