@@ -11,6 +11,8 @@ ResNet's; AdaptiveAvgPool2d(1) + reshape + Linear (:188-203) are the global-aver
 GEMM with the bias as epilogue shift."""
 import math
 
+import torch
+
 from ... import engine as E
 from ...tlx import nn
 from ...tlx.nn import as_nhwc
@@ -63,6 +65,38 @@ class BottleneckBlock(nn.Module):
         y = self.conv1.run_nhwc(self.conv0.run_nhwc(v))
         return self.conv2.run_nhwc(y, res=short, act=E.ACT_RELU)      # add + relu in the epilogue, :117-118
 
+    # -- the block cut at the seam the engine fuses (as resnet.py's BottleneckBlock): run_head() = conv0 -> grouped conv1; the
+    #    expand conv2 + skip + relu then runs either alone (finish) or in ONE launch with the next block's conv0
+    #    (E.bottleneck_seam: the wide map between two blocks is written once and not re-read by the reduce conv)
+    def run_head(self, v, t0=None):
+        return self.conv1.run_nhwc(t0 if t0 is not None else self.conv0.run_nhwc(v))
+
+    def skip(self, v):
+        return v if self.shortcut else self.short.run_nhwc(v)
+
+    def finish(self, y, short):
+        return self.conv2.run_nhwc(y, res=short, act=E.ACT_RELU)
+
+    def seam_with(self, nxt, y, v):
+        """(block output, nxt.conv0's output) in one launch, or None when the library has no fused kernel for these layers
+        (32x4d: 128 -> 256 -> 128 / 256 and 256 -> 512 -> 256, i.e. stages 1 and 2; fp16, >= 12 images)."""
+        c3, c1 = self.conv2._conv, nxt.conv0._conv
+        dt = E.precision()
+        if (dt != torch.float16 or c3.n_group != 1 or c1.n_group != 1 or c1.stride != (1, 1) or c3.biases is not None
+                or c1.biases is not None or self.conv2.act_code != E.ACT_NONE or nxt.conv0.act_code != E.ACT_RELU
+                or not E.bottleneck_seam_supported(c3.in_channels, c3.out_channels, c1.out_channels, dt)
+                or (c3.in_channels >= 256 and not E.option("seam256"))):
+            return None
+        n_img = y.shape[0]
+        if n_img < 12 or (c3.in_channels >= 256 and n_img < 96 and not E.in_halves()):
+            return None
+        pk3 = c3._cached("pk", lambda: E.PackedFilter(c3.filters, dt))
+        pk1 = c1._cached("pk", lambda: E.PackedFilter(c1.filters, dt))
+        bn3, bn1 = self.conv2.batch_norm, nxt.conv0.batch_norm
+        s3, h3 = c3._cached(("bn", id(bn3)), lambda: bn3.folded(None), deps=(bn3,))
+        s1, h1 = c1._cached(("bn", id(bn1)), lambda: bn1.folded(None), deps=(bn1,))
+        return E.bottleneck_seam(y, pk3, s3, h3, self.skip(v), pk1, s1, h1)
+
     def forward(self, inputs):
         return nn.from_nhwc(self.forward_nhwc(as_nhwc(inputs, self.data_format)), self.data_format)
 
@@ -114,8 +148,16 @@ class ResNeXt(nn.Module):
         else:
             v = self.conv.run_nhwc(as_nhwc(x, self.data_format))
         v = self.pool2d_max.run_nhwc(v)                                                   # :207
-        for block in self.block_list:
-            v = block.forward_nhwc(v)
+        t0 = None
+        for i, block in enumerate(self.block_list):                                       # :208-209, seams between blocks fused
+            y = block.run_head(v, t0)
+            t0 = None
+            nxt = self.block_list[i + 1] if i + 1 < len(self.block_list) else None
+            fused = block.seam_with(nxt, y, v) if nxt is not None else None
+            if fused is not None:
+                v, t0 = fused
+            else:
+                v = block.finish(y, block.skip(v))
         v = E.global_avgpool(v)                                                           # :210-211
         return self.out.run(v)
 
