@@ -10,6 +10,8 @@ shortcut's conv4 + BatchNorm (:287-309) is one launch and the block's add + relu
 import math
 from collections import OrderedDict
 
+import torch
+
 from ... import engine as E
 from ...tlx import nn
 from ...tlx.nn import as_nhwc, from_nhwc
@@ -127,8 +129,64 @@ class BottleneckBlock(nn.Module):
             short = self.conv4.run_nhwc(short, self.batch_norm)
         return self.conv3.run_nhwc(y, res=short, act=E.ACT_RELU)               # :318, :324-326
 
+    # -- the block cut at the seam the engine fuses (as resnet.py's BottleneckBlock): run_head() = conv1 -> (pool) -> split-attention
+    #    conv -> (pool); the expand conv3 + skip + relu then runs alone (finish) or in ONE launch with the next block's conv1
+    def run_head(self, v, t1=None):
+        pool = self.stride > 1 or self.is_first
+        y = t1 if t1 is not None else self.conv1.run_nhwc(v)
+        if self.avd and self.avd_first and pool:
+            y = self.avg_pool2d_1.run_nhwc(y)
+        y = self.conv2.run_nhwc(y)
+        if self.avd and self.avd_first == False and pool:  # noqa: E712
+            y = self.avg_pool2d_2.run_nhwc(y)
+        return y
+
+    def skip(self, v):
+        if self.stride != 1 or self.inplanes != self.planes * 4:
+            if self.avg_down:
+                v = self.avg_pool2d_3.run_nhwc(v)
+            return self.conv4.run_nhwc(v, self.batch_norm)
+        return v
+
+    def finish(self, y, short):
+        return self.conv3.run_nhwc(y, res=short, act=E.ACT_RELU)
+
+    def seam_with(self, nxt, y, v):
+        """(block output, nxt.conv1's output) in one launch, or None (no fused kernel for these widths / fp32 / few images)."""
+        c3, c1 = self.conv3._conv, nxt.conv1._conv
+        dt = E.precision()
+        if (dt != torch.float16 or c3.n_group != 1 or c1.n_group != 1 or c1.stride != (1, 1) or c3.biases is not None
+                or c1.biases is not None or self.conv3.act_code != E.ACT_NONE or nxt.conv1.act_code != E.ACT_RELU
+                or not E.bottleneck_seam_supported(c3.in_channels, c3.out_channels, c1.out_channels, dt)
+                or (c3.in_channels >= 256 and not E.option("seam256"))):
+            return None
+        n_img = y.shape[0]
+        if n_img < 12 or (c3.in_channels >= 256 and n_img < 96 and not E.in_halves()):
+            return None
+        pk3 = c3._cached("pk", lambda: E.PackedFilter(c3.filters, dt))
+        pk1 = c1._cached("pk", lambda: E.PackedFilter(c1.filters, dt))
+        bn3, bn1 = self.conv3.batch_norm, nxt.conv1.batch_norm
+        s3, h3 = c3._cached(("bn", id(bn3)), lambda: bn3.folded(None), deps=(bn3,))
+        s1, h1 = c1._cached(("bn", id(bn1)), lambda: bn1.folded(None), deps=(bn1,))
+        return E.bottleneck_seam(y, pk3, s3, h3, self.skip(v), pk1, s1, h1)
+
     def forward(self, x):
         return from_nhwc(self.forward_nhwc(as_nhwc(x, self.data_format)), self.data_format)
+
+
+def run_block_chain(blocks, v):
+    """All bottleneck blocks of the four stages in order, every block-to-block seam fused where the library has the kernel."""
+    t1 = None
+    for i, blk in enumerate(blocks):
+        y = blk.run_head(v, t1)
+        t1 = None
+        nxt = blocks[i + 1] if i + 1 < len(blocks) else None
+        fused = blk.seam_with(nxt, y, v) if nxt is not None else None
+        if fused is not None:
+            v, t1 = fused
+        else:
+            v = blk.finish(y, blk.skip(v))
+    return v
 
 
 class ResNeStLayer(nn.Module):
@@ -207,8 +265,8 @@ class ResNeSt(nn.Module):
         for m in rest:
             v = m.run_nhwc(v)
         v = self.max_pool2d.run_nhwc(v)                                          # :681
-        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
-            v = layer.forward_nhwc(v)
+        blocks = [b for layer in (self.layer1, self.layer2, self.layer3, self.layer4) for b in layer.bottleneck_block_list]
+        v = run_block_chain(blocks, v)                                           # :682-685, seams between blocks fused (fp16)
         v = E.global_avgpool(v)                                                  # :686-687
         return self.out.run(v)                                                   # :688
 
