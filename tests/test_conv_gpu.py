@@ -515,3 +515,25 @@ def test_conv2d_splitk_refuses_what_it_cannot_slice(dev):
     x = torch.zeros((4, 7, 7, 512), dtype=torch.float16, device=dev)
     with pytest.raises(RuntimeError, match="not supported"):
         _lib.call("tlxmi_conv2d_splitk", C.byref(d), 2, E._p(x), E._p(x), E._p(x), None, None, None, E._p(x), E._stream())
+
+
+# ---- maximum sizes: the kernels address their tensors with 32-bit buffer offsets (2 GiB per tensor).  A descriptor beyond
+# that is refused by the entry point with a message — before any launch, so the buffers handed over here can be tiny
+def test_tensors_beyond_the_32_bit_offsets_are_refused_not_launched(dev):
+    from tlxcv_amd import _lib
+    tiny = torch.zeros(64, device=dev, dtype=torch.float16)
+    f32 = torch.zeros(64, device=dev, dtype=torch.float32)
+    p = E._p
+    pk = E.PackedFilter(torch.zeros((64, 64, 1, 1), device=dev), torch.float16)
+    d = _lib.ConvDesc(dtype=E.dt_code(torch.float16), N=4096, H=224, W=224, C=64, Cout=64, R=1, S=1, stride_h=1, stride_w=1, pad_h=0,
+                      pad_w=0, dil_h=1, dil_w=1, Ho=224, Wo=224, x_ld=64, y_ld=64, res_ld=0, y_nstride=0, res_nstride=0, act=0,
+                      act_param=0.0, flags=0)                       # 26 GB of input
+    with pytest.raises(RuntimeError, match="2 GiB"):
+        _lib.call("tlxmi_conv2d", ctypes.byref(d), p(tiny), p(pk.buf), None, None, None, p(tiny), E._stream())
+    assert _lib.load().tlxmi_group_conv2d_small_supported(ctypes.byref(d), 16) == 0
+    sd = _lib.SeamDesc(dtype=E.dt_code(torch.float16), rows=1 << 23, K1=64, N1=256, N2=64, t2_ld=64, skip_ld=256, y_ld=256, t1_ld=64,
+                       act=E.ACT_RELU)                             # y: 2^23 rows x 512 bytes = 4 GiB
+    with pytest.raises(RuntimeError, match="2 GiB"):
+        _lib.call("tlxmi_bottleneck_seam", ctypes.byref(sd), p(tiny), p(pk.buf), p(f32), p(f32), p(tiny), p(tiny), p(pk.buf), p(f32),
+                  p(f32), p(tiny), E._stream())
+    torch.cuda.synchronize()
