@@ -191,6 +191,50 @@ def test_resnest_fp16_tracks_golden(dev, fp16_mode, fname):
     check_fp16_logits(y, ref, g["argmax"], fname[:-4])
 
 
+# The path ResNeXt / ResNeSt take at every realistic batch: from 12 images per launch their block-to-block seams are ONE
+# launch (resnext.py / resnest.py `seam_with` -> tlxmi_bottleneck_seam; at the fixtures' batch 1-2 it returns None).  The golden
+# images are planted in a batch of 16 other images: their logits must still match the reference-file fixture, and the fused
+# forward must equal the same forward with engine option "seams" off (expand conv + skip and the next reduce conv as two
+# launches) to fp16 rounding.  ResNeSt's skip goes through avg-pool-downsample + conv shortcut (`self.skip(v)`).
+# (fixture, family, batch, fused launches at least): from 12 images the seams whose expand conv reads <= 128 channels, from 96
+# images (or inside a two-stream forward) also those with 256 (ResNeXt stage 2: 256 -> 512 -> 256; ResNeSt stage 3: 256 -> 1024 -> 256)
+SEAM_FAMILIES = [("resnext50_32x4d_b2.npz", "resnext", 16, 3), ("resnest50_b2.npz", "resnest", 16, 6),
+                 ("resnest50_fast_b1.npz", "resnest", 16, 6), ("resnext50_32x4d_b2.npz", "resnext", 96, 6),
+                 ("resnest50_b2.npz", "resnest", 96, 10)]
+
+
+@pytest.mark.parametrize("fname,kind,full,least", SEAM_FAMILIES, ids=[f"{f[0][:-4]}@batch{f[2]}" for f in SEAM_FAMILIES])
+def test_block_seam_path_of_resnext_and_resnest_at_batch_16(dev, fp16_mode, fname, kind, full, least):
+    from tlxcv_amd import engine as E
+    g = np.load(os.path.join(GOLDEN, fname))
+    m, gold = (_resnext if kind == "resnext" else _resnest)(g, dev)
+    nb = gold.shape[0]
+    filler = torch.from_numpy(seeded.image_batch(full, 4321, int(g["hw"]))).to(dev)
+    x = filler.clone()
+    pos = [5, full - 1][:nb]
+    for i, p in enumerate(pos):
+        x[p] = gold[i]
+    calls = []
+    orig = E.bottleneck_seam
+    E.bottleneck_seam = lambda *a, **k: (calls.append(a[1].Cout), orig(*a, **k))[1]
+    try:
+        y = m(x)
+    finally:
+        E.bottleneck_seam = orig
+    assert len(calls) >= least, f"the fused seam launches were not taken at batch {full}: {calls}"
+    got = y[pos].float().cpu().numpy()
+    check_fp16_logits(got, g["logits"], g["argmax"], fname[:-4])
+    E.set_option("seams", False)
+    try:
+        y2 = m(x)
+    finally:
+        E.set_option("seams", True)
+    ref_range = float(g["logits"].max() - g["logits"].min())
+    d = (y.float() - y2.float()).abs().max().item()
+    assert d <= 0.003 * ref_range, f"{fname}: fused vs two-launch seams differ by {d:.3e} (logit range {ref_range:.2f})"
+    assert torch.isfinite(y).all()
+
+
 def _close(got, ref, dtype):
     got = got.float().cpu().numpy()
     scale = np.abs(ref).max()

@@ -14,8 +14,13 @@ pytestmark = pytest.mark.gpu
 # (K1, N1, N2, N, H, W): ResNet-50 layer1 / seam into layer2 / layer2 / seam into layer3 / layer3, small extents
 # ... / layer3 (256 -> 1024 -> 256 at 14 x 14: engine option "seam256", on by default) incl. a ragged row count (3 x 5 x 7 = 105
 # pixels: partial 16-pixel blocks, partial waves, a partial workgroup)
+# ... / the triples ResNeXt-50 32x4d and ResNeSt-50 hand to the same kernels (resnext.py:83-117: 128 -> 256 -> 128 inside stage 1,
+# 128 -> 256 -> 256 into stage 2, 256 -> 512 -> 256 inside stage 2; resnest.py's bottleneck: 64 / 128 / 256 -> 4x -> next width):
+# N1 values the ResNet cases do not reach, each with a ragged row count too
 CASES = [(64, 256, 64, 1, 9, 9), (64, 256, 64, 3, 14, 14), (64, 256, 128, 2, 7, 5), (128, 512, 128, 1, 11, 13),
-         (128, 512, 256, 2, 6, 6), (256, 1024, 256, 2, 14, 14), (256, 1024, 256, 3, 5, 7)]
+         (128, 512, 256, 2, 6, 6), (256, 1024, 256, 2, 14, 14), (256, 1024, 256, 3, 5, 7),
+         (128, 256, 128, 2, 14, 14), (128, 256, 128, 1, 9, 7), (128, 256, 256, 2, 7, 9), (256, 512, 256, 2, 14, 14),
+         (256, 512, 256, 1, 5, 11), (256, 1792, 256, 1, 7, 7), (64, 64, 64, 2, 9, 5), (128, 2048, 256, 1, 6, 5)]
 
 
 def _make(K1, N1, N2, N, H, W, seed):
@@ -51,6 +56,21 @@ def test_seam_matches_the_oracle_and_the_two_launch_path(dev, fp16_mode, cfg):
     # against the same engine run as two launches: same fp32 accumulation of fp16 products, possibly another order
     torch.testing.assert_close(y.float(), y2.float(), atol=2e-3, rtol=2e-3)
     torch.testing.assert_close(t1.float(), t12.float(), atol=4e-3, rtol=4e-3)
+
+
+def test_supported_never_promises_a_launch_that_is_refused(dev, fp16_mode):
+    """Every (K1, N1, N2) `tlxmi_bottleneck_seam_supported` answers yes to must launch (256 -> 2048 -> 256 used to be promised
+    and then refused for 165888 bytes of LDS); the widest N1 per kernel is launched on a handful of pixels."""
+    for K1, N2 in ((64, 64), (64, 128), (128, 128), (128, 256), (256, 256)):
+        widest = max(n1 for n1 in range(64, 4097, 64) if E.bottleneck_seam_supported(K1, n1, N2, torch.float16))
+        assert not E.bottleneck_seam_supported(K1, widest + 64, N2, torch.float16)
+        t2, skip, w3, w1, s3, h3, s1, h1 = _make(K1, widest, N2, 1, 3, 5, seed=widest)
+        nh = lambda a: a.permute(0, 2, 3, 1).contiguous().half().to(dev)               # noqa: E731
+        pk3, pk1 = E.PackedFilter(w3.to(dev), torch.float16), E.PackedFilter(w1.to(dev), torch.float16)
+        y, t1 = E.bottleneck_seam(nh(t2), pk3, s3.to(dev), h3.to(dev), nh(skip), pk1, s1.to(dev), h1.to(dev))
+        y_ref = OF.conv_bn_act(t2, w3, s3, h3, skip, E.ACT_RELU)
+        torch.testing.assert_close(y.float().cpu().permute(0, 3, 1, 2), y_ref, atol=2e-3, rtol=2e-3)
+    assert not E.bottleneck_seam_supported(256, 2048, 256, torch.float16)
 
 
 def test_seam_at_full_size_is_consistent_with_two_launches(dev, fp16_mode):

@@ -571,7 +571,12 @@ template <int K1, int N2, int PW, int NW, bool PROJ = false, int WPS = 0> static
 
 bool block_seam_shape_ok(int K1, int N1, int N2) {
     if (N1 % 64 || N1 < 64 || N1 > 2048) return false;
-    return (K1 == 64 && (N2 == 64 || N2 == 128)) || (K1 == 128 && (N2 == 128 || N2 == 256)) || (K1 == 256 && N2 == 256);
+    if (!((K1 == 64 && (N2 == 64 || N2 == 128)) || (K1 == 128 && (N2 == 128 || N2 == 256)) || (K1 == 256 && N2 == 256))) return false;
+    // the same LDS arithmetic as the launchers below (two buffers of K1/64 + N2/64 filter panels, the scale / shift tables of both
+    // convolutions, and — wave-pair form of 256 -> N1 -> 256 — 2 KiB of exchange slots per wave): "supported" must never
+    // answer yes to a launch that is then refused (256 -> 2048 -> 256 needs 165888 bytes; found by tests/test_seam_gpu.py)
+    const size_t lds = (size_t)2 * (K1 / 64 + N2 / 64) * 64 * 128 + (size_t)(2 * N1 + 2 * N2) * sizeof(float) + (K1 == 256 ? (size_t)8 * 2 * 1024 : 0);
+    return lds <= 160 * 1024;
 }
 
 int launch_block_seam(const SeamArgs& a0, int K1, int N2, hipStream_t st) {

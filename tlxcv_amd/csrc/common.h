@@ -89,6 +89,17 @@ template <int ACT> __device__ __forceinline__ float apply_act_t(float x, float p
     else return x;
 }
 template <int V> struct IntTag { static constexpr int value = V; };
+
+// The lane index, recomputed where it is used (2 VALU).  A lane constant derived once at kernel entry (lane & 15, lane >> 4, an
+// LDS offset built from them) stays live across a persistent kernel's whole K-tile stream; at the 256-register budget of two
+// waves per SIMD hipcc then spills it, and the reload is a scratch (vector-memory) load whose wait is `s_waitcnt vmcnt(0)` —
+// it drains every LDS-DMA in flight (gemm_stream's residual variants did that three times per output tile).  `volatile`
+// keeps the compiler from hoisting / merging the two instructions back into one long-lived value.
+__device__ __forceinline__ int lane_now() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
 // calls f(IntTag<act>{}) for the runtime activation code
 #define TLXMI_DISPATCH_ACT(act, f)                          \
     switch (act) {                                          \

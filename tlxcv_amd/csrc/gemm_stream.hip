@@ -159,6 +159,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
         int bm0 = 0, bn0 = 0;
         const bool ok = tile_origin(i, bm0, bn0);
         char* dst = smem + TABLE + (i & 1) * 2048 + wid * 256;
+        const int lane = lane_now();
         if (lane < 8) {
             const int off = ok ? (bn0 + 32 * wid + 4 * lane) * 4 : OOB;
             gs_dma16(hsrd, dst, off);
@@ -196,8 +197,8 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
     // 128h + 64wr + 16pi + px.  Always S stores (suppressed ones go to an out-of-range offset).
     auto epi = [&](auto h_tag, auto g_tag, int bm0, int bn0, int tpar, bool live) {
         constexpr int H = decltype(h_tag)::value, G = decltype(g_tag)::value;
-        int px = frow;
-        asm volatile("" : "+v"(px));   // offsets are recomputed here, not kept live across the K loop
+        const int ln = lane_now();     // offsets are recomputed here, not kept live across the K loop (common.h: lane_now)
+        const int px = ln & 15, fg = ln >> 4;
         const int col = 128 * G + 32 * wc + 8 * fg;
         const int ch0 = bn0 + col;
         const bool chok = live && ch0 < a.Cout && !TLXMI_DBG(a, 2);      // Cout is a multiple of 8 on this path
@@ -267,8 +268,8 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
     // 2*(r&1), 2*(r&1)+1: R loads now, added into the accumulators one K tile later.
     auto res_load = [&](auto r_tag, int bm0, int bn0) {
         constexpr int RS = decltype(r_tag)::value, Q = RS >> 1, H = (Q >> 1), G = (Q == 1 || Q == 2) ? 1 : 0, P0 = 2 * (RS & 1);
-        int px = frow;
-        asm volatile("" : "+v"(px));
+        const int ln = lane_now();
+        const int px = ln & 15, fg = ln >> 4;
         const int ch0 = bn0 + 128 * G + 32 * wc + 8 * fg;
 #pragma unroll
         for (int p = 0; p < 2; ++p) {

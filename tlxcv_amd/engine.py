@@ -24,6 +24,8 @@ _options = {"splitk": True,       # classifier heads: K slices side by side (tlx
                                   # neutral to slower in both forms, off
             "lnfuse_pass": False, # with lnfuse: the two-launch form (row statistics pass + tlxmi_linear_ln) instead of in-kernel statistics
             "attn_comb": True,    # Swin attention with the pre-summed bias + mask table (tlxmi_attention_comb)
+            "seams": True,        # block-to-block seams of the bottleneck families as one launch (tlxmi_bottleneck_seam); off = the
+                                  # expand conv and the next block's reduce conv as two launches (the A/B and the parity tests' other arm)
             "seam256": True,      # bottleneck seams with a 256-channel conv3 input (ResNet-50 layer3, 14 x 14) fused too
             "two_streams": True,  # large batches as two half batches on two HIP streams (two_streams(), below)
             "conv_splitk": True}  # convs with few pixels and a long K on K slices (tlxmi_conv2d_splitk)

@@ -155,7 +155,7 @@ class BottleneckBlock(nn.Module):
         """(block output, nxt.conv1's output) in one launch, or None (no fused kernel for these widths / fp32 / few images)."""
         c3, c1 = self.conv3._conv, nxt.conv1._conv
         dt = E.precision()
-        if (dt != torch.float16 or c3.n_group != 1 or c1.n_group != 1 or c1.stride != (1, 1) or c3.biases is not None
+        if (not E.option("seams") or dt != torch.float16 or c3.n_group != 1 or c1.n_group != 1 or c1.stride != (1, 1) or c3.biases is not None
                 or c1.biases is not None or self.conv3.act_code != E.ACT_NONE or nxt.conv1.act_code != E.ACT_RELU
                 or not E.bottleneck_seam_supported(c3.in_channels, c3.out_channels, c1.out_channels, dt)
                 or (c3.in_channels >= 256 and not E.option("seam256"))):

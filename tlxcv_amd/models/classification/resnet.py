@@ -109,7 +109,7 @@ class BottleneckBlock(nn.Module):
         source — or None when there is no fused kernel for these layers."""
         c3, c1 = self.conv3, nxt.conv1
         dt = E.precision()
-        if (dt != torch.float16 or c3.n_group != 1 or c1.n_group != 1 or c1.kernel_size != (1, 1) or c1.stride != (1, 1)
+        if (not E.option("seams") or dt != torch.float16 or c3.n_group != 1 or c1.n_group != 1 or c1.kernel_size != (1, 1) or c1.stride != (1, 1)
                 or c1.padding != (0, 0) or c3.biases is not None or c1.biases is not None
                 or not E.bottleneck_seam_supported(c3.in_channels, c3.out_channels, c1.out_channels, dt)
                 or (c3.in_channels >= 256 and not E.option("seam256"))):

@@ -82,7 +82,7 @@ class BottleneckBlock(nn.Module):
         (32x4d: 128 -> 256 -> 128 / 256 and 256 -> 512 -> 256, i.e. stages 1 and 2; fp16, >= 12 images)."""
         c3, c1 = self.conv2._conv, nxt.conv0._conv
         dt = E.precision()
-        if (dt != torch.float16 or c3.n_group != 1 or c1.n_group != 1 or c1.stride != (1, 1) or c3.biases is not None
+        if (not E.option("seams") or dt != torch.float16 or c3.n_group != 1 or c1.n_group != 1 or c1.stride != (1, 1) or c3.biases is not None
                 or c1.biases is not None or self.conv2.act_code != E.ACT_NONE or nxt.conv0.act_code != E.ACT_RELU
                 or not E.bottleneck_seam_supported(c3.in_channels, c3.out_channels, c1.out_channels, dt)
                 or (c3.in_channels >= 256 and not E.option("seam256"))):
