@@ -1,4 +1,4 @@
-"""The 256 x 256 GEMM kernels behind tlxmi_conv2d (gemm_pp.hip = candidate 7, gemm_stream.hip = candidate 8;
+"""The 256 x 256 GEMM kernels behind tlxmi_conv2d (gemm_pp.hip = candidate 7, gemm_stream.hip = candidate 8, gemm_w4.hip = candidate 11;
 Linear layers of reference vision_transformer.py:81-87,112-123) against the CPU oracle, one candidate
 forced at a time through TLXMI_TILE — the dispatcher would otherwise pick them only for large layers.
 
@@ -72,7 +72,7 @@ SHAPES = [
 ]
 
 
-@pytest.mark.parametrize("tile", [7, 8], ids=["pp", "stream"])
+@pytest.mark.parametrize("tile", [7, 8, 11], ids=["pp", "stream", "w4"])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.float32], ids=["fp16", "fp32"])
 @pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "x".join(map(str, s)))
 def test_linear_bias(dev, force_tile, tile, dtype, shape):
@@ -80,7 +80,7 @@ def test_linear_bias(dev, force_tile, tile, dtype, shape):
     run_linear(dev, dtype, *shape)
 
 
-@pytest.mark.parametrize("tile", [7, 8], ids=["pp", "stream"])
+@pytest.mark.parametrize("tile", [7, 8, 11], ids=["pp", "stream", "w4"])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.float32], ids=["fp16", "fp32"])
 @pytest.mark.parametrize("epi", ["none", "gelu", "relu", "res", "res_relu", "bn_relu", "bn_res", "nobias_res"])
 def test_linear_epilogues(dev, force_tile, tile, dtype, epi):
@@ -90,7 +90,7 @@ def test_linear_epilogues(dev, force_tile, tile, dtype, epi):
     run_linear(dev, dtype, 2 * 256 + 40, 768, 768, seed=3, **kw)
 
 
-@pytest.mark.parametrize("tile", [7, 8], ids=["pp", "stream"])
+@pytest.mark.parametrize("tile", [7, 8, 11], ids=["pp", "stream", "w4"])
 def test_many_tiles_per_workgroup(dev, force_tile, tile):
     # 197 x 3 tiles of the ViT-B proj / fc2 layers at batch 256: 2-3 tiles per workgroup with a residual
     force_tile(tile)

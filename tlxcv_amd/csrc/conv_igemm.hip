@@ -639,10 +639,11 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
     // candidate 8 = gemm_stream.hip: candidate 7 as a persistent kernel (one K-tile stream per CU)
     // candidate 9 = gemm_pp.hip on 128 x 256 tiles (3x3 convs whose 256 x 256 tiles would fill under half the CUs)
     // candidate 10 = gemm_pp.hip on 256 x 128 tiles (3x3 convs with 128 output channels)
-    constexpr int NC = 11;
+    // candidate 11 = gemm_w4.hip: 256 x 256 persistent, four waves with 128 x 128 wave tiles (pure GEMM rows)
+    constexpr int NC = 12;
     Cand cands[NC] = {{128, 128, 1.00f}, {64, 128, 0.85f}, {128, 64, 0.85f}, {64, 64, 0.70f}, {256, 128, 0.90f},
                       {256, 256, 1.12f}, {256, 128, 1.20f}, {256, 256, 1.40f}, {256, 256, 1.50f}, {128, 256, 1.25f},
-                      {256, 128, 1.25f}};
+                      {256, 128, 1.25f}, {256, 256, 0.f}};
     const bool gemm128_ok = a.nchunk == 1 && a.R == 1 && a.S == 1 && a.ph == 0 && a.pw == 0 && a.sh == 1 && a.sw == 1 && !a.strided_n &&
                             a.vec_io && a.Cout % 8 == 0 && a.y_bytes != 0 && a.Cout >= 128 && a.ktiles >= 2 &&
                             (!a.res || (long long)a.M * a.res_ld * (long long)sizeof(T) < (1ll << 31));
@@ -675,7 +676,7 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
         g.res_bytes = a.res ? (unsigned)((long long)a.M * a.res_ld * (long long)sizeof(T)) : 0u;
         if (gemm_wreg_ok(TLXMI_F16, g)) return launch_gemm_wreg(g, st);
     }
-    if (!gemm256_ok) cands[5].eff = cands[6].eff = cands[8].eff = 0.f;
+    if (!gemm256_ok) cands[5].eff = cands[6].eff = cands[8].eff = cands[11].eff = 0.f;
     if (!gemm256_ok && !pp_conv_ok) cands[7].eff = 0.f;
     // 128 x 256 tiles for plain GEMM rows too (few row tiles: 7 x 7 stage, 2048 -> 512); TLXMI_PP128=0: convs only (A/B)
     const int pp128_gemm = (int)tune_int("TLXMI_PP128", 1);
@@ -720,7 +721,7 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
         const int bm = cands[i].bm, bn = cands[i].bn;
         if (cands[i].eff <= 0.f) continue;
         if (bn == 128 && a.Cout <= 64) continue;
-        size_t lds = (i == 5 || i >= 7) ? (size_t)(i >= 9 ? 144 : 128) * 1024 : i == 6 ? (size_t)72 * 1024 : (size_t)(a.ktiles > 1 ? (i == 4 ? 3 : 2) : 1) * (bm + bn) * 128;
+        size_t lds = (i == 5 || i >= 7) ? (size_t)((i == 9 || i == 10) ? 144 : 128) * 1024 : i == 6 ? (size_t)72 * 1024 : (size_t)(a.ktiles > 1 ? (i == 4 ? 3 : 2) : 1) * (bm + bn) * 128;
         if (i < 5 && lds < (size_t)bm * bn * 4) lds = (size_t)bm * bn * 4;   // fp32 epilogue tile (gemm256 stores from registers)
         lds += 2 * bn * sizeof(float);                                        // scale / shift table
         int per_cu = (int)((160 * 1024) / lds);
@@ -738,7 +739,7 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
         // replay; the 512 -> 512 proj and every other layer shape measured no gain and keep their price)
         if (i == 8 && (a.flags & TLXMI_PLAN_SHARED_FULL) && a.ktiles >= 8 && (a.Cout >= 1024 || a.ktiles >= 32) && quant < 0.7f) quant = 0.7f;
         // 3x3 convs on the antiphase kernel: a short last round is cut off along the image axis (below)
-        if ((i == 7 || i >= 9) && as_conv && allow_split && tail_mode != 0 && blocks / slots >= 1 &&
+        if ((i == 7 || i == 9 || i == 10) && as_conv && allow_split && tail_mode != 0 && blocks / slots >= 1 &&
             blocks % slots != 0 && 4 * (blocks % slots) <= slots)
             quant = (float)blocks / (((float)(blocks / slots) + 0.4f) * slots);
         // wasted work inside partial tiles
@@ -764,7 +765,7 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
     const int forced = a.pp_slices > 1 ? -1 : (int)tune_int("TLXMI_TILE", -1);
     if (forced >= 0 && forced < NC && !(cands[forced].bn == 128 && a.Cout <= 64) &&
         (forced < 5 || (forced <= 9 && gemm256_ok) || ((forced == 7 || forced == 9) && pp_conv_ok) ||
-         (forced == 10 && (pp_conv128_ok || gemm128_ok)))) best = forced;
+         (forced == 10 && (pp_conv128_ok || gemm128_ok)) || (forced == 11 && gemm256_ok))) best = forced;
 #ifdef TLXMI_TUNING
     // TLXMI_FORCE="M:K:N:R:s=cand,...": force a candidate for one layer shape (tools/tile_search.py)
     if (const char* fs = getenv("TLXMI_FORCE")) {
@@ -774,14 +775,14 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
         if (hit && (hit == fs || hit[-1] == ',')) {
             const int f = atoi(hit + strlen(key));
             if (f >= 0 && f < NC && !(cands[f].bn == 128 && a.Cout <= 64) && (f != 4 || a.ktiles >= 4) &&
-                (f < 5 || (f <= 9 && gemm256_ok) || ((f == 7 || f == 9) && pp_conv_ok) || (f == 10 && (pp_conv128_ok || gemm128_ok)))) best = f;
+                (f < 5 || (f <= 9 && gemm256_ok) || ((f == 7 || f == 9) && pp_conv_ok) || (f == 10 && (pp_conv128_ok || gemm128_ok)) || (f == 11 && gemm256_ok))) best = f;
         }
     }
     if (tune_int("TLXMI_TRACE_TILES", 0))
         fprintf(stderr, "tile M=%d K=%d N=%d R=%d s=%d res=%d plan_cus=%d -> cand %d (%dx%d)\n", a.M, a.C * a.R * a.S, a.Cout, a.R, a.sh, a.res ? 1 : 0, cus, best,
                 cands[best].bm, cands[best].bn);
 #endif
-    if ((best == 7 || best >= 9) && as_conv && allow_split && tail_mode != 0 && a.pp_slices <= 1) {
+    if ((best == 7 || best == 9 || best == 10) && as_conv && allow_split && tail_mode != 0 && a.pp_slices <= 1) {
         // Image-axis tail split: one workgroup per CU, so a last round with few tiles costs a whole tile time.  The
         // images whose rows fill the whole rounds stay on this kernel; the last few images are a convolution of their
         // own on the small tiles (28 x 28 stage of ResNet-50 at batch 256: 784 tiles = 3.06 rounds -> 250 + 6 images).
@@ -861,13 +862,19 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
         g.act = a.act; g.act_param = a.act_param; g.flags = a.flags; g.mtiles = g.ntiles = 0;
         g.x_bytes = a.x_bytes; g.w_bytes = a.w_bytes; g.y_bytes = a.y_bytes;
         g.res_bytes = a.res ? (unsigned)((long long)a.M * a.res_ld * (long long)sizeof(T)) : 0u;
+        if (best == 11) {
+            g.ksteps = a.Kp_bytes / 128;
+            if (gemm_w4_ok(sizeof(T) == 2 ? TLXMI_F16 : TLXMI_F32, g))
+                return launch_gemm_w4(sizeof(T) == 2 ? TLXMI_F16 : TLXMI_F32, g, st, cus);
+            best = 8;
+        }
         if (best == 8) {
             g.ksteps = a.Kp_bytes / 128;
             if (gemm_stream_ok(sizeof(T) == 2 ? TLXMI_F16 : TLXMI_F32, g))
                 return launch_gemm_stream(sizeof(T) == 2 ? TLXMI_F16 : TLXMI_F32, g, st, cus);
             best = 7;
         }
-        if (best == 7 || best >= 9) {
+        if (best == 7 || best == 9 || best == 10) {
             g.ksteps = a.Kp_bytes / 128;
             if (a.pp_slices > 1) {
                 g.kslices = a.pp_slices;

@@ -49,6 +49,10 @@ int launch_gemm_pp_n128(int dtype, const Gemm256Args& a, hipStream_t st); // 256
 bool gemm_stream_ok(int dtype, const Gemm256Args& a);
 int launch_gemm_stream(int dtype, const Gemm256Args& a, hipStream_t st, int cus);
 
+// gemm_w4.hip: 256 x 256 tiles on four waves (one per SIMD, 128 x 128 wave tiles, the whole register file), persistent
+bool gemm_w4_ok(int dtype, const Gemm256Args& a);
+int launch_gemm_w4(int dtype, const Gemm256Args& a, hipStream_t st, int cus);
+
 // gemm_wreg.hip: K = 128 rows, all N channels per workgroup, the filter in registers (HBM-bound pointwise layers)
 bool gemm_wreg_ok(int dtype, const Gemm256Args& a);
 int launch_gemm_wreg(const Gemm256Args& a, hipStream_t st);

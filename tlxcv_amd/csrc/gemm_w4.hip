@@ -41,8 +41,9 @@ static __device__ __forceinline__ __amdgpu_buffer_rsrc_t w4_srd(const void* p, u
 static __device__ __forceinline__ u32x4 w4_load16(__amdgpu_buffer_rsrc_t rsrc, int voff) {
     return __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
 }
-static __device__ __forceinline__ void w4_store16(__amdgpu_buffer_rsrc_t rsrc, u32x4 v, int voff) {
-    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff, 0, 0);      // write-back: the next launch reads it from L2 / the Infinity Cache
+// POL: cache policy bits of the store (gfx950: 1 = sc0, 2 = nt, 16 = sc1)
+template <int POL> static __device__ __forceinline__ void w4_store16(__amdgpu_buffer_rsrc_t rsrc, u32x4 v, int voff) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff, 0, POL);
 }
 
 __device__ __attribute__((aligned(16))) float g_w4_ones[4] = {1.f, 1.f, 1.f, 1.f};
@@ -70,16 +71,19 @@ template <int N> __device__ __forceinline__ void w4_vmcnt() {
 }
 
 // ACT: compile-time activation (TLXMI_ACT_*; GELU in fp16 = gelu_fast2, in fp32 = erff).  RES: a.res added before the activation.
-template <typename T, int ACT, bool RES>
+// DBG (tuning flavour only, timing ablations; results are wrong): 1 no LDS-DMA in the loop, 2 no fragment reads in the loop, 4 no
+// mid-tile wait + barrier, 8 no MFMAs.
+template <typename T, int ACT, bool RES, int DBG = 0>
 __global__ __launch_bounds__(256) void gemm_w4_kernel(const Gemm256Args a) {
     constexpr int ES = (int)sizeof(T);
     constexpr int XR = 0, WR = 32768, KTB = 65536;      // regions of a K tile, bytes of a K tile
     constexpr int OOB = (int)0x80000000;
     constexpr int SPT = 32 * (ES / 2);                  // 16-byte stores of a wave's tile per lane
     constexpr int MPF = MmaW4<T>::N;                    // MFMA instructions per fragment pair
+    constexpr int STP = (DBG & 64 ? 16 : 0) | (DBG & 128 ? 2 : 0) | (DBG & 256 ? 1 : 0);      // store policy under test
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int t = threadIdx.x, lane = t & 63;
+    const int t = threadIdx.x;
     const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wr = wid >> 1, wc = wid & 1;
     const int nb = a.mtiles * a.ntiles;
@@ -107,33 +111,47 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const Gemm256Args a) {
     // ---- loader: a piece = 8 rows x 128 B (one wave instruction).  Wave w fills pieces w + 4j (j = 0..7) of the X region and of
     // the W region: rows 32j + 8w + (lane >> 3), slot lane & 7; (row >> 1) & 7 = (4 (w & 1) + (lane >> 4)) & 7 for all of them, so
     // a lane fetches the same K chunk `lc` for its 16 pieces and piece j is a wave-uniform stride further.
-    const int lrow = lane >> 3;
-    const int lc = (lane & 7) ^ ((4 * (wid & 1) + (lane >> 4)) & 7);
+    // Lane constants are (re)derived at the top of every output tile (lane_now(), common.h): nothing lane-constant then lives
+    // across the epilogue, whose register demand would otherwise push them to scratch — and a scratch reload waits vmcnt(0).
+    int lc, xf0, wf0;                              // this lane's K chunk; fragment offsets of the X / W region (k-step 1: ^ 64)
+    int lrow_w;                                    // 8 w + (lane >> 3): this lane's row inside a group of 32
+    auto lane_consts = [&]() {
+        const int ln = lane_now();
+        lc = (ln & 7) ^ ((4 * (wid & 1) + (ln >> 4)) & 7);
+        lrow_w = 8 * wid + (ln >> 3);
+        // fragment reads: lane (frow, fg) reads row frow of a 16-row sub-tile, 16-byte chunk 4 * ksub + fg
+        const int frow = ln & 15, fg = ln >> 4;
+        const int foff = frow * 128 + ((fg ^ ((frow >> 1) & 7)) << 4);
+        xf0 = XR + wr * 128 * 128 + foff;
+        wf0 = WR + wc * 128 * 128 + foff;
+    };
     const int xs32 = 32 * a.x_ld * ES, ws32 = 32 * a.Kp_bytes;
-    int xo, wo;                                    // cursor tile: byte offsets of X row 8w + lrow / of its filter row
+    int xo, wo;                                    // cursor tile: byte offsets of X row 8w + lrow / of its filter row (OOB: no tile)
     auto set_rows = [&](int i) {
         int bm0 = 0, bn0 = 0;
         const bool ok = tile_origin(i, bm0, bn0);
-        const int row = 8 * wid + lrow;            // < 32: the channel permutation acts inside groups of 32 rows
+        const int row = lrow_w;                    // < 32: the channel permutation acts inside groups of 32 rows
         const int n = (((row >> 2) & 3) << 3) | (((row >> 4) & 1) << 2) | (row & 3);
         xo = ok ? (bm0 + row) * a.x_ld * ES : OOB;
         wo = ok ? (bn0 + n) * a.Kp_bytes : OOB;
     };
     char* const lbase = smem + wid * 1024;
-    // pieces j0, j0 + 1 of both operands of the cursor's K tile `kt` -> buffer `par`
-    auto dma_pair = [&](int j, int par, int kt) {
+    // Offsets of piece 0 of both operands for the cursor's K tile (once per K tile; an offset with bit 31 set is out of range for
+    // every descriptor here — all tensors are < 2 GiB — and stays so under the small positive piece strides added below, so the
+    // pieces need no select of their own: zero fill, no memory traffic)
+    int xb, wb;
+    auto dma_prep = [&](int kt) {
         const int q = kt * 8 + lc;
-        const int xb = (q < a.kchunks && xo >= 0) ? xo + q * 16 : OOB;
-        const int wb = (q * 16 < a.Kp_bytes && wo >= 0) ? wo + q * 16 : OOB;
-        char* b = lbase + par * KTB + j * 4096;
-        w4_dma16(xsrd, b + XR, xb >= 0 ? xb + j * xs32 : OOB);
-        w4_dma16(wsrd, b + WR, wb >= 0 ? wb + j * ws32 : OOB);
+        // (branch-free on purpose: a select that hipcc turns into an exec-masked branch cuts the K tile's scheduling region in two)
+        const int xok = ((q - a.kchunks) & ~xo) >> 31, wok = ((q * 16 - a.Kp_bytes) & ~wo) >> 31;      // -1: inside K and a real tile
+        xb = ((xo + q * 16) & xok) | (OOB & ~xok);
+        wb = ((wo + q * 16) & wok) | (OOB & ~wok);
     };
-
-    // ---- fragment reads: lane (frow, fg) reads row frow of a 16-row sub-tile, 16-byte chunk 4 * ksub + fg
-    const int frow = lane & 15, fg = lane >> 4;
-    const int foff = frow * 128 + ((fg ^ ((frow >> 1) & 7)) << 4);
-    const int xf0 = XR + wr * 128 * 128 + foff, wf0 = WR + wc * 128 * 128 + foff;      // ksub 1: the same offset ^ 64
+    auto dma_pair = [&](int j, int par) {
+        char* b = lbase + par * KTB + j * 4096;
+        w4_dma16(xsrd, b + XR, xb + j * xs32);
+        w4_dma16(wsrd, b + WR, wb + j * ws32);
+    };
 
     f32x4 acc[8][8];          // [ci][pi]
     u32x4 wfA[8], xfA[8], wfB[8], xfB[8];
@@ -141,6 +159,13 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const Gemm256Args a) {
     // ---- epilogue of a finished tile, from registers: lane (fg, px) owns channels 128 wc + 32 cp + 8 fg .. +7 of pixel rows
     // 128 wr + 16 pi + px (the filter rows are permuted so that the sub-tiles 2 cp, 2 cp + 1 give 8 neighbours)
     auto epilogue = [&](int bm0, int bn0) {
+        if constexpr ((DBG & 32) != 0) {      // ablation: no epilogue at all
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(acc[i][j]));
+            return;
+        }
         const int ln = lane_now();
         const int px = ln & 15, fq = ln >> 4;
 #pragma unroll
@@ -190,18 +215,18 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const Gemm256Args a) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = apply_act_t<ACT>(v[e], a.act_param);
                 }
-                const int yo = (m < a.M && chok) ? (m * a.y_ld + ch0) * ES : OOB;      // out-of-range stores are dropped
+                const int yo = (m < a.M && chok && !(DBG & 16)) ? (m * a.y_ld + ch0) * ES : OOB;      // out-of-range stores are dropped
                 if constexpr (ES == 2) {
                     half8v hv;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) hv[e] = (half_t)v[e];
-                    w4_store16(ysrd, __builtin_bit_cast(u32x4, hv), yo);
+                    w4_store16<STP>(ysrd, __builtin_bit_cast(u32x4, hv), yo);
                 } else {
                     f32x4 f0, f1;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { f0[e] = v[e]; f1[e] = v[4 + e]; }
-                    w4_store16(ysrd, __builtin_bit_cast(u32x4, f0), yo);
-                    w4_store16(ysrd, __builtin_bit_cast(u32x4, f1), yo + 16);
+                    w4_store16<STP>(ysrd, __builtin_bit_cast(u32x4, f0), yo);
+                    w4_store16<STP>(ysrd, __builtin_bit_cast(u32x4, f1), yo + 16);
                 }
             }
         }
@@ -215,12 +240,15 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const Gemm256Args a) {
     };
 
     // ---- prologue: K tiles 0 and 1 of the stream; fragment set A of K tile 0
+    lane_consts();
     set_rows(0);
+    dma_prep(kc);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) dma_pair(j, 0, kc);
+    for (int j = 0; j < 8; ++j) dma_pair(j, 0);
     advance();
+    dma_prep(kc);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) dma_pair(j, 1, kc);
+    for (int j = 0; j < 8; ++j) dma_pair(j, 1);
     advance();
     w4_vmcnt<16>();
     __builtin_amdgcn_sched_barrier(0);
@@ -240,33 +268,48 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const Gemm256Args a) {
         constexpr int NST = decltype(nst_tag)::value;
         const char* kb = smem + par * KTB;
         const char* kn = smem + (par ^ 1) * KTB;
+        dma_prep(kc);      // (a few VALU instructions: they ride in the issue slots of k-step 0's MFMAs)
         // k-step 0: set A multiplies, set B (k-step 1 of this K tile) arrives
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            wfB[r] = *reinterpret_cast<const u32x4*>(kb + (wf0 ^ 64) + r * 2048);
-            xfB[r] = *reinterpret_cast<const u32x4*>(kb + (xf0 ^ 64) + r * 2048);
+            if constexpr (!(DBG & 2)) {
+                wfB[r] = *reinterpret_cast<const u32x4*>(kb + (wf0 ^ 64) + r * 2048);
+                xfB[r] = *reinterpret_cast<const u32x4*>(kb + (xf0 ^ 64) + r * 2048);
+            }
+            if constexpr (!(DBG & 8)) {
 #pragma unroll
-            for (int pi = 0; pi < 8; ++pi)
-                acc[r][pi] = MmaW4<T>::run(wfA[r], xfA[pi], ZERO ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[r][pi]);
+                for (int pi = 0; pi < 8; ++pi)
+                    acc[r][pi] = MmaW4<T>::run(wfA[r], xfA[pi], ZERO ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[r][pi]);
+            } else {
+                asm volatile("" ::"v"(wfA[r]), "v"(xfA[r]));
+            }
         }
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);          // 2 LDS reads
             __builtin_amdgcn_sched_group_barrier(0x008, 8 * MPF, 0);    // 8 fragment pairs of MFMAs
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's reads of buffer `par` are done ...
-        w4_vmcnt<NST>();                                          // ... and its pieces of the next K tile have landed
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!(DBG & 4)) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's reads of buffer `par` are done ...
+            w4_vmcnt<NST>();                                          // ... and its pieces of the next K tile have landed
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
         // k-step 1: set B multiplies, set A (k-step 0 of the next K tile) arrives, buffer `par` is refilled two K tiles ahead
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            wfA[r] = *reinterpret_cast<const u32x4*>(kn + wf0 + r * 2048);
-            xfA[r] = *reinterpret_cast<const u32x4*>(kn + xf0 + r * 2048);
-            dma_pair(r, par, kc);
+            if constexpr (!(DBG & 2)) {
+                wfA[r] = *reinterpret_cast<const u32x4*>(kn + wf0 + r * 2048);
+                xfA[r] = *reinterpret_cast<const u32x4*>(kn + xf0 + r * 2048);
+            }
+            if constexpr (!(DBG & 1)) dma_pair(r, par);
+            if constexpr (!(DBG & 8)) {
 #pragma unroll
-            for (int pi = 0; pi < 8; ++pi) acc[r][pi] = MmaW4<T>::run(wfB[r], xfB[pi], acc[r][pi]);
+                for (int pi = 0; pi < 8; ++pi) acc[r][pi] = MmaW4<T>::run(wfB[r], xfB[pi], acc[r][pi]);
+            } else {
+                asm volatile("" ::"v"(wfB[r]), "v"(xfB[r]));
+            }
         }
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
@@ -281,6 +324,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const Gemm256Args a) {
     for (int i = 0; i < n_mine; ++i) {
         int bm0, bn0;
         tile_origin(i, bm0, bn0);
+        if (i > 0) lane_consts();
         if (i == 0) ktile(IntTag<1>{}, IntTag<0>{});
         else ktile(IntTag<1>{}, IntTag<SPT>{});
         for (int kt = 1; kt < ks; ++kt) ktile(IntTag<0>{}, IntTag<0>{});
@@ -291,13 +335,13 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const Gemm256Args a) {
 
 // Preconditions as launch_gemm256 (conv_igemm.hip's dispatcher) plus: a.ksteps = packed pitch / 128 >= 2; a residual is
 // added before the activation.
-template <typename T, int ACT, bool RES> static int launch_w4(const Gemm256Args& a0, hipStream_t st, int cus) {
+template <typename T, int ACT, bool RES, int DBG = 0> static int launch_w4(const Gemm256Args& a0, hipStream_t st, int cus) {
     Gemm256Args a = a0;
     a.mtiles = (a.M + 255) / 256;
     a.ntiles = (a.Cout + 255) / 256;
     a.gn = a.ntiles;
     const size_t lds = (size_t)2 * 65536;
-    const void* fn = reinterpret_cast<const void*>(&gemm_w4_kernel<T, ACT, RES>);
+    const void* fn = reinterpret_cast<const void*>(&gemm_w4_kernel<T, ACT, RES, DBG>);
     if (int rc = raise_lds_limit(fn, (int)lds, "gemm_w4")) return rc;
     const int tiles = a.mtiles * a.ntiles;
     int grid = cus & ~7;            // one workgroup per CU; a multiple of 8 keeps a virtual block on its XCD
@@ -316,15 +360,33 @@ bool gemm_w4_ok(int dtype, const Gemm256Args& a) {
     return true;
 }
 
-template <typename T> static int launch_w4_t(const Gemm256Args& a, hipStream_t st, int cus) {
+template <typename T, int DBG> static int launch_w4_d(const Gemm256Args& a, hipStream_t st, int cus) {
     if (a.res) {
-        if (a.act == TLXMI_ACT_RELU) return launch_w4<T, TLXMI_ACT_RELU, true>(a, st, cus);
-        if (a.act == TLXMI_ACT_GELU) return launch_w4<T, TLXMI_ACT_GELU, true>(a, st, cus);
-        return launch_w4<T, TLXMI_ACT_NONE, true>(a, st, cus);
+        if (a.act == TLXMI_ACT_RELU) return launch_w4<T, TLXMI_ACT_RELU, true, DBG>(a, st, cus);
+        if (a.act == TLXMI_ACT_GELU) return launch_w4<T, TLXMI_ACT_GELU, true, DBG>(a, st, cus);
+        return launch_w4<T, TLXMI_ACT_NONE, true, DBG>(a, st, cus);
     }
-    if (a.act == TLXMI_ACT_RELU) return launch_w4<T, TLXMI_ACT_RELU, false>(a, st, cus);
-    if (a.act == TLXMI_ACT_GELU) return launch_w4<T, TLXMI_ACT_GELU, false>(a, st, cus);
-    return launch_w4<T, TLXMI_ACT_NONE, false>(a, st, cus);
+    if (a.act == TLXMI_ACT_RELU) return launch_w4<T, TLXMI_ACT_RELU, false, DBG>(a, st, cus);
+    if (a.act == TLXMI_ACT_GELU) return launch_w4<T, TLXMI_ACT_GELU, false, DBG>(a, st, cus);
+    return launch_w4<T, TLXMI_ACT_NONE, false, DBG>(a, st, cus);
+}
+
+template <typename T> static int launch_w4_t(const Gemm256Args& a, hipStream_t st, int cus) {
+#ifdef TLXMI_TUNING
+    if constexpr (sizeof(T) == 2) {
+        switch ((int)tune_int("TLXMI_W4_DBG", 0)) {      // timing ablations (results are wrong)
+            case 1: return launch_w4<T, TLXMI_ACT_NONE, false, 1>(a, st, cus);
+            case 4: return launch_w4<T, TLXMI_ACT_NONE, false, 4>(a, st, cus);
+            case 5: return launch_w4<T, TLXMI_ACT_NONE, false, 5>(a, st, cus);
+            case 7: return launch_w4<T, TLXMI_ACT_NONE, false, 7>(a, st, cus);
+            case 16: return launch_w4_d<T, 16>(a, st, cus);
+            case 32: return launch_w4_d<T, 32>(a, st, cus);
+            case 128: return launch_w4_d<T, 128>(a, st, cus);
+            default: break;
+        }
+    }
+#endif
+    return launch_w4_d<T, 0>(a, st, cus);
 }
 
 int launch_gemm_w4(int dtype, const Gemm256Args& a, hipStream_t st, int cus) {
