@@ -115,7 +115,7 @@ _SPECIAL = {
 }
 ALL_SYMBOLS = sorted(list(PROTOTYPES) + list(_SPECIAL))
 
-TUNE_LIB_PATH = os.path.join(_HERE, "libtlxmi_tune.so")   # `make -C tlxcv_amd/csrc tune` (-DTLXMI_TUNING)
+TUNE_LIB_PATH = os.environ.get("TLXMI_TUNE_LIB") or os.path.join(_HERE, "libtlxmi_tune.so")   # `make -C tlxcv_amd/csrc tune` (-DTLXMI_TUNING); TLXMI_TUNE_LIB: A/B two builds (tools/)
 
 _lib = None        # the library call() goes through: the product build, or the tuning flavour inside `with tuning():`
 _product = None

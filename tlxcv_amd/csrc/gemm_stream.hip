@@ -23,16 +23,21 @@
 // Layout of a K tile in LDS, wave->quadrant map, fragment reads, channel permutation: gemm_pp.hip.
 //
 // In-order VMEM sequence of one wave around a tile boundary (L = last K tile of a tile; D = 2 DMA pieces,
-// S = the stores of a quadrant (32 outputs per lane: 4 x 16 B for fp16, 8 for fp32), T = 2 table pieces, 3 with row statistics), and the counted waits:
+// S = the stores of a quadrant (32 outputs per lane: 4 x 16 B for fp16, 8 for fp32), T = 2 table pieces, 3 with row statistics), and the counted waits.
+// Round 4: a quadrant's epilogue (arithmetic + its S stores) runs INSIDE the MFMA segment that follows the one that finished
+// it — co-issued with that segment's 16 MFMAs on another quadrant (an MFMA 16x16x32 holds the wave's issue for 8 of its 16
+// cycles) — instead of in the load segment in front of it, where it stretched the barrier interval of both wave groups
+// (tools/ab_graph.py on the ViT-B/16 forward: 8.5 ms with every GEMM epilogue removed, 11.0 with them).  The order of the
+// vector-memory operations is unchanged; only the three waits that used to sit behind a store batch now sit in front of it:
 //     p0(L)   D W1(L+1)                        wait W1(L)          : 8
-//     p1(L)   D X1(L+1), S00                   wait X1(L)          : 8 + S
-//     p2(L)   D X0(L+2), T, S01
-//     p3(L)   D W0(L+2), S11                   wait X0,W0(L+1)     : 8 + 3S + T
-//     p0(L+1) S10, D W1(L+2)                   wait W1(L+1)        : 8 + 4S + T
+//     p1(L)   D X1(L+1)                        wait X1(L)          : 8              | MFMAs (0,1) + E00: S00
+//     p2(L)   D X0(L+2), T                                                          | MFMAs (1,1) + E01: S01
+//     p3(L)   D W0(L+2)                        wait X0,W0(L+1)     : 8 + 2S + T     | MFMAs (1,0) + E11: S11
+//     p0(L+1) D W1(L+2)                        wait W1(L+1)        : 8 + 3S + T     | MFMAs (0,0) + E10: S10
 //     p1(L+1) D X1(L+2)                        wait X1(L+1)        : 8 + 4S + T
 //     p2(L+1) D X0(L+3)
 //     p3(L+1) D W0(L+3)                        wait X0,W0(L+2)     : 8 + 2S
-//     p0(L+2) ...                              wait W1(L+2)        : 8      (steady state)
+//     p0(L+2) ...                              wait W1(L+2)        : 8      (waits for S10 too: 8 + S would do)
 // (a count = number of operations issued after the target; counts above 63 are clamped, which only waits
 // for more).  A K tile that issues residual loads (R = 2 for fp16) at p0 uses 8 + R in its waits.
 #include "common.h"
@@ -201,7 +206,9 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
         const int px = ln & 15, fg = ln >> 4;
         const int col = 128 * G + 32 * wc + 8 * fg;
         const int ch0 = bn0 + col;
-        const bool chok = live && ch0 < a.Cout && !TLXMI_DBG(a, 2);      // Cout is a multiple of 8 on this path
+        // (branch-free selects on purpose: an exec-masked branch would cut the MFMA segment this runs in into basic blocks and
+        //  the scheduler could no longer put the arithmetic between the MFMAs)
+        const int chm = (live && !TLXMI_DBG(a, 2)) ? ((ch0 - a.Cout) >> 31) : 0;      // -1: a real channel (Cout is a multiple of 8 on this path)
         if TLXMI_DBG(a, 1) {   // ablation: stores without the arithmetic
 #pragma unroll
             for (int pi = 0; pi < 4 * (ES / 2); ++pi) gs_store16_nt(ysrd, __builtin_bit_cast(u32x4, acc[2 * G][4 * H + (pi & 3)]), OOB);
@@ -248,7 +255,8 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = apply_act_t<ACT>(v[e], a.act_param);
             }
-            const int yo = (chok && m < a.M) ? (m * a.y_ld + ch0) * ES : OOB;   // out-of-range stores are dropped
+            const int okm = chm & ((m - a.M) >> 31);
+            const int yo = (((m * a.y_ld + ch0) * ES) & okm) | (OOB & ~okm);   // out-of-range stores are dropped
             if constexpr (ES == 2) {
                 half8v hv;
 #pragma unroll
@@ -274,7 +282,8 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const int m = bm0 + 128 * H + 64 * wr + 16 * (P0 + p) + px;
-            const int ro = (m < a.M && ch0 < a.Cout) ? (m * a.res_ld + ch0) * ES : OOB;
+            const int okm = ((m - a.M) & (ch0 - a.Cout)) >> 31;
+            const int ro = (((m * a.res_ld + ch0) * ES) & okm) | (OOB & ~okm);
 #pragma unroll
             for (int hh = 0; hh < ES / 2; ++hh) rr[p * (ES / 2) + hh] = gs_load16(rsrd, ro + 16 * hh);
         }
@@ -305,8 +314,10 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
     __builtin_amdgcn_sched_barrier(0);     \
     __builtin_amdgcn_s_barrier();          \
     __builtin_amdgcn_sched_barrier(0);
-// one quadrant x one K tile; ZERO: the accumulators start from 0 (first K tile of an output tile)
-#define GS_MMA(H, G, WF, ZERO)                                                                              \
+// one quadrant x one K tile; ZERO: the accumulators start from 0 (first K tile of an output tile).  EPI: a statement (the
+// epilogue of the quadrant finished one phase earlier) whose instructions the scheduler spreads between the MFMAs: 3 vector
+// instructions behind each MFMA, the rest (and the stores) behind the last one.
+#define GS_MMA_E(H, G, WF, ZERO, EPI)                                                                       \
     {                                                                                                       \
         __builtin_amdgcn_s_setprio(1);                                                                      \
         _Pragma("unroll") for (int pi = 0; pi < 4; ++pi)                                                    \
@@ -316,8 +327,14 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
         _Pragma("unroll") for (int pi = 0; pi < 4; ++pi)                                                    \
         _Pragma("unroll") for (int ci = 0; ci < 2; ++ci)                                                    \
             acc[2 * G + ci][4 * H + pi] = MmaGS<T>::run(WF[ci][1], xf[pi][1], acc[2 * G + ci][4 * H + pi]); \
+        EPI;                                                                                                \
+        _Pragma("unroll") for (int q = 0; q < 16; ++q) {                                                    \
+            __builtin_amdgcn_sched_group_barrier(0x008, sizeof(T) == 2 ? 1 : 4, 0);                         \
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                              \
+        }                                                                                                   \
         __builtin_amdgcn_s_setprio(0);                                                                      \
     }
+#define GS_MMA(H, G, WF, ZERO) GS_MMA_E(H, G, WF, ZERO, (void)0)
 
     const int ks = a.ksteps;
     // stream state: compute side (tile ordinal ci_, buffer parity cpar) and the two DMA cursors
@@ -359,43 +376,41 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
         // ---- p0: quadrant (0,0)
         read_x(kb, RX0);
         read_w(kb, RW0, w0f);
-        if constexpr (MODE == GS_K0_AFTER) epi(IntTag<1>{}, IntTag<0>{}, pbm0, pbn0, (i - 1) & 1, true);
         if constexpr (MODE > GS_R0 && MODE <= GS_RC) res_add(IntTag<MODE - GS_R0 - 1>{});
         if constexpr (RI) {
             __builtin_amdgcn_sched_barrier(0);   // the new loads re-use the registers just consumed
             res_load(IntTag<MODE - GS_R0>{}, bm0, bn0);
         }
         dma_w(RW1, para, wa, kta);
-        gs_vmcnt<(MODE == GS_K0_AFTER ? 8 + 4 * S + TT : 8 + RQ)>();
+        gs_vmcnt<(MODE == GS_K0_AFTER ? 8 + 3 * S + TT : 8 + RQ)>();
         GS_SYNC();
-        GS_MMA(0, 0, w0f, K0);
+        if constexpr (MODE == GS_K0_AFTER) { GS_MMA_E(0, 0, w0f, K0, epi(IntTag<1>{}, IntTag<0>{}, pbm0, pbn0, (i - 1) & 1, true)); }
+        else { GS_MMA(0, 0, w0f, K0); }
         GS_SYNC();
         // ---- p1: quadrant (0,1)
         read_w(kb, RW1, w1f);
         dma_x(RX1, para, xa, kta);
         adv_a();
-        if constexpr (MODE == GS_LAST) epi(IntTag<0>{}, IntTag<0>{}, bm0, bn0, i & 1, true);
-        gs_vmcnt<(MODE == GS_K0_AFTER ? 8 + 4 * S + TT : MODE == GS_LAST ? 8 + S : 8 + RQ)>();
+        gs_vmcnt<(MODE == GS_K0_AFTER ? 8 + 4 * S + TT : 8 + RQ)>();
         GS_SYNC();
-        GS_MMA(0, 1, w1f, K0);
+        if constexpr (MODE == GS_LAST) { GS_MMA_E(0, 1, w1f, K0, epi(IntTag<0>{}, IntTag<0>{}, bm0, bn0, i & 1, true)); }
+        else { GS_MMA(0, 1, w1f, K0); }
         GS_SYNC();
         // ---- p2: quadrant (1,1)
         read_x(kb, RX1);
         dma_x(RX0, parb, xb, ktb);
-        if constexpr (MODE == GS_LAST) {
-            dma_table(i + 1);
-            epi(IntTag<0>{}, IntTag<1>{}, bm0, bn0, i & 1, true);
-        }
+        if constexpr (MODE == GS_LAST) dma_table(i + 1);
         GS_SYNC();
-        GS_MMA(1, 1, w1f, K0);
+        if constexpr (MODE == GS_LAST) { GS_MMA_E(1, 1, w1f, K0, epi(IntTag<0>{}, IntTag<1>{}, bm0, bn0, i & 1, true)); }
+        else { GS_MMA(1, 1, w1f, K0); }
         GS_SYNC();
         // ---- p3: quadrant (1,0)
         dma_w(RW0, parb, wb, ktb);
         adv_b();
-        if constexpr (MODE == GS_LAST) epi(IntTag<1>{}, IntTag<1>{}, bm0, bn0, i & 1, true);
-        gs_vmcnt<(MODE == GS_K0_AFTER ? 8 + 2 * S : MODE == GS_LAST ? 8 + 3 * S + TT : 8 + RQ)>();
+        gs_vmcnt<(MODE == GS_K0_AFTER ? 8 + 2 * S : MODE == GS_LAST ? 8 + 2 * S + TT : 8 + RQ)>();
         GS_SYNC();
-        GS_MMA(1, 0, w0f, K0);
+        if constexpr (MODE == GS_LAST) { GS_MMA_E(1, 0, w0f, K0, epi(IntTag<1>{}, IntTag<1>{}, bm0, bn0, i & 1, true)); }
+        else { GS_MMA(1, 0, w0f, K0); }
         GS_SYNC();
         cpar ^= 1;
     };
@@ -426,6 +441,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
     if (n_mine > 0) epi(IntTag<1>{}, IntTag<0>{}, bm0, bn0, (n_mine - 1) & 1, true);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // zero-fill DMAs of the stream's tail
 #undef GS_MMA
+#undef GS_MMA_E
 #undef GS_SYNC
 }
 
