@@ -369,30 +369,6 @@ int tlxmi_window_reverse_layernorm(const void* win, const void* res, const float
                                    float eps, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * LayerNorm folded into the Linear that follows it (vision_transformer.py:144-159 norm1 -> attn.qkv,
- * norm2 -> mlp.fc1; swin_transformer.py:258-300).  tlxmi_row_stats writes stats[row] = (rstd, -mean*rstd)
- * (biased variance, eps as nn.LayerNorm); tlxmi_linear_ln computes
- *     y[m][n] = act( stats[m][0] * sum_k x[m][k] * Wg[n][k] + stats[m][1] * c1[n] + c2[n] )
- * where the caller packed Wg = W * gamma (tlxmi_pack_filter, 1x1) and prepared
- * c1[n] = sum_k Wg[n][k] (of the values as packed), c2[n] = bias[n] + sum_k W[n][k] * beta[k].
- * x: [rows][x_ld] raw (un-normalised) rows, y: [rows][y_ld].  Returns TLXMI_ERR_UNSUPPORTED for shapes
- * outside the 256 x 256 GEMM kernel (Cout % 8, Cout >= 64, K >= 2 x 128 bytes, tensors < 2 GiB): the caller
- * then keeps tlxmi_layernorm + tlxmi_conv2d.
- * ---------------------------------------------------------------------------------------- */
-int tlxmi_row_stats(const void* x, int dtype, int64_t rows, int C, int x_ld, float eps, float* stats,
-                    void* stream);
-int tlxmi_linear_ln(int dtype, int64_t rows, int K, int Cout, int x_ld, int y_ld, const void* x,
-                    const void* w_packed, const float* c1, const float* c2, const float* rowstats, int act,
-                    void* y, void* stream);
-/* The same in ONE launch, without tlxmi_row_stats: the GEMM kernel sums x and x^2 of the rows it multiplies (from the
- * fragments it feeds the MFMAs) and derives (rstd, -mean * rstd) with `eps` itself — the variance as E[x^2] - mean^2 in
- * fp32 over the fp16 inputs.  fp16 only, Cout >= 256; other shapes / dtypes return TLXMI_ERR_UNSUPPORTED and the caller
- * keeps tlxmi_layernorm + tlxmi_conv2d.  Wg / c1 / c2 as above. */
-int tlxmi_layernorm_linear(int dtype, int64_t rows, int K, int Cout, int x_ld, int y_ld, const void* x,
-                           const void* w_packed, const float* c1, const float* c2, float eps, int act,
-                           void* y, void* stream);
-
-/* ------------------------------------------------------------------------------------------
  * Fused multi-head self attention on a packed qkv matrix (the output of the qkv Linear):
  *   qkv: [B][Ntok][3][heads][hd]   (vision_transformer.py:112-116; swin_transformer.py:194-200)
  *   out: [B][Ntok][heads*hd]       softmax(scale * q k^T + bias + mask) v, heads re-interleaved

@@ -119,9 +119,6 @@ def test_auto_dispatch_tail_split(dev, force_tile):
     run_linear(dev, torch.float16, 50432, 768, 3072, act=E.ACT_GELU, seed=7)
 
 
-# ---- LayerNorm folded into the following Linear: statistics inside the GEMM (tlxmi_layernorm_linear) and the two-launch form
-# (tlxmi_row_stats + tlxmi_linear_ln).  (197 * 67, 768, 3072) = 52 M tiles x 12 = 624 tiles: 2 full rounds + a tail launch of
-# half-height tiles on a 256-CU device for the GELU layer, and several tiles per workgroup of the persistent kernel.
 # ---- K = 128 / 256 on many rows: the filter-in-registers streaming kernel (gemm_wreg.hip; Swin-B stages 1 and 2,
 # swin_transformer.py:192-229, 37-50): every compiled width (K = 128: 128 / 256 / 384 / 512 output channels; K = 256: 256 / 512 / 768 /
 # 1024, the last two as two column slices), a ragged last row tile, every epilogue family (the residual ones stay on the tiled
@@ -149,109 +146,3 @@ def test_linear_k128_filter_in_registers(dev, K, Cout, epi):
     torch.cuda.synchronize()
     torch.testing.assert_close(got.view(M, Cout).float().cpu(), want, **tol(torch.float16))
     torch.testing.assert_close(got.float(), old.float(), atol=2e-3, rtol=2e-3)
-
-
-@pytest.mark.parametrize("in_kernel", [True, False], ids=["in_kernel", "stats_pass"])
-@pytest.mark.parametrize("act", [E.ACT_NONE, E.ACT_GELU], ids=["none", "gelu"])
-@pytest.mark.parametrize("shape", [(197 * 3, 768, 2304), (300, 192, 576), (1000, 128, 512), (77, 384, 1536), (197 * 67, 768, 3072),
-                                   (197 * 67 + 5, 768, 768)], ids=lambda s: "x".join(map(str, s)))
-def test_linear_ln(dev, shape, act, in_kernel):
-    import torch.nn.functional as F
-    M, K, Cout = shape
-    rng = np.random.default_rng(21)
-    x = q16(rnd(rng, (M, K)) * 1.5 + rnd(rng, (M, 1)) * 0.7)         # rows with a non-zero mean
-    w = rnd(rng, (Cout, K), (1.0 / K) ** 0.5)
-    b = rnd(rng, (Cout,), 0.2)
-    gamma = torch.from_numpy(rng.uniform(0.5, 1.5, K).astype(np.float32))
-    beta = rnd(rng, (K,), 0.3)
-    eps = 1e-6
-    want = F.linear(F.layer_norm(x, (K,), gamma, beta, eps), w, b)    # vision_transformer.py:144-159 on torch-CPU fp32
-    if act == E.ACT_GELU:
-        want = F.gelu(want)
-    prep = E.LinearLN(w.to(dev), b.to(dev), gamma.to(dev), beta.to(dev), torch.float16)
-    xd = x.half().to(dev)
-    got = E.linear_ln(xd, prep, eps, act, in_kernel=in_kernel)
-    torch.cuda.synchronize()
-    # the fused form rounds W*gamma to fp16 (the two-launch form rounds LN(x) instead): same size of error
-    torch.testing.assert_close(got.float().cpu(), want, atol=6e-3, rtol=6e-3)
-    for _ in range(3):      # bit-reproducible: the statistics are summed in a fixed order, the table hand-off is race-free
-        assert torch.equal(E.linear_ln(xd, prep, eps, act, in_kernel=in_kernel), got)
-
-
-def test_layernorm_linear_rows_far_from_zero_mean(dev):
-    """The in-kernel statistics take the variance as E[x^2] - mean^2 in fp32: rows whose mean is 40 standard deviations
-    away from zero (|mean| = 20, std 0.5) must still normalise correctly, and a constant row (variance 0) must not blow up."""
-    import torch.nn.functional as F
-    M, K, Cout = 700, 768, 512
-    rng = np.random.default_rng(23)
-    x = rnd(rng, (M, K)) * 0.5 + torch.from_numpy(rng.choice([-20.0, 20.0], (M, 1)).astype(np.float32))
-    x[5] = 3.0
-    x = q16(x)
-    w = rnd(rng, (Cout, K), (1.0 / K) ** 0.5)
-    b = rnd(rng, (Cout,), 0.2)
-    gamma = torch.from_numpy(rng.uniform(0.5, 1.5, K).astype(np.float32))
-    beta = rnd(rng, (K,), 0.3)
-    eps = 1e-5
-    want = F.linear(F.layer_norm(x, (K,), gamma, beta, eps), w, b)
-    prep = E.LinearLN(w.to(dev), b.to(dev), gamma.to(dev), beta.to(dev), torch.float16)
-    got = E.linear_ln(x.half().to(dev), prep, eps, E.ACT_NONE, in_kernel=True).float().cpu()
-    assert torch.isfinite(got).all()
-    # a * (x . W') and b * c1 are both ~ |mean| / std * |c1| and cancel: what is left carries the fp16 rounding of W' times that
-    # ratio (40x the usual) — the bound scales with it; the constant row gives bias + W @ beta exactly in both forms
-    torch.testing.assert_close(got, want, atol=0.12, rtol=2e-2)
-    torch.testing.assert_close(got[5], want[5], atol=6e-3, rtol=6e-3)
-
-
-def test_row_stats(dev):
-    rng = np.random.default_rng(22)
-    x = q16(rnd(rng, (1000, 768)) * 2.0 + 0.5)
-    stats = torch.empty((1000, 2), dtype=torch.float32, device=dev)
-    from tlxcv_amd import _lib
-    import ctypes as C
-    xd = x.half().to(dev)
-    _lib.call("tlxmi_row_stats", C.c_void_p(xd.data_ptr()), 0, 1000, 768, 768, C.c_float(1e-5), C.c_void_p(stats.data_ptr()), None)
-    torch.cuda.synchronize()
-    mean = x.mean(1)
-    rstd = 1.0 / torch.sqrt(x.var(1, unbiased=False) + 1e-5)
-    torch.testing.assert_close(stats[:, 0].cpu(), rstd, atol=1e-5, rtol=1e-5)
-    torch.testing.assert_close(stats[:, 1].cpu(), -mean * rstd, atol=1e-5, rtol=1e-5)
-
-
-# ---- classifier heads: few rows, large filter -> K slices side by side + deterministic reduction (tlxmi_linear_splitk)
-@pytest.mark.parametrize("dtype", [torch.float16, torch.float32], ids=["fp16", "fp32"])
-@pytest.mark.parametrize("shape,act,res", [((64, 25088, 512), E.ACT_RELU, False), ((256, 4096, 1000), E.ACT_NONE, False),
-                                           ((4, 4096, 4096), E.ACT_RELU, False), ((130, 9216, 520), E.ACT_NONE, True),
-                                           ((1, 8192, 1000), E.ACT_NONE, False)], ids=lambda v: str(v).replace(" ", ""))
-def test_linear_splitk(dev, dtype, shape, act, res):
-    M, K, Cout = shape
-    rng = np.random.default_rng(71)
-    x = rnd(rng, (M, K))
-    w = rnd(rng, (Cout, K), (1.0 / K) ** 0.5)
-    b = rnd(rng, (Cout,), 0.2)
-    r = rnd(rng, (M, Cout)) if res else None
-    if dtype == torch.float16:
-        x, w = q16(x), q16(w)
-        r = q16(r) if r is not None else None
-    want = x @ w.t() + b
-    if r is not None:
-        want = want + r
-    if act == E.ACT_RELU:
-        want = torch.relu(want)
-    pk = E.PackedFilter(w.to(dev), dtype)
-    xd = x.to(dtype).to(dev)
-    assert E._linear_splits(M, K, pk, xd) >= 2          # the shapes above take the split path
-    got = E.linear(xd, pk, b.to(dev), r.to(dtype).to(dev) if r is not None else None, act)
-    got2 = E.linear(xd, pk, b.to(dev), r.to(dtype).to(dev) if r is not None else None, act)
-    torch.cuda.synchronize()
-    assert torch.equal(got, got2)                         # fixed summation order
-    # partial sums are fp32 in both modes: the only fp16 rounding is the final store (half an ulp of the result)
-    t = dict(atol=1e-4, rtol=1e-4) if dtype == torch.float32 else dict(atol=1e-3, rtol=1e-3)
-    torch.testing.assert_close(got.float().cpu(), want, **t)
-    if dtype == torch.float16:
-        # the split path equals the unsplit GEMM (fp32 accumulate, one rounding) to fp16 rounding of the result
-        E.set_option("splitk", False)
-        try:
-            plain = E.linear(xd, pk, b.to(dev), r.to(dtype).to(dev) if r is not None else None, act)
-        finally:
-            E.set_option("splitk", True)
-        torch.testing.assert_close(got.float().cpu(), plain.float().cpu(), atol=1e-3, rtol=1e-3)

@@ -86,9 +86,6 @@ PROTOTYPES = {
     "tlxmi_layernorm": [_vp, _vp, _vp, _vp, _i, _l, _i, _i, _i, _f, _vp],
     "tlxmi_layernorm_window_partition": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp],
     "tlxmi_window_reverse_layernorm": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp],
-    "tlxmi_row_stats": [_vp, _i, _l, _i, _i, _f, _vp, _vp],
-    "tlxmi_linear_ln": [_i, _l, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
-    "tlxmi_layernorm_linear": [_i, _l, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp],
     "tlxmi_attention": [C.POINTER(AttnDesc), _vp, _vp, _vp, _vp, _vp],
     "tlxmi_attention_comb": [C.POINTER(AttnDesc), _vp, _vp, _vp, _vp],
     "tlxmi_mha": [C.POINTER(MhaDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -137,27 +137,6 @@ __device__ __forceinline__ f32x2v gelu_fast2(f32x2v x) {
     return x * phi;
 }
 
-// LayerNorm statistics of one 16-row fragment pair (8 dwords = 16 fp16 values of this lane's row): s2 += sum x^2, s1 += sum x.
-// ONE inline-asm block per call: the callers pick the fragment of the wave's row block by a 4-way SCALAR branch on the wave
-// index, and plain C++ in the branches is folded back by the compiler into "copy the selected 8 registers, then common code"
-// (8 v_mov + the same 16 dot products, and the copies of both halves sunk into one load segment); asm statements are not
-// merged.  Dependent v_dot2c accumulations two instructions apart need no wait states (it is what hipcc itself emits); the
-// trailing s_nop covers a plain VALU read of the sums right behind the block.
-static __device__ __forceinline__ void ln_dot16(float& s1, float& s2, const u32x4& f0, const u32x4& f1) {
-    asm volatile(
-        "v_dot2c_f32_f16 %0, %2, %2\n\tv_dot2c_f32_f16 %1, 0x3c003c00, %2\n\t"
-        "v_dot2c_f32_f16 %0, %3, %3\n\tv_dot2c_f32_f16 %1, 0x3c003c00, %3\n\t"
-        "v_dot2c_f32_f16 %0, %4, %4\n\tv_dot2c_f32_f16 %1, 0x3c003c00, %4\n\t"
-        "v_dot2c_f32_f16 %0, %5, %5\n\tv_dot2c_f32_f16 %1, 0x3c003c00, %5\n\t"
-        "v_dot2c_f32_f16 %0, %6, %6\n\tv_dot2c_f32_f16 %1, 0x3c003c00, %6\n\t"
-        "v_dot2c_f32_f16 %0, %7, %7\n\tv_dot2c_f32_f16 %1, 0x3c003c00, %7\n\t"
-        "v_dot2c_f32_f16 %0, %8, %8\n\tv_dot2c_f32_f16 %1, 0x3c003c00, %8\n\t"
-        "v_dot2c_f32_f16 %0, %9, %9\n\tv_dot2c_f32_f16 %1, 0x3c003c00, %9\n\t"
-        "s_nop 2"
-        : "+v"(s2), "+v"(s1)
-        : "v"(f0[0]), "v"(f0[1]), "v"(f0[2]), "v"(f0[3]), "v"(f1[0]), "v"(f1[1]), "v"(f1[2]), "v"(f1[3]));
-}
-
 // ---- wave64 reductions --------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

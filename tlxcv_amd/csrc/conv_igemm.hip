@@ -667,7 +667,7 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
     if (gemm128_ok && sizeof(T) == 2 && (a.kchunks == 16 || wreg_k256) && a.M >= 16384 && a.pp_slices <= 1 && !a.out_f32 && wreg &&
         tune_int("TLXMI_TILE", -1) < 0) {
         Gemm256Args g;
-        g.debug = 0; g.conv = 0; g.rowstats = nullptr;
+        g.debug = 0; g.conv = 0;
         g.x = a.x; g.w = a.w; g.y = a.y; g.scale = a.scale; g.shift = a.shift; g.res = a.res;
         g.M = a.M; g.Cout = a.Cout; g.x_ld = a.x_ld; g.y_ld = a.y_ld; g.res_ld = a.res_ld;
         g.kchunks = a.kchunks; g.ksteps = a.Kp_bytes / 128; g.Kp_bytes = a.Kp_bytes;
@@ -834,7 +834,6 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
             Gemm256Args g;
             g.debug = 0;
             g.conv = 0;
-            g.rowstats = nullptr;
             g.x = hi.x; g.w = hi.w; g.y = hi.y; g.scale = hi.scale; g.shift = hi.shift; g.res = hi.res;
             g.M = hi.M; g.Cout = hi.Cout; g.x_ld = hi.x_ld; g.y_ld = hi.y_ld; g.res_ld = hi.res_ld;
             g.kchunks = hi.kchunks; g.ksteps = hi.Kp_bytes / 128; g.Kp_bytes = hi.Kp_bytes;
@@ -855,7 +854,6 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
             g.ctshift = 0;
             while ((1 << g.ctshift) < tpk) ++g.ctshift;
         }
-        g.rowstats = nullptr;
         g.x = a.x; g.w = a.w; g.y = a.y; g.scale = a.scale; g.shift = a.shift; g.res = a.res;
         g.M = a.M; g.Cout = a.Cout; g.x_ld = a.x_ld; g.y_ld = a.y_ld; g.res_ld = a.res_ld;
         g.kchunks = a.kchunks; g.ksteps = a.Kp_bytes / 64; g.Kp_bytes = a.Kp_bytes;
@@ -1204,102 +1202,6 @@ extern "C" int tlxmi_linear_splitk(int dtype, int64_t rows, int K, int Cout, int
         hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3(grid), dim3(256), 0, as_stream(stream), (const float*)partials, splits, (long)rows, Cout,
                            (long)pstride, scale, shift, (const float*)res, res_ld, act, act_param, flags, (float*)y, y_ld);
     return check_launch("linear_splitk");
-}
-
-// LayerNorm + Linear in one launch (vision_transformer.py:144-159 norm1 -> attn.qkv, norm2 -> mlp.fc1;
-// swin_transformer.py:258-300): with W' = W * gamma (packed), c1[n] = sum_k W'[n][k], c2[n] = bias[n] + sum_k W[n][k] * beta[k]
-// and the row statistics (a, b) = (rstd, -mean * rstd) of tlxmi_row_stats,
-//     Linear(LN(x))[m][n] = a[m] * (x . W'[n]) + b[m] * c1[n] + c2[n]
-// so the normalised activations are never written: the GEMM reads the raw rows, the epilogue applies the row
-// affine.  Runs on the 256 x 256 GEMM kernel (gemm_pp.hip); shapes it does not take return UNSUPPORTED and the
-// caller keeps tlxmi_layernorm + tlxmi_conv2d.
-extern "C" int tlxmi_linear_ln(int dtype, int64_t rows, int K, int Cout, int x_ld, int y_ld, const void* x,
-                               const void* w_packed, const float* c1, const float* c2, const float* rowstats, int act,
-                               void* y, void* stream) {
-    TLXMI_REQUIRE(x && w_packed && y && c1 && c2 && rowstats, TLXMI_ERR_BAD_ARG, "linear_ln: null buffer");
-    TLXMI_REQUIRE(dtype == TLXMI_F16 || dtype == TLXMI_F32, TLXMI_ERR_BAD_ARG, "linear_ln: bad dtype %d", dtype);
-    TLXMI_REQUIRE(rows > 0 && K > 0 && Cout > 0 && x_ld >= K && y_ld >= Cout, TLXMI_ERR_BAD_ARG, "linear_ln: bad extent");
-    TLXMI_REQUIRE(act >= TLXMI_ACT_NONE && act <= TLXMI_ACT_SILU, TLXMI_ERR_BAD_ARG, "linear_ln: bad act %d", act);
-    const int es = (int)elt_size(dtype);
-    TLXMI_REQUIRE((K * es) % 16 == 0 && (x_ld * es) % 16 == 0 && (y_ld * es) % 16 == 0 && aligned16(x) && aligned16(w_packed) && aligned16(y),
-                  TLXMI_ERR_ALIGNMENT, "linear_ln: rows must be whole 16-byte chunks");
-    const long long xb = (long long)rows * x_ld * es, yb = (long long)rows * y_ld * es;
-    const int kchunks = K * es / 16, ktiles = (kchunks + 7) / 8;
-    if (!(Cout % 8 == 0 && Cout >= 64 && ktiles >= 2 && xb < (1ll << 31) && yb < (1ll << 31) && rows < (1ll << 31)))
-        return fail(TLXMI_ERR_UNSUPPORTED, "linear_ln: shape %lld x %d -> %d is outside the 256 x 256 GEMM kernel", (long long)rows, K, Cout);
-    Gemm256Args g;
-    g.debug = 0;
-    g.conv = 0;
-    g.x = (const char*)x; g.w = (const char*)w_packed; g.y = (char*)y; g.scale = c1; g.shift = c2; g.res = nullptr;
-    g.rowstats = rowstats;
-    g.M = (int)rows; g.Cout = Cout; g.x_ld = x_ld; g.y_ld = y_ld; g.res_ld = 0;
-    g.kchunks = kchunks; g.Kp_bytes = ktiles * 128; g.ksteps = ktiles;
-    g.act = act; g.act_param = 0.f; g.flags = 0; g.mtiles = g.ntiles = 0; g.gn = 1;
-    g.x_bytes = (unsigned)xb; g.y_bytes = (unsigned)yb; g.res_bytes = 0;
-    g.w_bytes = (unsigned)(((size_t)(Cout + 127) / 128 * 128) * (size_t)g.Kp_bytes);
-    // the persistent kernel hides the plain epilogue (not the GELU arithmetic): same choice as the dispatcher's
-    const int rc = (act != TLXMI_ACT_GELU && gemm_stream_ok(dtype, g)) ? launch_gemm_stream(dtype, g, as_stream(stream), num_cus())
-                                                                       : launch_gemm_pp(dtype, g, as_stream(stream));
-    if (rc != TLXMI_OK) return rc;
-    return check_launch("linear_ln");
-}
-
-// LayerNorm + Linear in ONE launch, no statistics pass: as tlxmi_linear_ln, but the GEMM kernel sums x and x^2 of the rows it
-// multiplies (from the MFMA fragments, gemm_pp.hip LNF / gemm_stream.hip ROWAFF == 2) and derives (rstd, -mean * rstd)
-// itself.  fp16 only (the fp32 parity mode keeps the reference's order of operations).  A short last round of the
-// one-tile-per-workgroup kernel (GELU layers) runs as a second launch on half-height tiles, like the dispatcher's tail split.
-extern "C" int tlxmi_layernorm_linear(int dtype, int64_t rows, int K, int Cout, int x_ld, int y_ld, const void* x,
-                                      const void* w_packed, const float* c1, const float* c2, float eps, int act,
-                                      void* y, void* stream) {
-    TLXMI_REQUIRE(x && w_packed && y && c1 && c2, TLXMI_ERR_BAD_ARG, "layernorm_linear: null buffer");
-    TLXMI_REQUIRE(dtype == TLXMI_F16 || dtype == TLXMI_F32, TLXMI_ERR_BAD_ARG, "layernorm_linear: bad dtype %d", dtype);
-    TLXMI_REQUIRE(rows > 0 && K > 0 && Cout > 0 && x_ld >= K && y_ld >= Cout && eps >= 0.f, TLXMI_ERR_BAD_ARG, "layernorm_linear: bad extent");
-    TLXMI_REQUIRE(act >= TLXMI_ACT_NONE && act <= TLXMI_ACT_SILU, TLXMI_ERR_BAD_ARG, "layernorm_linear: bad act %d", act);
-    if (dtype != TLXMI_F16) return fail(TLXMI_ERR_UNSUPPORTED, "layernorm_linear: fp16 only (fp32 runs tlxmi_layernorm + tlxmi_conv2d)");
-    const int es = 2;
-    TLXMI_REQUIRE((K * es) % 16 == 0 && (x_ld * es) % 16 == 0 && (y_ld * es) % 16 == 0 && aligned16(x) && aligned16(w_packed) && aligned16(y),
-                  TLXMI_ERR_ALIGNMENT, "layernorm_linear: rows must be whole 16-byte chunks");
-    const long long xb = (long long)rows * x_ld * es, yb = (long long)rows * y_ld * es;
-    const int kchunks = K * es / 16, ktiles = (kchunks + 7) / 8;
-    if (!(Cout % 8 == 0 && Cout >= 256 && ktiles >= 2 && xb < (1ll << 31) && yb < (1ll << 31) && rows < (1ll << 31)))
-        return fail(TLXMI_ERR_UNSUPPORTED, "layernorm_linear: shape %lld x %d -> %d is outside the 256 x 256 GEMM kernel", (long long)rows, K, Cout);
-    Gemm256Args g;
-    g.debug = 0;
-    g.conv = 0;
-    g.x = (const char*)x; g.w = (const char*)w_packed; g.y = (char*)y; g.scale = c1; g.shift = c2; g.res = nullptr;
-    g.rowstats = nullptr;
-    g.ln_fused = 1; g.ln_k = K; g.ln_eps = eps;
-    g.M = (int)rows; g.Cout = Cout; g.x_ld = x_ld; g.y_ld = y_ld; g.res_ld = 0;
-    g.kchunks = kchunks; g.Kp_bytes = ktiles * 128; g.ksteps = ktiles;
-    g.act = act; g.act_param = 0.f; g.flags = 0; g.mtiles = g.ntiles = 0; g.gn = 1;
-    g.x_bytes = (unsigned)xb; g.y_bytes = (unsigned)yb; g.res_bytes = 0;
-    g.w_bytes = (unsigned)(((size_t)(Cout + 127) / 128 * 128) * (size_t)g.Kp_bytes);
-    const hipStream_t st = as_stream(stream);
-    const int cus = num_cus();
-    int rc;
-    {      // one tile per workgroup (gemm_pp.hip, LNF): the persistent kernel does not gather statistics
-        const int nt = (Cout + 255) / 256;
-        const long t256 = (long)((rows + 255) / 256) * nt;
-        const long full = t256 / cus, left = t256 % cus;
-        const int m_split = (int)((full * cus) / nt) * 256;
-        if (full >= 1 && left != 0 && 2 * left <= cus && m_split > 0 && m_split < g.M) {
-            Gemm256Args lo = g, hi = g;
-            lo.M = m_split;
-            lo.x_bytes = (unsigned)((size_t)m_split * x_ld * es);
-            lo.y_bytes = (unsigned)((size_t)m_split * y_ld * es);
-            hi.M = g.M - m_split;
-            hi.x = g.x + (size_t)m_split * x_ld * es;
-            hi.y = g.y + (size_t)m_split * y_ld * es;
-            hi.x_bytes = g.x_bytes - lo.x_bytes;
-            hi.y_bytes = g.y_bytes - lo.y_bytes;
-            rc = launch_gemm_pp(dtype, lo, st);
-            if (rc == TLXMI_OK) rc = launch_gemm_pp128(dtype, hi, st);
-        } else {
-            rc = launch_gemm_pp(dtype, g, st);
-        }
-    }
-    if (rc != TLXMI_OK) return rc;
-    return check_launch("layernorm_linear");
 }
 
 // ------------------------------------------------------------------------------------------

@@ -11,13 +11,6 @@ struct Gemm256Args {
     const float* scale;
     const float* shift;
     const char* res;
-    const float* rowstats;   // [M][2] per-row (a, b): y = act(acc * a + b * scale[n] + shift[n]) (LayerNorm folded into the Linear)
-    // LayerNorm folded in WITHOUT a statistics pass (tlxmi_layernorm_linear): the kernel sums x and x^2 of its own X rows from
-    // the fragments it feeds the MFMAs (v_dot2c_f32_f16, the four waves that share a row block take a quarter each) and
-    // derives (a, b) = (rstd, -mean * rstd) itself.  ln_k = true K (elements); fp16 only; rowstats must be null.
-    int ln_fused = 0;
-    int ln_k = 0;
-    float ln_eps = 0.f;
     int M, Cout, x_ld, y_ld, res_ld;
     int kchunks;   // true 16-byte chunks per row
     int ksteps;    // 64-byte steps (packed pitch / 64)

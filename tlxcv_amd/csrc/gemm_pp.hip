@@ -71,14 +71,8 @@ template <> struct MmaPP<float> {
 // mask of the taps that fall inside the image (bit clear -> out-of-range descriptor offset -> zero fill).
 // HN = W half tiles per K tile: (HM, HN) = (2, 1) is the mirror image of (1, 2) — a 256 x 128 tile for layers with 128
 // output channels (3x3 convs of ResNet's 28 x 28 stage): phases (0,0) and (1,0), X1 taking W1's place in the DMA order.
-// LNF (fp16, !CONV): LayerNorm statistics of the X rows gathered inside the K loop (Gemm256Args::ln_fused).  Lane (frow, fg)
-// holds 8 consecutive K values of row 64wr + 16pi + frow per (pi, ksub) fragment; wave wc sums x and x^2 of the fragments
-// pi == wc (16 v_dot2c per X half and K tile, issued in the load segment AFTER the MFMAs that used the fragments: no
-// wait), and after the K loop the four fg lanes of a row are added, (a, b) = (rstd, -mean * rstd) goes to a 256-row table
-// in LDS, one barrier, and the epilogue applies y = a * acc + b * c1[n] + c2[n] (c1 in `scale`, c2 in `shift`).
-template <typename T, int HM, int HN, bool CONV, bool LNF = false>
+template <typename T, int HM, int HN, bool CONV>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
-    static_assert(!LNF || (!CONV && sizeof(T) == 2 && HN == 2), "in-kernel LayerNorm statistics: fp16 plain GEMM rows, 256 columns");
     static_assert(HM + HN >= 3 && HM <= 2 && HN <= 2, "tile is 256x256, 128x256 or 256x128");
     constexpr int ES = (int)sizeof(T);
     constexpr int BM = 128 * HM, BN = 128 * HN;
@@ -196,17 +190,6 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
             wf[ci][1] = *reinterpret_cast<const u32x4*>(kb + region + ci * 2048 + (wf0 ^ 64));
         }
     };
-    // ---- LNF: running sums of x and x^2 over this wave's row block (pi == wc), [h] = X half
-    float ln_s1[2] = {0.f, 0.f}, ln_s2[2] = {0.f, 0.f};
-    auto ln_acc = [&](auto h_tag) {
-        if constexpr (LNF) {
-            constexpr int h = decltype(h_tag)::value;
-            if (wc == 0) ln_dot16(ln_s1[h], ln_s2[h], xf[0][0], xf[0][1]);      // wc is wave-uniform: scalar branches
-            else if (wc == 1) ln_dot16(ln_s1[h], ln_s2[h], xf[1][0], xf[1][1]);
-            else if (wc == 2) ln_dot16(ln_s1[h], ln_s2[h], xf[2][0], xf[2][1]);
-            else ln_dot16(ln_s1[h], ln_s2[h], xf[3][0], xf[3][1]);
-        }
-    };
 #define TLXMI_PP_MMA(H, G, WF)                                                                       \
     {                                                                                                \
         __builtin_amdgcn_s_setprio(1);                                                               \
@@ -228,17 +211,6 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
         if (a.scale) sc_t = a.scale[ch];
         if (a.shift) sh_t = a.shift[ch];
     }
-    // row statistics of the wave's 8 pixel sub-tiles (LayerNorm folded in): loaded here, used in the epilogue
-    float2 rowab[HM][4];
-#pragma unroll
-    for (int h = 0; h < HM; ++h)
-#pragma unroll
-        for (int pi = 0; pi < 4; ++pi) {
-            const int m = bm0 + 128 * h + 64 * wr + 16 * pi + (lane & 15);
-            if constexpr (CONV || LNF) rowab[h][pi] = make_float2(1.f, 0.f);
-            else rowab[h][pi] = (a.rowstats && m < a.M) ? *reinterpret_cast<const float2*>(a.rowstats + 2 * (size_t)m) : make_float2(1.f, 0.f);
-        }
-    __builtin_amdgcn_sched_barrier(0);   // these loads are older than every DMA: their wait leaves the DMAs in flight
     if constexpr (HM == 2 && HN == 2) {
         stage_x(0, 0, 0);
         stage_w(0, 0, 0);
@@ -307,7 +279,6 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
             // p1
             read_w(kb, RW1, w1f);
             stage_x(1, kt + 1, (kt + 1) & 1);
-            ln_acc(IntTag<0>{});                                         // X0 fragments of this K tile: still in xf until p2
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // X1(kt)
             TLXMI_PP_SYNC();
             TLXMI_PP_MMA(0, 1, w1f);
@@ -320,7 +291,6 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
             TLXMI_PP_SYNC();
             // p3
             stage_w(0, kt + 2, kt & 1);
-            ln_acc(IntTag<1>{});                                         // X1 fragments
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // X0(kt+1), W0(kt+1)
             TLXMI_PP_SYNC();
             TLXMI_PP_MMA(HM - 1, 0, w0f);
@@ -342,7 +312,6 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
             // p1
             read_w(kb, RW1, w1f);
             stage_w(1, kt + 2, b2);
-            ln_acc(IntTag<0>{});
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // X0(kt+1), W0(kt+1)
             TLXMI_PP_SYNC();
             TLXMI_PP_MMA(0, 1, w1f);
@@ -356,23 +325,6 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
 #undef TLXMI_PP_MMA
 #undef TLXMI_PP_SYNC
 
-    float2* const lntab = reinterpret_cast<float2*>(smem + NBUF * KTB + 2 * BN * sizeof(float));   // [BM] (a, b), behind the channel table
-    if constexpr (LNF) {
-        const float inv_k = 1.f / (float)a.ln_k;
-#pragma unroll
-        for (int h = 0; h < HM; ++h) {
-            float s1 = ln_s1[h], s2 = ln_s2[h];
-            s1 += __shfl_xor(s1, 16, 64);
-            s2 += __shfl_xor(s2, 16, 64);
-            s1 += __shfl_xor(s1, 32, 64);
-            s2 += __shfl_xor(s2, 32, 64);
-            const float mean = s1 * inv_k;
-            const float var = fmaxf(s2 * inv_k - mean * mean, 0.f);
-            const float rstd = __builtin_amdgcn_rsqf(var + a.ln_eps);
-            if (lane < 16) lntab[128 * h + 64 * wr + 16 * wc + lane] = make_float2(rstd, -mean * rstd);
-        }
-        __syncthreads();
-    }
     if TLXMI_DBG(a, 1) {   // ablation: no epilogue
 #pragma unroll
         for (int i = 0; i < 2 * HN; ++i)
@@ -432,21 +384,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
                 for (int pi = 0; pi < 4; ++pi) {
                     const int m = bm0 + 128 * h + 64 * wr + prow(pi) * 16 + px;
                     float v[8], rv[8];
-                    if (LNF || (!CONV && a.rowstats)) {   // LayerNorm folded in: row scale, row offset times the filter-row sums, shift
-                        float2 ab;
-                        if constexpr (LNF) ab = lntab[128 * h + 64 * wr + 16 * prow(pi) + px];
-                        else ab = rowab[h][pi];
 #pragma unroll
-                        for (int bb = 0; bb < 4; ++bb) {
-                            v[bb] = acc[2 * g][4 * h + pi][bb] * ab.x + (ab.y * sc[bb] + sf[bb]);
-                            v[4 + bb] = acc[2 * g + 1][4 * h + pi][bb] * ab.x + (ab.y * sc[4 + bb] + sf[4 + bb]);
-                        }
-                    } else {
-#pragma unroll
-                        for (int bb = 0; bb < 4; ++bb) {
-                            v[bb] = acc[2 * g][4 * h + pi][bb] * sc[bb] + sf[bb];
-                            v[4 + bb] = acc[2 * g + 1][4 * h + pi][bb] * sc[4 + bb] + sf[4 + bb];
-                        }
+                    for (int bb = 0; bb < 4; ++bb) {
+                        v[bb] = acc[2 * g][4 * h + pi][bb] * sc[bb] + sf[bb];
+                        v[4 + bb] = acc[2 * g + 1][4 * h + pi][bb] * sc[4 + bb] + sf[4 + bb];
                     }
                     if (a.res) {
                         if constexpr (ES == 2) {
@@ -502,14 +443,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
 }
 
 // Preconditions as launch_gemm256 (checked by conv_igemm.hip's dispatcher); a.ksteps = packed pitch / 128.
-template <typename T, int HM, int HN, bool CONV, bool LNF = false> static int launch_pp_t(const Gemm256Args& a0, hipStream_t st) {
+template <typename T, int HM, int HN, bool CONV> static int launch_pp_t(const Gemm256Args& a0, hipStream_t st) {
     Gemm256Args a = a0;
     a.debug = (int)tune_int("TLXMI_DEBUG", 0);     // ablation bits: tuning flavour only (TLXMI_DBG is `false` in the product)
     a.mtiles = (a.M + 128 * HM - 1) / (128 * HM);
     a.ntiles = (a.Cout + 128 * HN - 1) / (128 * HN);
     a.gn = a.ntiles;
-    const size_t lds = (size_t)(HM + HN == 4 ? 8 : 9) * 128 * 128 + 2 * 256 * sizeof(float) + (LNF ? 256 * sizeof(float2) : 0);
-    const void* fn = reinterpret_cast<const void*>(&gemm_pp_kernel<T, HM, HN, CONV, LNF>);
+    const size_t lds = (size_t)(HM + HN == 4 ? 8 : 9) * 128 * 128 + 2 * 256 * sizeof(float);
+    const void* fn = reinterpret_cast<const void*>(&gemm_pp_kernel<T, HM, HN, CONV>);
     if (int rc = raise_lds_limit(fn, (int)lds, "gemm_pp")) return rc;
     void* args[] = {&a};
     hipError_t e = hipLaunchKernel(fn, dim3((unsigned)(a.mtiles * a.ntiles * (a.kslices > 1 ? a.kslices : 1))), dim3(512), args, lds, st);
@@ -518,10 +459,6 @@ template <typename T, int HM, int HN, bool CONV, bool LNF = false> static int la
 }
 
 int launch_gemm_pp(int dtype, const Gemm256Args& a, hipStream_t st) {
-    if (a.ln_fused) {
-        if (dtype != TLXMI_F16 || a.conv || a.rowstats) return fail(TLXMI_ERR_UNSUPPORTED, "gemm_pp: in-kernel LayerNorm statistics are fp16 GEMM rows only");
-        return launch_pp_t<half_t, 2, 2, false, true>(a, st);
-    }
     if (a.conv) {
         if (dtype == TLXMI_F16) return launch_pp_t<half_t, 2, 2, true>(a, st);
         return launch_pp_t<float, 2, 2, true>(a, st);
@@ -532,10 +469,6 @@ int launch_gemm_pp(int dtype, const Gemm256Args& a, hipStream_t st) {
 
 // 128 x 256 tiles (same preconditions)
 int launch_gemm_pp128(int dtype, const Gemm256Args& a, hipStream_t st) {
-    if (a.ln_fused) {
-        if (dtype != TLXMI_F16 || a.conv || a.rowstats) return fail(TLXMI_ERR_UNSUPPORTED, "gemm_pp: in-kernel LayerNorm statistics are fp16 GEMM rows only");
-        return launch_pp_t<half_t, 1, 2, false, true>(a, st);
-    }
     if (a.conv) {
         if (dtype == TLXMI_F16) return launch_pp_t<half_t, 1, 2, true>(a, st);
         return launch_pp_t<float, 1, 2, true>(a, st);

@@ -23,7 +23,7 @@
 // Layout of a K tile in LDS, wave->quadrant map, fragment reads, channel permutation: gemm_pp.hip.
 //
 // In-order VMEM sequence of one wave around a tile boundary (L = last K tile of a tile; D = 2 DMA pieces,
-// S = the stores of a quadrant (32 outputs per lane: 4 x 16 B for fp16, 8 for fp32), T = 2 table pieces, 3 with row statistics), and the counted waits.
+// S = the stores of a quadrant (32 outputs per lane: 4 x 16 B for fp16, 8 for fp32), T = 2 table pieces), and the counted waits.
 // Round 4: a quadrant's epilogue (arithmetic + its S stores) runs INSIDE the MFMA segment that follows the one that finished
 // it — co-issued with that segment's 16 MFMAs on another quadrant (an MFMA 16x16x32 holds the wave's issue for 8 of its 16
 // cycles) — instead of in the load segment in front of it, where it stretched the barrier interval of both wave groups
@@ -89,16 +89,14 @@ template <int N> __device__ __forceinline__ void gs_vmcnt() {
 
 // ACT: TLXMI_ACT_NONE / RELU / GELU (other activations, and exact-erf GELU in fp32, stay on gemm_pp.hip).
 // RES: a.res is added (before the activation; a.scale must be null) — needs >= 11 K tiles.
-// ROWAFF: per-row (a, b) of tlxmi_row_stats applied in the epilogue (LayerNorm folded in), one more table piece per tile
-template <typename T, int ACT, bool RES, bool ROWAFF>
+template <typename T, int ACT, bool RES>
 __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
     constexpr int ES = (int)sizeof(T);
     constexpr int HALF = 128 * 128;            // bytes of a half tile
     constexpr int RX0 = 0, RX1 = HALF, RW0 = 2 * HALF, RW1 = 3 * HALF;   // regions of a K tile
     constexpr int TABLE = 8 * HALF;            // two tables of 8 x 256 B behind the two K tiles
     constexpr int OOB = (int)0x80000000;
-    constexpr int ROWTAB = TABLE + 2 * 2048;   // two tables of 256 rows x (a, b) behind the channel tables
-    constexpr int S = ES == 2 ? 4 : 8, R = ES, TT = ROWAFF ? 3 : 2;   // R: loads of one residual step (2 pixel rows x 8 channels per lane)
+    constexpr int S = ES == 2 ? 4 : 8, R = ES, TT = 2;   // R: loads of one residual step (2 pixel rows x 8 channels per lane)
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int t = threadIdx.x, lane = t & 63;
@@ -124,7 +122,6 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
     const __amdgpu_buffer_rsrc_t ysrd = gs_srd(a.y, a.y_bytes);
     const __amdgpu_buffer_rsrc_t rsrd = gs_srd(a.res ? a.res : a.y, a.res ? a.res_bytes : 0u);
     const __amdgpu_buffer_rsrc_t hsrd = gs_srd(a.shift, a.shift ? (unsigned)a.Cout * 4u : 0u);   // null: zero fill
-    const __amdgpu_buffer_rsrc_t rowsrd = gs_srd(a.rowstats, a.rowstats ? (unsigned)a.M * 8u : 0u);   // null: zero fill
     const __amdgpu_buffer_rsrc_t ssrd = a.scale ? gs_srd(a.scale, (unsigned)a.Cout * 4u) : gs_srd(g_ones4, 16u);
 
     // ---- loader (gemm_pp.hip): piece = 8 rows x 128 B; wave w fills pieces w, w+8 of a half tile
@@ -170,9 +167,6 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
             gs_dma16(hsrd, dst, off);
             gs_dma16(ssrd, dst + 128, a.scale ? off : 0);
         }
-        // row statistics (LayerNorm folded in, tlxmi_linear_ln): rows 32w .. 32w+31 of the tile, 2 per lane; without
-        // them the piece is a zero fill that keeps the operation count uniform
-        if (ROWAFF && lane < 16) gs_dma16(rowsrd, smem + ROWTAB + (i & 1) * 2048 + wid * 256, ok ? (bm0 + 32 * wid + 2 * lane) * 8 : OOB);
     };
 
     // ---- fragment reads (gemm_pp.hip)
@@ -225,23 +219,14 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
         for (int pi = 0; pi < 4; ++pi) {
             const int m = bm0 + 128 * H + 64 * wr + 16 * pi + px;
             float v[8];
-            if constexpr (ROWAFF) {   // y = a[m] * acc + b[m] * c1[n] + c2[n]
-                const float2 ab = *reinterpret_cast<const float2*>(smem + ROWTAB + tpar * 2048 + (128 * H + 64 * wr + 16 * pi + px) * 8);
 #pragma unroll
-                for (int bb = 0; bb < 4; ++bb) {
-                    v[bb] = acc[2 * G][4 * H + pi][bb] * ab.x + (ab.y * s0[bb] + h0[bb]);
-                    v[4 + bb] = acc[2 * G + 1][4 * H + pi][bb] * ab.x + (ab.y * s1[bb] + h1[bb]);
-                }
-            } else {
-#pragma unroll
-                for (int bb = 0; bb < 4; ++bb) {
-                    if constexpr (RES) {
-                        v[bb] = acc[2 * G][4 * H + pi][bb] + h0[bb];
-                        v[4 + bb] = acc[2 * G + 1][4 * H + pi][bb] + h1[bb];
-                    } else {
-                        v[bb] = acc[2 * G][4 * H + pi][bb] * s0[bb] + h0[bb];
-                        v[4 + bb] = acc[2 * G + 1][4 * H + pi][bb] * s1[bb] + h1[bb];
-                    }
+            for (int bb = 0; bb < 4; ++bb) {
+                if constexpr (RES) {
+                    v[bb] = acc[2 * G][4 * H + pi][bb] + h0[bb];
+                    v[4 + bb] = acc[2 * G + 1][4 * H + pi][bb] + h1[bb];
+                } else {
+                    v[bb] = acc[2 * G][4 * H + pi][bb] * s0[bb] + h0[bb];
+                    v[4 + bb] = acc[2 * G + 1][4 * H + pi][bb] * s1[bb] + h1[bb];
                 }
             }
             if constexpr (ACT == TLXMI_ACT_GELU && ES == 2) {
@@ -447,14 +432,14 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
 
 // Preconditions as launch_gemm256 (conv_igemm.hip's dispatcher) plus: a.ksteps = packed pitch / 128 >= 2;
 // with a residual: fp16, a.scale == nullptr, residual added before the activation, a.ksteps >= 11.
-template <typename T, int ACT, bool RES, bool ROWAFF = false> static int launch_gs(const Gemm256Args& a0, hipStream_t st, int cus) {
+template <typename T, int ACT, bool RES> static int launch_gs(const Gemm256Args& a0, hipStream_t st, int cus) {
     Gemm256Args a = a0;
     a.debug = (int)tune_int("TLXMI_DEBUG", 0);     // ablation bits: tuning flavour only (TLXMI_DBG is `false` in the product)
     a.mtiles = (a.M + 255) / 256;
     a.ntiles = (a.Cout + 255) / 256;
     a.gn = a.ntiles;
-    const size_t lds = (size_t)8 * 128 * 128 + 4 * 2048;   // two K tiles, channel tables, row tables
-    const void* fn = reinterpret_cast<const void*>(&gemm_stream_kernel<T, ACT, RES, ROWAFF>);
+    const size_t lds = (size_t)8 * 128 * 128 + 2 * 2048;   // two K tiles, channel tables
+    const void* fn = reinterpret_cast<const void*>(&gemm_stream_kernel<T, ACT, RES>);
     if (int rc = raise_lds_limit(fn, (int)lds, "gemm_stream")) return rc;
     const int tiles = a.mtiles * a.ntiles;
     int grid = cus & ~7;            // one workgroup per CU; a multiple of 8 keeps a virtual block on its XCD
@@ -468,7 +453,6 @@ template <typename T, int ACT, bool RES, bool ROWAFF = false> static int launch_
 
 template <typename T> static int launch_gs_t(const Gemm256Args& a, hipStream_t st, int cus) {
     if constexpr (sizeof(T) == 2) {
-        if (a.rowstats) return launch_gs<T, TLXMI_ACT_NONE, false, true>(a, st, cus);   // gemm_stream_ok: fp16, no act, no residual
         if (a.res) {
             if (a.act == TLXMI_ACT_RELU) return launch_gs<T, TLXMI_ACT_RELU, true>(a, st, cus);
             return launch_gs<T, TLXMI_ACT_NONE, true>(a, st, cus);
@@ -482,9 +466,8 @@ template <typename T> static int launch_gs_t(const Gemm256Args& a, hipStream_t s
 }
 
 bool gemm_stream_ok(int dtype, const Gemm256Args& a) {
-    if (a.ksteps < 2 || a.ln_fused) return false;      // in-kernel LayerNorm statistics: gemm_pp.hip only
+    if (a.ksteps < 2) return false;
     if (a.act != TLXMI_ACT_NONE && a.act != TLXMI_ACT_RELU && !(a.act == TLXMI_ACT_GELU && dtype == TLXMI_F16 && !a.res)) return false;
-    if (a.rowstats && (dtype != TLXMI_F16 || a.act != TLXMI_ACT_NONE || a.res)) return false;
     if (a.res && (dtype != TLXMI_F16 || a.scale != nullptr || (a.flags & TLXMI_EPI_RES_AFTER_ACT) || a.ksteps < 11)) return false;
     return true;
 }

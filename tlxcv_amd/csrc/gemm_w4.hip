@@ -354,7 +354,7 @@ template <typename T, int ACT, bool RES, int DBG = 0> static int launch_w4(const
 }
 
 bool gemm_w4_ok(int dtype, const Gemm256Args& a) {
-    if (a.ksteps < 2 || a.ln_fused || a.rowstats || a.conv || a.kslices > 1) return false;
+    if (a.ksteps < 2 || a.conv || a.kslices > 1) return false;
     if (a.res && (a.flags & TLXMI_EPI_RES_AFTER_ACT)) return false;
     if (a.act != TLXMI_ACT_NONE && a.act != TLXMI_ACT_RELU && a.act != TLXMI_ACT_GELU) return false;
     return true;

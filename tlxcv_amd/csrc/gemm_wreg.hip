@@ -152,7 +152,7 @@ __global__ __launch_bounds__(64 * NCG * NRG, K == 128 ? 3 : 2) void gemm_wreg_ke
 
 // fp16 dense rows, K = 128 (one 256-byte packed filter row), N = 64 * {2 .. 8}, 16-byte aligned rows
 bool gemm_wreg_ok(int dtype, const Gemm256Args& a) {
-    if (dtype != TLXMI_F16 || a.rowstats || a.ln_fused || a.conv || a.kslices > 1 || a.res) return false;
+    if (dtype != TLXMI_F16 || a.conv || a.kslices > 1 || a.res) return false;
     const int n64 = a.Cout / 64;
     if (a.Cout % 64) return false;
     if (a.kchunks == 16 && a.Kp_bytes == 256) {               // K = 128

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
     }
 #pragma unroll
     for (int r = 0; r < RW; ++r) rstd[r] = 1.f / sqrtf(group_sum<LPR>(rstd[r]) / (float)C + eps);
-    if (stats) {   // statistics only (tlxmi_row_stats): (rstd, -mean * rstd) per row, nothing else is written
+    if (stats) {   // statistics only (internal; no entry point since round 4): (rstd, -mean * rstd) per row, nothing else is written
         if (lane == 0) {
 #pragma unroll
             for (int r = 0; r < RW; ++r)
@@ -279,20 +279,6 @@ extern "C" int tlxmi_layernorm(const void* x, const float* gamma, const float* b
                   TLXMI_ERR_ALIGNMENT, "layernorm: C=%d / strides must be whole 16-byte chunks", C);
     if (dt == TLXMI_F16) return launch_ln<half_t>(x, gamma, beta, y, (long)rows, C, x_ld, y_ld, eps, as_stream(stream));
     return launch_ln<float>(x, gamma, beta, y, (long)rows, C, x_ld, y_ld, eps, as_stream(stream));
-}
-
-// Row statistics of LayerNorm without the normalised output: stats[row] = (rstd, -mean * rstd), so that
-// LN(x)[row][k] = x[row][k] * stats[row][0] + stats[row][1] before gamma / beta.  Feeds tlxmi_linear_ln, which
-// applies the normalisation in the epilogue of the Linear that follows the LayerNorm
-// (vision_transformer.py:144-159: norm1 -> attn.qkv, norm2 -> mlp.fc1; swin_transformer.py:258-300).
-extern "C" int tlxmi_row_stats(const void* x, int dt, int64_t rows, int C, int x_ld, float eps, float* stats, void* stream) {
-    TLXMI_REQUIRE(x && stats && rows > 0 && C > 0, TLXMI_ERR_BAD_ARG, "row_stats: bad argument");
-    TLXMI_REQUIRE(dt == TLXMI_F16 || dt == TLXMI_F32, TLXMI_ERR_BAD_ARG, "row_stats: bad dtype");
-    const int V = 16 / (int)elt_size(dt);
-    TLXMI_REQUIRE(C % V == 0 && x_ld % V == 0 && x_ld >= C && aligned16(x) && ((uintptr_t)stats & 7) == 0, TLXMI_ERR_ALIGNMENT,
-                  "row_stats: C=%d / stride must be whole 16-byte chunks, stats 8-byte aligned", C);
-    if (dt == TLXMI_F16) return launch_ln<half_t>(x, nullptr, nullptr, const_cast<void*>(x), (long)rows, C, x_ld, x_ld, eps, as_stream(stream), stats);
-    return launch_ln<float>(x, nullptr, nullptr, const_cast<void*>(x), (long)rows, C, x_ld, x_ld, eps, as_stream(stream), stats);
 }
 
 // LayerNorm fused with Swin's window plumbing (swin_transformer.py:315-335):

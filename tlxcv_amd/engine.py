@@ -20,9 +20,6 @@ _precision = torch.float16
 
 # Host-side A/B switches (tools/ only; no environment variable is read on the product path).
 _options = {"splitk": True,       # classifier heads: K slices side by side (tlxmi_linear_splitk)
-            "lnfuse": False,      # LayerNorm folded into the next Linear (tlxmi_layernorm_linear / tlxmi_linear_ln): measured
-                                  # neutral to slower in both forms, off
-            "lnfuse_pass": False, # with lnfuse: the two-launch form (row statistics pass + tlxmi_linear_ln) instead of in-kernel statistics
             "attn_comb": True,    # Swin attention with the pre-summed bias + mask table (tlxmi_attention_comb)
             "seams": True,        # block-to-block seams of the bottleneck families as one launch (tlxmi_bottleneck_seam); off = the
                                   # expand conv and the next block's reduce conv as two launches (the A/B and the parity tests' other arm)
@@ -640,73 +637,6 @@ def _linear_splits(rows, K, pk, x):
     if best and rows * pk.Cout * es * best >= (1 << 31):
         return 0
     return best
-
-
-def linear_ln_supported(K, Cout, dtype, rows=None, device=None):
-    """Whether a layer takes the fused LayerNorm + Linear path (set_option("lnfuse", False) turns it off).  fp16 only: the
-    fp32 parity mode keeps the reference's order of operations.  Default form: tlxmi_layernorm_linear — ONE launch, the GEMM
-    kernel sums x and x^2 of its own rows (ViT-B/16: the 36-us LayerNorm pass in front of qkv and fc1 is gone).  With
-    set_option("lnfuse_pass", True): round 2's tlxmi_row_stats + tlxmi_linear_ln (the statistics pass cost what the LayerNorm
-    pass saved); that form has no tail split, so with `rows` given it also requires a well-filled last round."""
-    if not _options["lnfuse"]:
-        return False
-    if not (dtype == torch.float16 and Cout % 8 == 0 and Cout >= 256 and K % 8 == 0 and K * 2 >= 256):
-        return False
-    if rows is not None and _options["lnfuse_pass"]:
-        idx = torch.cuda.current_device() if device is None or device.index is None else device.index
-        if idx not in _cus:
-            _cus[idx] = torch.cuda.get_device_properties(idx).multi_processor_count
-        tiles = ((rows + 255) // 256) * ((Cout + 255) // 256)
-        rounds = (tiles + _cus[idx] - 1) // _cus[idx]
-        if tiles < 0.85 * rounds * _cus[idx]:
-            return False
-    return True
-
-
-class LinearLN:
-    """LayerNorm folded into the Linear that follows it (include/tlxmi.h, tlxmi_linear_ln): packed W * gamma,
-    c1 = row sums of the packed values, c2 = bias + W @ beta."""
-
-    def __init__(self, w_out_in, bias, gamma, beta, dtype):
-        w = w_out_in.detach().float()
-        g, b = gamma.detach().float().to(w.device), beta.detach().float().to(w.device)
-        wg = w * g[None, :]
-        self.pk = PackedFilter(wg.view(w.shape[0], w.shape[1], 1, 1).contiguous(), dtype)
-        self.c1 = wg.to(dtype).float().sum(dim=1).contiguous()
-        self.c2 = (w @ b + (bias.detach().float().to(w.device) if bias is not None else 0.0)).contiguous()
-        self.K, self.Cout = w.shape[1], w.shape[0]
-
-
-def linear_ln(x, prep, eps, act=ACT_NONE, in_kernel=None):
-    """act(Linear(LayerNorm(x))) for x (..., K) on the raw rows.  in_kernel (default: not option "lnfuse_pass"): one launch,
-    statistics gathered inside the GEMM (tlxmi_layernorm_linear); else a row statistics kernel + tlxmi_linear_ln."""
-    need_gpu(x, "input")
-    shp = x.shape
-    if not x.is_contiguous():
-        x = x.contiguous()
-    rows = x.numel() // shp[-1]
-    if in_kernel is None:
-        in_kernel = not _options["lnfuse_pass"]
-    y = torch.empty((*shp[:-1], prep.Cout), dtype=x.dtype, device=x.device)
-    stats = None
-    if not in_kernel:
-        stats = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
-        _lib.call("tlxmi_row_stats", _p(x), dt_code(x.dtype), rows, prep.K, prep.K, C.c_float(eps), _p(stats), _stream())
-    if _probe is not None:      # bench.py's roofline pass: the GEMM launch alone, like conv2d()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-    if in_kernel:
-        _lib.call("tlxmi_layernorm_linear", dt_code(x.dtype), rows, prep.K, prep.Cout, prep.K, prep.Cout, _p(x), _p(prep.pk.buf),
-                  _p(prep.c1), _p(prep.c2), C.c_float(eps), act, _p(y), _stream())
-    else:
-        _lib.call("tlxmi_linear_ln", dt_code(x.dtype), rows, prep.K, prep.Cout, prep.K, prep.Cout, _p(x), _p(prep.pk.buf),
-                  _p(prep.c1), _p(prep.c2), _p(stats), act, _p(y), _stream())
-    if _probe is not None:
-        e1.record()
-        es = x.element_size()
-        _probe.append((e0, e1, (rows * prep.K + rows * prep.Cout + prep.Cout * prep.K) * es + rows * 8,
-                       2 * rows * prep.Cout * prep.K, (rows, 1, 1, prep.K, prep.Cout, 1, 1, False)))
-    return y
 
 
 def dwconv2d(x, w_rsc, stride=1, padding=0, dilation=1, scale=None, shift=None, act=ACT_NONE, act_param=0.0, out_hw=None):

@@ -9,8 +9,8 @@ change of arithmetic):
   * Attention (:112-123) = qkv GEMM(+bias) -> one fused softmax(q k^T * scale) v kernel on the
     packed qkv matrix -> proj GEMM with bias and the residual add of Block.forward (:173) fused.
   * Mlp (:81-87) = fc1 GEMM with bias+exact-erf GELU epilogue -> fc2 GEMM with bias + residual (:174).
-  * norm1 / norm2 (:172-174) are folded into the qkv / fc1 GEMMs in fp16 mode (tlxmi_layernorm_linear: the kernel sums x and
-    x^2 of its own rows; W * gamma is packed once); fp32 parity mode keeps LayerNorm then Linear.
+  * norm1 / norm2 (:172-174) are LayerNorm launches of their own in front of the qkv / fc1 GEMMs (folding them into the GEMMs
+    was built in rounds 2 - 3, measured equal or slower in every form and removed in round 4: DESIGN 5.2).
   * final LayerNorm only on the cls rows (x[:, 0] commutes with a per-row norm, :327-328).
 """
 import numpy as np
@@ -61,8 +61,8 @@ class Mlp(nn.Module):
         self.drop = nn.Dropout(drop)
 
     def run(self, x, res=None, norm=None):
-        # bias + GELU in the GEMM epilogue; `norm` (Block.norm2) folded into the same GEMM
-        h = self.fc1.run_ln(x, norm, act=self.act.ACT) if norm is not None else self.fc1.run(x, act=self.act.ACT)
+        # `norm` (Block.norm2), then bias + GELU in the GEMM epilogue
+        h = self.fc1.run(norm(x) if norm is not None else x, act=self.act.ACT)
         return self.fc2.run(h, res=res, out=res)       # bias + residual, written in place
 
     def forward(self, x):
@@ -84,8 +84,8 @@ class Attention(nn.Module):
         self.proj_drop = nn.Dropout(proj_drop)
 
     def run(self, x, res=None, norm=None):
-        # (B, N, 3*C), packed [3][heads][hd]; `norm` (Block.norm1) folded into the qkv GEMM
-        qkv = self.qkv.run_ln(x, norm) if norm is not None else self.qkv.run(x)
+        # `norm` (Block.norm1), then (B, N, 3*C), packed [3][heads][hd]
+        qkv = self.qkv.run(norm(x) if norm is not None else x)
         a = E.attention(qkv, self.num_heads, self.scale)               # softmax(q k^T * scale) v, heads merged
         return self.proj.run(a, res=res, out=res)
 
@@ -115,8 +115,8 @@ class Block(nn.Module):
 
     def run_inplace(self, x):
         """x (B, N, C) engine dtype, updated in place: x += attn(norm1(x)); x += mlp(norm2(x))."""
-        self.attn.run(x, res=x, norm=self.norm1)       # norm1 -> qkv and norm2 -> fc1 folded into the GEMMs (fp16: the kernels
-        self.mlp.run(x, res=x, norm=self.norm2)        # gather the row statistics themselves, engine.linear_ln_supported)
+        self.attn.run(x, res=x, norm=self.norm1)
+        self.mlp.run(x, res=x, norm=self.norm2)
         return x
 
     def forward(self, x):

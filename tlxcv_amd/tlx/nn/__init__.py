@@ -667,18 +667,6 @@ class Linear(Module):
             x = x.to(dt)
         return E.linear(x, pk, b, res, act, out)
 
-    def run_ln(self, x, norm, act=E.ACT_NONE):
-        """act(self(norm(x))) with the LayerNorm `norm` folded into this Linear's GEMM (fp16 throughput mode;
-        otherwise, and for shapes the fused kernel does not take, LayerNorm then Linear as two launches)."""
-        dt = E.precision()
-        if x.dtype != dt:
-            x = x.to(dt)
-        if not E.linear_ln_supported(self.in_features, self.out_features, dt, x.numel() // x.shape[-1], x.device):
-            return self.run(norm(x), act=act)
-        prep = self._cached(("ln", id(norm)), lambda: E.LinearLN(self.weights.detach().t().contiguous(), self.biases,
-                                                                 norm.gamma, norm.beta, dt), deps=(norm,))
-        return E.linear_ln(x, prep, norm.epsilon, act)
-
     def forward(self, x):
         y = self.run(x)
         return self.act(y) if self.act is not None else y

@@ -1,5 +1,5 @@
 """ViT-B/16 block pieces at batch 256 (M = 50432), fp16, interleaved in one process (HIP events, median of rounds):
-LayerNorm, qkv / fc1 plain vs LayerNorm folded in (in-kernel statistics / statistics pass), proj, fc2, attention."""
+LayerNorm, qkv, fc1, proj, fc2, attention."""
 import os
 import sys
 
@@ -22,7 +22,7 @@ gamma, beta = (torch.rand(D, generator=g) + 0.5).to(dev), (torch.randn(D, genera
 def lin(cin, cout):
     w = (torch.randn((cout, cin), generator=g) * cin ** -0.5).to(dev)
     b = (torch.randn(cout, generator=g) * 0.1).to(dev)
-    return w, b, E.PackedFilter(w, torch.float16), (E.LinearLN(w, b, gamma, beta, torch.float16) if cin == D else None)
+    return w, b, E.PackedFilter(w, torch.float16), None
 
 
 wq, bq, pkq, lnq = lin(D, 3 * D)
@@ -34,11 +34,7 @@ qkv = torch.randn((B, 197, 3 * D), generator=g).half().to(dev)
 cases = {
     "layernorm": lambda: E.layernorm(x, gamma, beta, 1e-6),
     "qkv plain": lambda: E.linear(x, pkq, bq),
-    "qkv ln in-kernel": lambda: E.linear_ln(x, lnq, 1e-6, E.ACT_NONE, in_kernel=True),
-    "qkv ln stats-pass": lambda: E.linear_ln(x, lnq, 1e-6, E.ACT_NONE, in_kernel=False),
     "fc1 plain (gelu)": lambda: E.linear(x, pk1, b1, act=E.ACT_GELU),
-    "fc1 ln in-kernel": lambda: E.linear_ln(x, ln1, 1e-6, E.ACT_GELU, in_kernel=True),
-    "fc1 ln stats-pass": lambda: E.linear_ln(x, ln1, 1e-6, E.ACT_GELU, in_kernel=False),
     "proj + res": lambda: E.linear(x, pkp, bp, res=res, out=res),
     "fc2 + res": lambda: E.linear(h, pk2, b2, res=res, out=res),
     "attention": lambda: E.attention(qkv, 12, 0.125),
