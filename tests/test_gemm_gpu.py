@@ -97,6 +97,39 @@ def test_many_tiles_per_workgroup(dev, force_tile, tile):
     run_linear(dev, torch.float16, 50432, 768, 768, res=True, seed=5)
 
 
+@pytest.mark.parametrize("plan", [None, "half"], ids=["device", "half_device"])
+@pytest.mark.parametrize("case", [(50432, 768, 768, True, E.ACT_NONE), (25216, 768, 768, True, E.ACT_NONE), (25216, 3072, 768, True, E.ACT_NONE),
+                                  (25216 + 77, 768, 2304, False, E.ACT_NONE), (12544, 512, 512, True, E.ACT_NONE),
+                                  (12544, 2048, 512, False, E.ACT_RELU), (197 * 3 + 5, 768, 768, True, E.ACT_NONE)],
+                         ids=lambda c: "x".join(map(str, c[:3])) + ("+res" if c[3] else ""))
+def test_balanced_tail_on_half_height_tiles_in_the_stream(dev, force_tile, case, plan):
+    """gemm_stream.hip's own tail: a last round at most half full (ViT-B/16 proj / fc2: 591 tiles on 256 CUs, 297 on the 128 a
+    two-stream forward plans for) and launches of fewer tiles than half the CUs (Swin-B stage 3) run their last rows as
+    half-height tiles inside the persistent kernel — against the oracle, with a residual (whose H = 1 steps must read nothing),
+    ragged last rows, and equal to the same launch with the half-height tiles switched off (bit for bit without a residual: same K
+    order per output)."""
+    from tlxcv_amd._lib import tuning
+    M, K, Cout, res, act = case
+    force_tile(8)
+    with E.shared_plan(plan):
+        run_linear(dev, torch.float16, M, K, Cout, res=res, act=act, seed=M % 97)
+        rng = np.random.default_rng(3)
+        x = q16(rnd(rng, (M, K))).half().to(dev)
+        pk = E.PackedFilter(q16(rnd(rng, (Cout, K), (1.0 / K) ** 0.5)).to(dev), torch.float16)
+        b = rnd(rng, (Cout,), 0.2).to(dev)
+        r = q16(rnd(rng, (M, Cout))).half().to(dev) if res else None
+        y1 = E.linear(x, pk, b, res=r, act=act)
+        with tuning(TLXMI_TILE="8", TLXMI_HALFTAIL="0"):
+            y0 = E.linear(x, pk, b, res=r, act=act)
+        torch.cuda.synchronize()
+        if not res:
+            assert torch.equal(y0, y1)
+        else:      # a row's residual enters its fp32 sum at another K tile when the row moves from the H = 1 half of a whole tile
+            torch.testing.assert_close(y0.float(), y1.float(), atol=2e-3, rtol=2e-3)      # to a half-height one: last-bit differences
+            assert (y0 != y1).float().mean().item() < 0.02
+        assert torch.equal(E.linear(x, pk, b, res=r, act=act), y1)      # and the launch itself is reproducible
+
+
 def test_auto_dispatch_tail_on_half_height_tiles(dev, force_tile):
     # 197 x 3 tiles = 2 rounds + 79: 170 row tiles go to the 256 x 256 kernel, the last 6912 rows to the same
     # antiphase kernel on 128 x 256 tiles (gemm_pp128), with bias + residual

@@ -732,7 +732,10 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
         const long slots = (long)cus * per_cu;
         const long rounds = (blocks + slots - 1) / slots;
         float quant = (float)blocks / (float)(rounds * slots);
-        if ((i == 7 || i == 8) && tail_split) quant = (float)blocks / (((float)full_rounds + 0.6f) * slots);   // the tail round: ~0.6 of a tile time
+        if (i == 7 && tail_split) quant = (float)blocks / (((float)full_rounds + 0.6f) * slots);   // the tail round: ~0.6 of a tile time
+        // the persistent kernel balances its own tail (gemm_stream.hip: a last round at most half full, or fewer tiles than half
+        // the CUs, runs as half-height tiles at ~0.7 of a tile time), shared device or not
+        if (i == 8 && blocks % slots != 0 && 2 * (blocks % slots) <= slots) quant = (float)blocks / (((float)(blocks / slots) + 0.7f) * slots);
         // a two-stream forward planned for the whole device: the CUs a persistent launch leaves idle serve the other stream, and
         // on long K loops the K-tile stream beats half-height tiles even when it fills under half a round — Swin-B stage 3 at
         // half batch 64, qkv 12544 x 512 -> 1536 and fc2 2048 -> 512: forward 7.88 -> 7.67 ms (tools/tile_search.py on the graph
@@ -808,7 +811,7 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
             }
         }
     }
-    if ((best == 7 || best == 8) && tail_split) {
+    if (best == 7 && tail_split) {
         // rows of the full rounds (whole M tiles) -> this candidate; the rest -> best small-tile candidate
         const int nt = (a.Cout + 255) / 256;
         const int m_split = (int)((full_rounds * cus) / nt) * 256;

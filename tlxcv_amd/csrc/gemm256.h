@@ -19,6 +19,9 @@ struct Gemm256Args {
     float act_param;
     unsigned flags;
     int mtiles, ntiles;
+    // gemm_stream.hip only: tiles [0, tiles_full) are 256-row tiles of rows [0, m_full), tiles [tiles_full, tiles_total) are
+    // HALF-HEIGHT tiles (128 rows, the H = 1 phases idle) of rows [m_full, M) — the rows of a short last round (launch_gs)
+    int tiles_full = 0, tiles_total = 0, m_full = 0;
     int gn;        // N-tiles per column panel of the tile walk
     unsigned x_bytes, w_bytes, y_bytes, res_bytes;
     int debug;     // tuning builds only

@@ -22,6 +22,14 @@
 //     constant block), accumulators are not zeroed (the first MFMA of a tile takes C = 0).
 // Layout of a K tile in LDS, wave->quadrant map, fragment reads, channel permutation: gemm_pp.hip.
 //
+// Balanced tail (round 4).  One workgroup per CU: when the tiles are r whole rounds plus a last round that is at most half
+// full, that round costs a whole tile time for a fraction of the CUs (ViT-B/16 at batch 256: proj / fc2 are 2.32 rounds paid
+// as 3; measured on the forward: batch 220, whole rounds, runs 5.7 % more images per second than batch 256).  The rows of
+// the short round are then cut into HALF-HEIGHT tiles (128 rows) at the end of every workgroup's tile list: twice as many
+// workgroups get one, and such a tile runs the same K-tile stream with its H = 1 phases idle — no X1 traffic (out-of-range
+// DMA offsets), no MFMAs, the (1, *) epilogues reduced to their dropped stores — so every vector-memory count and every
+// barrier stays where it is.  No partial sums, no cross-workgroup exchange: results are bit-identical to the full tiles'.
+//
 // In-order VMEM sequence of one wave around a tile boundary (L = last K tile of a tile; D = 2 DMA pieces,
 // S = the stores of a quadrant (32 outputs per lane: 4 x 16 B for fp16, 8 for fp32), T = 2 table pieces), and the counted waits.
 // Round 4: a quadrant's epilogue (arithmetic + its S stores) runs INSIDE the MFMA segment that follows the one that finished
@@ -102,18 +110,21 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
     const int t = threadIdx.x, lane = t & 63;
     const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wr = wid >> 2, wc = wid & 3;
-    const int nb = a.mtiles * a.ntiles;
+    const int nb = a.tiles_total;
     const int n_mine = ((int)blockIdx.x < nb) ? (nb - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
 
     // i-th tile of this workgroup -> origin.  Virtual block id = blockIdx + i*grid (grid is a multiple of 8,
     // so the id keeps its XCD); ids sharing an XCD walk consecutive tiles, N tiles fastest.
-    auto tile_origin = [&](int i, int& bm0, int& bn0) -> bool {
+    auto tile_origin = [&](int i, int& bm0, int& bn0, bool& half) -> bool {
+        half = false;
         if (i >= n_mine) return false;
         const int id = (int)blockIdx.x + i * (int)gridDim.x;
-        const int xcd = id & 7, qd = nb >> 3, rm = nb & 7;
-        const int L = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (id >> 3);
+        half = id >= a.tiles_full;
+        const int n = half ? nb - a.tiles_full : a.tiles_full, j = half ? id - a.tiles_full : id;      // walk each kind's list
+        const int xcd = j & 7, qd = n >> 3, rm = n & 7;
+        const int L = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (j >> 3);
         const int tm = L / a.ntiles;
-        bm0 = tm * 256;
+        bm0 = half ? a.m_full + tm * 128 : tm * 256;
         bn0 = (L - tm * a.ntiles) * 256;
         return true;
     };
@@ -134,10 +145,11 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
     const int x64 = 64 * a.x_ld * ES, w64 = 64 * a.Kp_bytes;
     auto set_rows = [&](int i, int half, int& xo, int& wo) {
         int bm0 = 0, bn0 = 0;
-        const bool ok = tile_origin(i, bm0, bn0);
+        bool th;
+        const bool ok = tile_origin(i, bm0, bn0, th);
         const int row = 128 * half + 8 * wid + lrow;
         const int n = (row & ~31) | (((row >> 2) & 3) << 3) | (((row >> 4) & 1) << 2) | (row & 3);
-        xo = ok ? (bm0 + row) * a.x_ld * ES : OOB;
+        xo = (ok && !(th && half)) ? (bm0 + row) * a.x_ld * ES : OOB;      // a half-height tile has no X1
         wo = ok ? (bn0 + n) * a.Kp_bytes : OOB;
     };
     char* const lbase = smem + wid * 1024;
@@ -159,7 +171,8 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
     // scale / shift table of tile i -> table (i & 1): wave w brings channels 32w..32w+31, [shift 32][scale 32]
     auto dma_table = [&](int i) {
         int bm0 = 0, bn0 = 0;
-        const bool ok = tile_origin(i, bm0, bn0);
+        bool th;
+        const bool ok = tile_origin(i, bm0, bn0, th);
         char* dst = smem + TABLE + (i & 1) * 2048 + wid * 256;
         const int lane = lane_now();
         if (lane < 8) {
@@ -190,6 +203,12 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
             wf[ci][0] = *reinterpret_cast<const u32x4*>(kb + region + ci * 2048 + wf0);
             wf[ci][1] = *reinterpret_cast<const u32x4*>(kb + region + ci * 2048 + (wf0 ^ 64));
         }
+    };
+
+    // the S stores of a quadrant that does not exist (H = 1 of a half-height tile), dropped by the range check: the counts stay
+    auto dead_stores = [&]() {
+#pragma unroll
+        for (int q = 0; q < S; ++q) gs_store16_wb(ysrd, u32x4{0u, 0u, 0u, 0u}, OOB);
     };
 
     // ---- quadrant epilogue: lane (fg, px) owns channels 128g + 32wc + 8fg .. +7 of pixel rows
@@ -259,7 +278,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
     };
     // Residual step r = 0..7 covers quadrant (r>>1) in the phase order (0,0) (0,1) (1,1) (1,0), pixel sub-tiles
     // 2*(r&1), 2*(r&1)+1: R loads now, added into the accumulators one K tile later.
-    auto res_load = [&](auto r_tag, int bm0, int bn0) {
+    auto res_load = [&](auto r_tag, int bm0, int bn0, bool thalf) {
         constexpr int RS = decltype(r_tag)::value, Q = RS >> 1, H = (Q >> 1), G = (Q == 1 || Q == 2) ? 1 : 0, P0 = 2 * (RS & 1);
         const int ln = lane_now();
         const int px = ln & 15, fg = ln >> 4;
@@ -267,7 +286,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const int m = bm0 + 128 * H + 64 * wr + 16 * (P0 + p) + px;
-            const int okm = ((m - a.M) & (ch0 - a.Cout)) >> 31;
+            const int okm = (H == 1 && thalf) ? 0 : (((m - a.M) & (ch0 - a.Cout)) >> 31);      // (H = 1 of a half-height tile: zeros)
             const int ro = (((m * a.res_ld + ch0) * ES) & okm) | (OOB & ~okm);
 #pragma unroll
             for (int hh = 0; hh < ES / 2; ++hh) rr[p * (ES / 2) + hh] = gs_load16(rsrd, ro + 16 * hh);
@@ -351,9 +370,13 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
     if (wr == 1) { GS_SYNC(); }   // group 1 runs one barrier behind
 
     int bm0 = 0, bn0 = 0, pbm0 = 0, pbn0 = 0;
+    bool hcur = false;      // the tile being multiplied is half-height
 
-    auto ktile = [&](auto mode_tag, int i) {
+    // HF: the tile is half-height (compile time: a run-time test around the MFMA blocks makes the register allocator split the
+    // accumulators' live ranges at every join — 80 - 120 spilled registers; a half-height tile is always a workgroup's last)
+    auto ktile = [&](auto mode_tag, auto half_tag, int i) {
         constexpr int MODE = decltype(mode_tag)::value;
+        constexpr bool HF = decltype(half_tag)::value != 0;
         constexpr bool K0 = MODE == GS_K0_FIRST || MODE == GS_K0_AFTER;
         constexpr bool RI = MODE >= GS_R0 && MODE < GS_RC;   // issues residual loads
         constexpr int RQ = RI ? R : 0;
@@ -364,12 +387,12 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
         if constexpr (MODE > GS_R0 && MODE <= GS_RC) res_add(IntTag<MODE - GS_R0 - 1>{});
         if constexpr (RI) {
             __builtin_amdgcn_sched_barrier(0);   // the new loads re-use the registers just consumed
-            res_load(IntTag<MODE - GS_R0>{}, bm0, bn0);
+            res_load(IntTag<MODE - GS_R0>{}, bm0, bn0, HF);
         }
         dma_w(RW1, para, wa, kta);
         gs_vmcnt<(MODE == GS_K0_AFTER ? 8 + 3 * S + TT : 8 + RQ)>();
         GS_SYNC();
-        if constexpr (MODE == GS_K0_AFTER) { GS_MMA_E(0, 0, w0f, K0, epi(IntTag<1>{}, IntTag<0>{}, pbm0, pbn0, (i - 1) & 1, true)); }
+        if constexpr (MODE == GS_K0_AFTER) { GS_MMA_E(0, 0, w0f, K0, epi(IntTag<1>{}, IntTag<0>{}, pbm0, pbn0, (i - 1) & 1, true)); }      // (the tile before is never half-height)
         else { GS_MMA(0, 0, w0f, K0); }
         GS_SYNC();
         // ---- p1: quadrant (0,1)
@@ -381,49 +404,74 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
         if constexpr (MODE == GS_LAST) { GS_MMA_E(0, 1, w1f, K0, epi(IntTag<0>{}, IntTag<0>{}, bm0, bn0, i & 1, true)); }
         else { GS_MMA(0, 1, w1f, K0); }
         GS_SYNC();
-        // ---- p2: quadrant (1,1)
-        read_x(kb, RX1);
+        // ---- p2: quadrant (1,1) — idle in a half-height tile (its MFMA segment still carries the epilogue of (0,1))
+        if constexpr (!HF) read_x(kb, RX1);
         dma_x(RX0, parb, xb, ktb);
         if constexpr (MODE == GS_LAST) dma_table(i + 1);
         GS_SYNC();
-        if constexpr (MODE == GS_LAST) { GS_MMA_E(1, 1, w1f, K0, epi(IntTag<0>{}, IntTag<1>{}, bm0, bn0, i & 1, true)); }
-        else { GS_MMA(1, 1, w1f, K0); }
+        if constexpr (!HF) {
+            if constexpr (MODE == GS_LAST) { GS_MMA_E(1, 1, w1f, K0, epi(IntTag<0>{}, IntTag<1>{}, bm0, bn0, i & 1, true)); }
+            else { GS_MMA(1, 1, w1f, K0); }
+        } else {
+            if constexpr (MODE == GS_LAST) epi(IntTag<0>{}, IntTag<1>{}, bm0, bn0, i & 1, true);
+        }
         GS_SYNC();
         // ---- p3: quadrant (1,0)
         dma_w(RW0, parb, wb, ktb);
         adv_b();
         gs_vmcnt<(MODE == GS_K0_AFTER ? 8 + 2 * S : MODE == GS_LAST ? 8 + 2 * S + TT : 8 + RQ)>();
         GS_SYNC();
-        if constexpr (MODE == GS_LAST) { GS_MMA_E(1, 0, w0f, K0, epi(IntTag<1>{}, IntTag<1>{}, bm0, bn0, i & 1, true)); }
-        else { GS_MMA(1, 0, w0f, K0); }
+        if constexpr (!HF) {
+            if constexpr (MODE == GS_LAST) { GS_MMA_E(1, 0, w0f, K0, epi(IntTag<1>{}, IntTag<1>{}, bm0, bn0, i & 1, true)); }
+            else { GS_MMA(1, 0, w0f, K0); }
+        } else {
+            if constexpr (MODE == GS_LAST) dead_stores();
+        }
         GS_SYNC();
         cpar ^= 1;
     };
 
-    for (int i = 0; i < n_mine; ++i) {
-        pbm0 = bm0;
-        pbn0 = bn0;
-        tile_origin(i, bm0, bn0);
-        if (i == 0) ktile(IntTag<GS_K0_FIRST>{}, i);
-        else ktile(IntTag<GS_K0_AFTER>{}, i);
+    auto tile = [&](auto half_tag, int i) {
+        if (i == 0) ktile(IntTag<GS_K0_FIRST>{}, half_tag, i);
+        else ktile(IntTag<GS_K0_AFTER>{}, half_tag, i);
         int kt = 1;
         if constexpr (RES) {
-            ktile(IntTag<GS_R0>{}, i);
-            ktile(IntTag<GS_R0 + 1>{}, i);
-            ktile(IntTag<GS_R0 + 2>{}, i);
-            ktile(IntTag<GS_R0 + 3>{}, i);
-            ktile(IntTag<GS_R0 + 4>{}, i);
-            ktile(IntTag<GS_R0 + 5>{}, i);
-            ktile(IntTag<GS_R0 + 6>{}, i);
-            ktile(IntTag<GS_R0 + 7>{}, i);
-            ktile(IntTag<GS_RC>{}, i);
+            ktile(IntTag<GS_R0>{}, half_tag, i);
+            ktile(IntTag<GS_R0 + 1>{}, half_tag, i);
+            ktile(IntTag<GS_R0 + 2>{}, half_tag, i);
+            ktile(IntTag<GS_R0 + 3>{}, half_tag, i);
+            ktile(IntTag<GS_R0 + 4>{}, half_tag, i);
+            ktile(IntTag<GS_R0 + 5>{}, half_tag, i);
+            ktile(IntTag<GS_R0 + 6>{}, half_tag, i);
+            ktile(IntTag<GS_R0 + 7>{}, half_tag, i);
+            ktile(IntTag<GS_RC>{}, half_tag, i);
             kt = 10;
         }
-        for (; kt < ks - 1; ++kt) ktile(IntTag<GS_INTERIOR>{}, i);
-        ktile(IntTag<GS_LAST>{}, i);
+        for (; kt < ks - 1; ++kt) ktile(IntTag<GS_INTERIOR>{}, half_tag, i);
+        ktile(IntTag<GS_LAST>{}, half_tag, i);
+    };
+    // this workgroup's tiles: n_full whole tiles, then at most one half-height tile (its last: launch_gs) — run behind the loop,
+    // not inside it, so that the two code paths meet at no loop-carried join
+    bool last_half = false;
+    {
+        int b0, b1;
+        if (n_mine > 0) tile_origin(n_mine - 1, b0, b1, last_half);
+    }
+    const int n_full = n_mine - (last_half ? 1 : 0);
+    for (int i = 0; i < n_full; ++i) {
+        pbm0 = bm0;
+        pbn0 = bn0;
+        tile_origin(i, bm0, bn0, hcur);
+        tile(IntTag<0>{}, i);
+    }
+    if (last_half) {
+        pbm0 = bm0;
+        pbn0 = bn0;
+        tile_origin(n_full, bm0, bn0, hcur);
+        tile(IntTag<1>{}, n_full);
     }
     if (wr == 0) { GS_SYNC(); }   // barrier counts match again
-    if (n_mine > 0) epi(IntTag<1>{}, IntTag<0>{}, bm0, bn0, (n_mine - 1) & 1, true);
+    if (n_mine > 0 && !hcur) epi(IntTag<1>{}, IntTag<0>{}, bm0, bn0, (n_mine - 1) & 1, true);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // zero-fill DMAs of the stream's tail
 #undef GS_MMA
 #undef GS_MMA_E
@@ -441,10 +489,29 @@ template <typename T, int ACT, bool RES> static int launch_gs(const Gemm256Args&
     const size_t lds = (size_t)8 * 128 * 128 + 2 * 2048;   // two K tiles, channel tables
     const void* fn = reinterpret_cast<const void*>(&gemm_stream_kernel<T, ACT, RES>);
     if (int rc = raise_lds_limit(fn, (int)lds, "gemm_stream")) return rc;
+    int maxgrid = cus & ~7;         // one workgroup per CU; a multiple of 8 keeps a virtual block on its XCD
+    if (maxgrid < 8) maxgrid = 8;
     const int tiles = a.mtiles * a.ntiles;
-    int grid = cus & ~7;            // one workgroup per CU; a multiple of 8 keeps a virtual block on its XCD
-    if (grid < 8) grid = 8;
-    if (grid > tiles) grid = tiles; // fewer tiles than CUs: one tile each (ids < tiles, mapping still bijective)
+    int grid = maxgrid < tiles ? maxgrid : tiles;   // fewer tiles than CUs: one tile each (ids < tiles, mapping still bijective)
+    a.tiles_full = a.tiles_total = tiles;
+    a.m_full = a.mtiles * 256;
+    // Balanced tail (file header): r whole rounds + a last round at most half full -> the rows behind the whole row tiles of
+    // the r rounds become half-height tiles; fewer tiles than half the CUs -> every tile is half-height.  Taken when the
+    // half-height tiles are at most one per workgroup (consecutive ids behind the full tiles: it is then that workgroup's LAST tile,
+    // which is what the kernel's compile-time half-height path relies on).
+    {
+        const int r = tiles / maxgrid, rem = tiles % maxgrid;
+        const int mt_full = r == 0 ? 0 : (r * maxgrid) / a.ntiles;
+        const int halves = ((a.M - mt_full * 256 + 127) / 128) * a.ntiles;
+        const bool tail = r >= 1 && rem != 0 && 2 * rem <= maxgrid && halves <= maxgrid;      // (<= one per workgroup, its last tile)
+        const bool small = tune_int("TLXMI_HALFTAIL", 1) == 2 && r == 0 && halves <= maxgrid && halves > tiles;      // (measured: a loss on Swin-B — every half-height tile re-reads its whole filter panel; tuning flavour only)
+        if ((tail || small) && tune_int("TLXMI_HALFTAIL", 1)) {
+            a.tiles_full = mt_full * a.ntiles;
+            a.m_full = mt_full * 256;
+            a.tiles_total = a.tiles_full + halves;
+            grid = maxgrid < a.tiles_total ? maxgrid : a.tiles_total;
+        }
+    }
     void* args[] = {&a};
     hipError_t e = hipLaunchKernel(fn, dim3((unsigned)grid), dim3(512), args, lds, st);
     if (e != hipSuccess) return fail(TLXMI_ERR_LAUNCH, "gemm_stream: HIP launch failed: %s", hipGetErrorString(e));
