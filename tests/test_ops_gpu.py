@@ -339,3 +339,20 @@ def test_scale_channels(dev, dtype, shape):
     got = E.scale_channels(nchw_to_engine(x, dtype, dev), sc.to(dtype).to(dev))
     torch.cuda.synchronize()
     torch.testing.assert_close(engine_to_nchw(got), x * sc[:, :, None, None], **tol(dtype))
+
+
+def test_swin_module_level_window_helpers_match_the_reference_definitions(dev):
+    """swin_transformer.py:85-116: window_partition / window_reverse as module-level functions with the reference's signatures
+    (a drop-in import can name them), against the reshape / transpose definitions, both precisions; drop_path is the identity
+    in eval mode (:35-47)."""
+    from tlxcv_amd.models.classification import swin_transformer as S
+    rng = np.random.default_rng(5)
+    for dtype in (torch.float16, torch.float32):
+        B, H, W, Cc, ws = 3, 14, 21, 32, 7
+        x = torch.from_numpy(rng.standard_normal((B, H, W, Cc)).astype(np.float32)).to(dtype)
+        ref = x.reshape(B, H // ws, ws, W // ws, ws, Cc).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws, ws, Cc)
+        win = S.window_partition(x.to(dev), ws)
+        assert win.shape == ref.shape and torch.equal(win.cpu(), ref)
+        back = S.window_reverse(win, ws, H, W, Cc)
+        assert back.shape == x.shape and torch.equal(back.cpu(), x)
+    assert S.drop_path(x, 0.3, False) is x and S.DropPath(0.2).set_eval()(x) is x

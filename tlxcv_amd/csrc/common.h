@@ -41,13 +41,14 @@ inline long tune_int(const char* name, long dflt) {
 // before they leave.  Round 3 measured it again on the hipGraph replay of the whole two-stream forwards: write-back instead
 // of non-temporal for gemm_pp (plain GEMM), gemm256 and gemm_stream: Swin-B 7.86 -> 7.64 ms, ResNet-50 3.51 -> 3.48, ViT-B/16
 // 11.35 -> 11.30 (the round-1 per-layer sweep that chose non-temporal timed each launch alone, re-writing one buffer).
-// A/B (tuning flavour): TLXMI_DEBUG bit 0x4000 flips gemm_pp (plain GEMM) / gemm256 to non-temporal, bit 4 gemm_stream,
+// A/B (tuning flavour): TLXMI_NT_STORES = TLXMI_DEBUG bit 0x4000 flips gemm_pp (plain GEMM) / gemm256 to NON-TEMPORAL stores (the
+// macro is named for what the set bit selects; the product compiles it to false = write-back), bit 4 does the same for gemm_stream,
 // bit 0x8000 conv_halo.
-#define TLXMI_WB_STORES(args) (((args).debug & 0x4000) != 0)
+#define TLXMI_NT_STORES(args) (((args).debug & 0x4000) != 0)
 #else
 constexpr long tune_int(const char*, long dflt) { return dflt; }
 #define TLXMI_DBG(args, bit) (false)
-#define TLXMI_WB_STORES(args) (false)
+#define TLXMI_NT_STORES(args) (false)
 #endif
 
 // ---- device-side vector types -------------------------------------------------------------

@@ -1135,7 +1135,8 @@ extern "C" int tlxmi_group_conv2d(const tlxmi_conv2d_desc* d, int groups, const 
     // 8 per group 28 x 28 89 -> 61 and stride 2 from 56 x 56 140 -> 113, 16 per group 14 x 14 51 -> 49; it loses at 16 per group
     // with stride 2 (66 -> 80) and at 32 per group (38 -> 72, 35 -> 58: two real products in four there, and 7 x 7 tiles are
     // all prologue), which stay on the block-diagonal path.  TLXMI_GCONV (tuning flavour): bit (log2(cg / 4) + 4 * (stride - 1)).
-    if (gconv_small_ok(d, groups, res) && nchunk == d->C / 64 && aligned16(x) && aligned16(w_packed) && ((uintptr_t)y & 7u) == 0) {
+    if (gconv_small_ok(d, groups, res) && nchunk == d->C / 64 && aligned16(x) && aligned16(w_packed) && ((uintptr_t)y & 7u) == 0 &&
+        aligned16(scale) && aligned16(shift)) {      // (group_conv.hip fetches scale / shift as 16-byte vectors; otherwise the general path)
         const int qi = cgi == 4 ? 0 : cgi == 8 ? 1 : cgi == 16 ? 2 : 3;
         if ((tune_int("TLXMI_GCONV", 0x37) >> (qi + 4 * (d->stride_h - 1))) & 1)
             return launch_gconv_small(d, groups, x, w_packed, scale, shift, y, kpad_elems_of(d->C / nchunk, d->R, d->S, d->dtype) * 2, as_stream(stream));

@@ -232,15 +232,15 @@ __global__ __launch_bounds__(WGN * 128, 2) void gemm256_kernel(const Gemm256Args
                 half8v h;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) h[e] = (half_t)v[e];
-                if (!TLXMI_WB_STORES(a)) buf_store16_wb(ysrd, __builtin_bit_cast(u32x4, h), yo);
+                if (!TLXMI_NT_STORES(a)) buf_store16_wb(ysrd, __builtin_bit_cast(u32x4, h), yo);
                 else buf_store16_nt(ysrd, __builtin_bit_cast(u32x4, h), yo);
             } else {
                 f32x4 f0, f1;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { f0[e] = v[e]; f1[e] = v[4 + e]; }
-                if (!TLXMI_WB_STORES(a)) buf_store16_wb(ysrd, __builtin_bit_cast(u32x4, f0), yo);
+                if (!TLXMI_NT_STORES(a)) buf_store16_wb(ysrd, __builtin_bit_cast(u32x4, f0), yo);
                 else buf_store16_nt(ysrd, __builtin_bit_cast(u32x4, f0), yo);
-                if (!TLXMI_WB_STORES(a)) buf_store16_wb(ysrd, __builtin_bit_cast(u32x4, f1), yo + 16);
+                if (!TLXMI_NT_STORES(a)) buf_store16_wb(ysrd, __builtin_bit_cast(u32x4, f1), yo + 16);
                 else buf_store16_nt(ysrd, __builtin_bit_cast(u32x4, f1), yo + 16);
             }
         }

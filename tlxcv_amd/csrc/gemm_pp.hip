@@ -424,15 +424,15 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
                         half8v hv;
 #pragma unroll
                         for (int e = 0; e < 8; ++e) hv[e] = (half_t)v[e];
-                        if (CONV || !TLXMI_WB_STORES(a)) pp_store16_wb(ysrd, __builtin_bit_cast(u32x4, hv), yo);
+                        if (CONV || !TLXMI_NT_STORES(a)) pp_store16_wb(ysrd, __builtin_bit_cast(u32x4, hv), yo);
                         else pp_store16_nt(ysrd, __builtin_bit_cast(u32x4, hv), yo);
                     } else {
                         f32x4 f0, f1;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { f0[e] = v[e]; f1[e] = v[4 + e]; }
-                        if (CONV || !TLXMI_WB_STORES(a)) pp_store16_wb(ysrd, __builtin_bit_cast(u32x4, f0), yo);
+                        if (CONV || !TLXMI_NT_STORES(a)) pp_store16_wb(ysrd, __builtin_bit_cast(u32x4, f0), yo);
                         else pp_store16_nt(ysrd, __builtin_bit_cast(u32x4, f0), yo);
-                        if (CONV || !TLXMI_WB_STORES(a)) pp_store16_wb(ysrd, __builtin_bit_cast(u32x4, f1), yo + 16);
+                        if (CONV || !TLXMI_NT_STORES(a)) pp_store16_wb(ysrd, __builtin_bit_cast(u32x4, f1), yo + 16);
                         else pp_store16_nt(ysrd, __builtin_bit_cast(u32x4, f1), yo + 16);
                     }
                 }

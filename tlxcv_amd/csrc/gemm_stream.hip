@@ -149,7 +149,8 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
         const bool ok = tile_origin(i, bm0, bn0, th);
         const int row = 128 * half + 8 * wid + lrow;
         const int n = (row & ~31) | (((row >> 2) & 3) << 3) | (((row >> 4) & 1) << 2) | (row & 3);
-        xo = (ok && !(th && half)) ? (bm0 + row) * a.x_ld * ES : OOB;      // a half-height tile has no X1
+        const int xrow = TLXMI_DBG(a, 8) ? ((bm0 + row) & 2047) : bm0 + row;      // (ablation bit 8: every X row from the first 2048 — L2-resident operand, timing only)
+        xo = (ok && !(th && half)) ? xrow * a.x_ld * ES : OOB;      // a half-height tile has no X1
         wo = ok ? (bn0 + n) * a.Kp_bytes : OOB;
     };
     char* const lbase = smem + wid * 1024;
@@ -260,7 +261,11 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
                 for (int e = 0; e < 8; ++e) v[e] = apply_act_t<ACT>(v[e], a.act_param);
             }
             const int okm = chm & ((m - a.M) >> 31);
-            const int yo = (((m * a.y_ld + ch0) * ES) & okm) | (OOB & ~okm);   // out-of-range stores are dropped
+            int yo = (((m * a.y_ld + ch0) * ES) & okm) | (OOB & ~okm);   // out-of-range stores are dropped
+            if TLXMI_DBG(a, 16) {   // ablation (wrong data, right byte count): this store instruction writes 8 whole 128-byte lines
+                const int mm = bm0 + 128 * H + 64 * wr + 16 * pi + 8 * (col >> 7) + (ln >> 3), cc = bn0 + (128 * (G ^ (col >> 7)) + 64 * (wc >> 1) + 8 * (ln & 7));
+                yo = (mm < a.M && cc < a.Cout && live) ? (mm * a.y_ld + cc) * ES : OOB;
+            }
             if constexpr (ES == 2) {
                 half8v hv;
 #pragma unroll

@@ -275,7 +275,8 @@ extern "C" int tlxmi_layernorm(const void* x, const float* gamma, const float* b
     TLXMI_REQUIRE(x && y && rows > 0 && C > 0, TLXMI_ERR_BAD_ARG, "layernorm: bad argument");
     TLXMI_REQUIRE(dt == TLXMI_F16 || dt == TLXMI_F32, TLXMI_ERR_BAD_ARG, "layernorm: bad dtype");
     const int V = 16 / (int)elt_size(dt);
-    TLXMI_REQUIRE(C % V == 0 && x_ld % V == 0 && y_ld % V == 0 && x_ld >= C && y_ld >= C && aligned16(x) && aligned16(y),
+    TLXMI_REQUIRE(C % V == 0 && x_ld % V == 0 && y_ld % V == 0 && x_ld >= C && y_ld >= C && aligned16(x) && aligned16(y) &&
+                      aligned16(gamma) && aligned16(beta),      // gamma / beta are fetched as whole 16-byte vectors
                   TLXMI_ERR_ALIGNMENT, "layernorm: C=%d / strides must be whole 16-byte chunks", C);
     if (dt == TLXMI_F16) return launch_ln<half_t>(x, gamma, beta, y, (long)rows, C, x_ld, y_ld, eps, as_stream(stream));
     return launch_ln<float>(x, gamma, beta, y, (long)rows, C, x_ld, y_ld, eps, as_stream(stream));
@@ -298,7 +299,7 @@ static int check_ln_window(const char* name, int dt, int B, int H, int W, int C,
 
 extern "C" int tlxmi_layernorm_window_partition(const void* x, const float* gamma, const float* beta, void* win, int dt,
                                                 int B, int H, int W, int C, int ws, int shift, float eps, void* stream) {
-    TLXMI_REQUIRE(x && win && aligned16(x) && aligned16(win), TLXMI_ERR_BAD_ARG, "layernorm_window_partition: bad buffer");
+    TLXMI_REQUIRE(x && win && aligned16(x) && aligned16(win) && aligned16(gamma) && aligned16(beta), TLXMI_ERR_BAD_ARG, "layernorm_window_partition: bad buffer");
     if (int e = check_ln_window("layernorm_window_partition", dt, B, H, W, C, ws, shift)) return e;
     const WinMap wm{1, H, W, ws, shift};
     const long rows = (long)B * H * W;
@@ -309,7 +310,7 @@ extern "C" int tlxmi_layernorm_window_partition(const void* x, const float* gamm
 extern "C" int tlxmi_window_reverse_layernorm(const void* win, const void* res, const float* gamma, const float* beta,
                                               void* sum, void* y, int dt, int B, int H, int W, int C, int ws, int shift,
                                               float eps, void* stream) {
-    TLXMI_REQUIRE(win && res && sum && y && aligned16(win) && aligned16(res) && aligned16(sum) && aligned16(y), TLXMI_ERR_BAD_ARG,
+    TLXMI_REQUIRE(win && res && sum && y && aligned16(win) && aligned16(res) && aligned16(sum) && aligned16(y) && aligned16(gamma) && aligned16(beta), TLXMI_ERR_BAD_ARG,
                   "window_reverse_layernorm: bad buffer");
     if (int e = check_ln_window("window_reverse_layernorm", dt, B, H, W, C, ws, shift)) return e;
     const WinMap wm{2, H, W, ws, shift};

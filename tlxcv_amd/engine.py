@@ -117,7 +117,6 @@ def to_model_device(inputs, model):
 # hipGraph replay, ResNet-50 batch 256 3.77 -> 3.52 ms (batch 512 7.11 -> 6.43, batch 128 2.17 -> 2.12, batch 64 -1 %), Swin-B
 # batch 128 9.14 -> 8.60 ms, VGG-16 batch 64 2.75 -> 2.63 ms, ViT-B/16 batch 256 unchanged (not applied there).  The halves are
 # independent (eval-mode forward, no batch statistics): the result is the concatenation, row for row what the halves give alone.
-_side_streams = {}
 _cache_builds = 0
 # Per host THREAD: whether a two-stream forward is being enqueued and which planning hint its launches carry
 # (TLXMI_PLAN_SHARED_* in every conv / linear descriptor).  Nothing process-wide is mutated: two threads — or two models —
@@ -152,8 +151,13 @@ class shared_plan:
 
 
 def note_cache_build():
-    """A layer built a derived tensor (packed filter, folded BatchNorm, bias / mask table) just now, on the current stream."""
+    """A layer built a derived tensor (packed filter, folded BatchNorm, bias / mask table) just now, on the current stream.
+    Not while a hipGraph is being captured: the build (and the redo of the two-stream forward it triggers) would be recorded
+    into the graph for good — run one eager forward first (bench.py, graph.GraphedForward and the tests do)."""
     global _cache_builds
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("tlxcv_amd: a layer built its packed filter / folded BatchNorm / table during hipGraph capture; "
+                           "run one eager forward of the model (same precision, same weights) before capturing")
     _cache_builds += 1
 
 
@@ -164,13 +168,17 @@ def run_halves(fn, x, plan=None):
     done again — the same launches every later call makes, so the first result equals the later ones bit for bit.
     plan: while the halves are enqueued every conv / linear descriptor carries a planning hint (TLXMI_PLAN_SHARED_*: the
     launch shares the device) — "half": tiles priced for half the CUs and no tail splits (ResNet-50 batch 256 -3 %; Swin-B
-    +3 %), "full": the device's CU count, no tail splits only (Swin-B batch 128 -1.3 %).  The hint is per call and the
-    bookkeeping per host thread: nothing process-wide changes."""
+    +3 %), "full": the device's CU count, no tail splits only (Swin-B batch 128 -1.3 %).  The hint is per call, the side stream
+    and the bookkeeping per host thread.  What IS process-wide: the count of derived-tensor builds — two threads that share ONE
+    model must not race its first forward (run it once on one thread first); separate models per thread are independent."""
     cur = torch.cuda.current_stream(x.device)
     idx = x.device.index if x.device.index is not None else torch.cuda.current_device()
-    side = _side_streams.get(idx)
+    sides = getattr(_tls, "side_streams", None)      # per host thread AND device: two threads forwarding on one GPU do not
+    if sides is None:                                # serialise through one shared side stream
+        sides = _tls.side_streams = {}
+    side = sides.get(idx)
     if side is None:
-        side = _side_streams[idx] = torch.cuda.Stream(device=x.device)
+        side = sides[idx] = torch.cuda.Stream(device=x.device)
     n = x.shape[0] // 2
     _tls.depth = getattr(_tls, "depth", 0) + 1
     hint = shared_plan(plan)

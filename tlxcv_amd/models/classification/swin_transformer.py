@@ -22,7 +22,7 @@ from ... import engine as E
 from ...tlx import nn
 from ...tlx.nn import as_nhwc
 
-__all__ = ["SwinTransformer", "swintransformer_tiny_patch4_window7_224", "swintransformer_small_patch4_window7_224",
+__all__ = ["SwinTransformer", "window_partition", "window_reverse", "drop_path", "DropPath", "swintransformer_tiny_patch4_window7_224", "swintransformer_small_patch4_window7_224",
            "swintransformer_base_patch4_window7_224", "swintransformer_large_patch4_window7_224",
            "swintransformer_base_patch4_window12_384", "swintransformer_large_patch4_window12_384"]
 
@@ -31,6 +31,38 @@ trunc_normal_ = nn.initializers.TruncatedNormal(stddev=0.02)
 
 def to_2tuple(x):
     return tuple([x] * 2)
+
+
+def drop_path(x, drop_prob=0.0, training=False):
+    """Stochastic depth (swin_transformer.py:35-47): the identity in eval mode, the only mode this engine runs."""
+    if drop_prob == 0.0 or not training:
+        return x
+    raise RuntimeError("tlxcv_amd: drop_path in training mode — this engine runs eval-mode forward passes only")
+
+
+class DropPath(nn.Module):
+    """swin_transformer.py:50-59."""
+
+    def __init__(self, drop_prob=None):
+        super().__init__()
+        self.drop_prob = drop_prob
+
+    def forward(self, x):
+        return drop_path(x, self.drop_prob or 0.0, self.is_train)
+
+
+def window_partition(x, window_size):
+    """(B, H, W, C) -> (num_windows * B, window_size, window_size, C)   (swin_transformer.py:85-99), on tlxmi_window_partition."""
+    B, H, W, C = x.shape
+    x = E.need_gpu(x, "input").contiguous()
+    return E.window_partition(x, int(window_size), 0).view(-1, window_size, window_size, C)
+
+
+def window_reverse(windows, window_size, H, W, C):
+    """(num_windows * B, window_size, window_size, C) -> (B, H, W, C)   (swin_transformer.py:102-116), on tlxmi_window_reverse."""
+    windows = E.need_gpu(windows, "input").contiguous()
+    B = windows.numel() // (H * W * C)
+    return E.window_reverse(windows.view(-1, window_size * window_size, C), B, H, W, int(window_size), 0)
 
 
 class Mlp(nn.Module):

@@ -8,8 +8,12 @@ export TMPDIR=/tmp
 OUT=gpurun_out/pmc_wall
 rm -rf $OUT; mkdir -p $OUT
 python3 tools/wall_micro.py 6 > $OUT/unprofiled.txt 2>&1
+REPS=2
 run() { local tag=$1; shift
-  timeout -k 10 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$tag -- python3 tools/wall_micro.py 2 > $OUT/$tag.log 2>&1; echo "pass $tag rc=$?"; }
+  timeout -k 10 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$tag -- python3 tools/wall_micro.py $REPS > $OUT/$tag.log 2>&1
+  local rc=$?; echo "pass $tag rc=$rc"
+  if [ $rc -ne 0 ]; then echo "!! counter pass $tag failed (rc $rc): no wall.txt is written from partial data"; exit $rc; fi; }
+export REPS
 run a SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE
 run b SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD
 run c MfmaUtil
@@ -27,7 +31,12 @@ for tag in "abcd":
             if "gemm_stream" not in row["Kernel_Name"]:
                 continue
             per[int(row["Dispatch_Id"])][row["Counter_Name"]] = float(row["Counter_Value"])
-    ids = sorted(per)                 # 3 launches per kind (1 warm-up + 2), in order A, B, C
+    ids = sorted(per)                 # REPS + 1 launches per kind (1 warm-up + REPS), in order A, B, C
+    import os
+    reps = int(os.environ.get("REPS", "2"))
+    # the kinds are told apart by dispatch order only: refuse anything but exactly 3 x (REPS + 1) gemm_stream launches (a tail
+    # split, a failed pass or another TLXMI_TILE would silently shift the counters onto the wrong kind)
+    assert len(ids) == 3 * (reps + 1), f"pass {tag}: {len(ids)} gemm_stream dispatches, expected {3 * (reps + 1)}"
     n = len(ids) // 3
     for i, d in enumerate(ids):
         for c, v in per[d].items():
@@ -38,8 +47,11 @@ for k in kinds:
     out.append("  " + "  ".join(f"{c}={a[c]:.4g}" for c in sorted(a)))
     gui = a.get("GRBM_GUI_ACTIVE", 0.0)
     if gui:
-        clk = gui / 8.0               # summed over the 8 XCDs
-        cus = 256.0
+        import torch
+        prop = torch.cuda.get_device_properties(0) if torch.cuda.is_available() else None
+        cus = float(prop.multi_processor_count) if prop else 256.0
+        xcds = 8.0 if cus == 256.0 else max(1.0, cus // 32)      # MI355X: 8 XCDs of 32 CUs
+        clk = gui / xcds              # GRBM_GUI_ACTIVE is summed over the XCDs
         out.append(f"  kernel cycles (GRBM_GUI_ACTIVE / 8) = {clk:.4g}")
         if "SQ_VALU_MFMA_BUSY_CYCLES" in a:
             out.append(f"  MFMA pipe busy     = SQ_VALU_MFMA_BUSY_CYCLES / (cycles x CUs x 4 SIMDs) = {a['SQ_VALU_MFMA_BUSY_CYCLES'] / (clk * cus * 4):.3f}")
