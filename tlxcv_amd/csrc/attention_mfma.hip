@@ -18,6 +18,10 @@
 
 namespace tlxmi {
 
+#ifndef ATTN_STAGE_BATCH
+#define ATTN_STAGE_BATCH 4
+#endif
+
 struct AttnArgs {
     const void* qkv;
     const float* bias;
@@ -87,7 +91,8 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const AttnArgs a) {
     }
 
     // ---- stage K and V (zero rows for padded keys); loads are issued in batches ahead of the LDS writes
-    constexpr int ITEMS = NP * CPR, PER = (ITEMS + 255) / 256, BATCH = PER < 4 ? PER : 4;
+    // (TLXMI_ATTN_BATCH, tuning flavour: loads in flight per thread and operand; all PER of them = one memory latency per workgroup)
+    constexpr int ITEMS = NP * CPR, PER = (ITEMS + 255) / 256, BATCH = PER < ATTN_STAGE_BATCH ? PER : ATTN_STAGE_BATCH;
     for (int b0 = 0; b0 < PER; b0 += BATCH) {
         u32x4 kv[BATCH], vv[BATCH];
 #pragma unroll

@@ -9,10 +9,11 @@ import tlxcv_amd
 from tlxcv_amd import seeded, models
 dev = torch.device("cuda:0")
 tlxcv_amd.set_precision("fp16")
-m = models.vit_base_patch16_224()
+wl = sys.argv[2] if len(sys.argv) > 2 else "vit_base_patch16_224"
+m = getattr(models, wl)()
 m.load_dict(seeded.fill(seeded.shapes_of(m), 1))
 m = m.to(dev).set_eval()
-base = torch.from_numpy(seeded.image_batch(32, 0)).to(dev).repeat(9, 1, 1, 1).contiguous()
+base = torch.from_numpy(seeded.image_batch(32, 0)).to(dev).repeat(20, 1, 1, 1).contiguous()
 sizes = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else "256,220,218,222,128,110".split(","))]
 graphs = {}
 for bs in sizes:
