@@ -212,3 +212,30 @@ def test_derived_tensors_follow_parameter_updates():
     e0 = conv._weights_epoch
     conv.load_dict({"filters": torch.zeros(8, 8, 1, 1)}, strict=False)
     assert conv._weights_epoch == e0 + 1               # what a captured hipGraph compares before replay
+
+
+def test_linear_tail_plan_matches_the_round_arithmetic():
+    """Host logic of engine._linear_tail (no GPU): ViT-B/16 proj at batch 256 on 256 CUs -> 170 row tiles on the persistent
+    kernel, 6912 rows on K slices; whole rounds, a last round over half full, too short a K -> no split."""
+    from tlxcv_amd import engine
+    import types
+    class PK:      # noqa: E306
+        def __init__(self, K, Cout):
+            self.Cin = self.Cin_pad = K
+            self.Cout = Cout
+    class X:       # noqa: E306
+        device = types.SimpleNamespace(index=0)
+        dtype = torch.float16
+        def element_size(self):
+            return 2
+    engine._cus[0] = 256
+    try:
+        assert engine._linear_tail(50432, 768, PK(768, 768), X())[0] == 170 * 256
+        assert engine._linear_tail(50432, 3072, PK(3072, 768), X()) == (170 * 256, 2)
+        assert engine._linear_tail(220 * 197, 768, PK(768, 768), X()) is None          # 170 x 3 = 510 tiles: whole rounds... of 256? 1.99 -> over half
+        assert engine._linear_tail(50432, 768, PK(768, 2304), X()) is None            # 1773 tiles = 6 rounds + 237: over half full
+        assert engine._linear_tail(50432, 256, PK(256, 768), X()) is None             # 4 K tiles: too short for slices
+        with engine.shared_plan("half"):
+            assert engine._linear_tail(25216, 768, PK(768, 768), X())[0] == 85 * 256
+    finally:
+        engine._cus.pop(0, None)

@@ -25,7 +25,10 @@ _options = {"splitk": True,       # classifier heads: K slices side by side (tlx
                                   # expand conv and the next block's reduce conv as two launches (the A/B and the parity tests' other arm)
             "seam256": True,      # bottleneck seams with a 256-channel conv3 input (ResNet-50 layer3, 14 x 14) fused too
             "two_streams": True,  # large batches as two half batches on two HIP streams (two_streams(), below)
-            "conv_splitk": True}  # convs with few pixels and a long K on K slices (tlxmi_conv2d_splitk)
+            "conv_splitk": True,  # convs with few pixels and a long K on K slices (tlxmi_conv2d_splitk)
+            "tail_splitk": False} # Linear layers: the rows of a short last round of 256 x 256 tiles on K slices (_linear_tail): built,
+                                  # parity-green, measured a LOSS on the ViT-B/16 forward (10.63 -> 11.61 ms for every K >= 768,
+                                  # 10.91 for fc2 only: two more launches + the fp32 partial planes cost more than the idle round)
 
 
 def set_option(name, value):
@@ -611,6 +614,23 @@ def linear(x, pk, bias=None, res=None, act=ACT_NONE, out=None):
         o4 = out.view(rows, 1, 1, pk.Cout)
     if x.dtype != pk.dtype:
         raise RuntimeError(f"linear: input dtype {x.dtype} != packed filter dtype {pk.dtype}")
+    tail = _linear_tail(rows, shp[-1], pk, x) if (_probe is None and pk.R == 1 and pk.S == 1) else None
+    if tail is not None:
+        # Whole rounds of 256 x 256 tiles on the persistent kernel, the rows of the short last round as K slices side by side +
+        # the deterministic slice-order reduction (bias, residual, activation there): the balanced tail WITHOUT giving up the
+        # tile's arithmetic intensity (a K slice of a tile reads as many operand bytes per FLOP as the whole tile)
+        m_lo, slices = tail
+        y = out.view(rows, pk.Cout) if out is not None else torch.empty((rows, pk.Cout), dtype=x.dtype, device=x.device)
+        x2 = x.view(rows, shp[-1])
+        r2 = res.view(rows, pk.Cout) if res is not None else None
+        conv2d(x2[:m_lo].view(m_lo, 1, 1, shp[-1]), pk, shift=bias, res=(r2[:m_lo].view(m_lo, 1, 1, pk.Cout) if r2 is not None else None),
+               act=act, out=y[:m_lo].view(m_lo, 1, 1, pk.Cout))
+        hi = rows - m_lo
+        part = torch.empty((slices, hi, pk.Cout), dtype=torch.float32, device=x.device)      # fp32 partial sums
+        _lib.call("tlxmi_linear_splitk", dt_code(x.dtype), hi, shp[-1], pk.Cout, shp[-1], _p(x2[m_lo:]), _p(pk.buf), slices, _p(part),
+                  None, _p(bias), _p(r2[m_lo:] if r2 is not None else None), pk.Cout if r2 is not None else 0, act, C.c_float(0.0), 0,
+                  _p(y[m_lo:]), pk.Cout, _stream())
+        return y.view(*shp[:-1], pk.Cout)
     splits = _linear_splits(rows, shp[-1], pk, x) if (out is None and _probe is None and pk.R == 1 and pk.S == 1) else 0
     if splits:
         # few rows, large filter (classifier heads): K slices side by side + a deterministic reduction (tlxmi_linear_splitk)
@@ -621,6 +641,49 @@ def linear(x, pk, bias=None, res=None, act=ACT_NONE, out=None):
         return y.view(*shp[:-1], pk.Cout)
     y = conv2d(x4, pk, shift=bias, res=r4, act=act, out=o4)
     return y.view(*shp[:-1], pk.Cout)
+
+
+def _linear_tail(rows, K, pk, x):
+    """(rows of the whole rounds, K slices of the rest) for a Linear whose 256 x 256 tiles are r whole rounds on the CUs this
+    launch is planned for plus a last round at most half full — ViT-B/16 proj / fc2 at batch 256: 2.32 rounds paid as 3, and
+    batch 222 runs 6 % fewer images per second than batch 220 (tools/batch_quant.py) — else None.  The persistent kernel then
+    runs exactly r rounds and the leftover rows go to tlxmi_linear_splitk.  OFF by default (set_option("tail_splitk", True) for the
+    A/B): measured slower than the idle round it removes (the option table above); the in-kernel half-height tiles of
+    gemm_stream.hip are what the product runs."""
+    if not _options["tail_splitk"] or pk.Cin != K or pk.Cin_pad != K or pk.Cout < 256:
+        return None
+    es = x.element_size()
+    kt = K * es // 128                      # K tiles of 128 bytes
+    if (K * es) % 128 or kt < _TAIL_MIN_KTILES or (pk.Cout * es) % 16:
+        return None
+    idx = x.device.index if x.device.index is not None else torch.cuda.current_device()
+    if idx not in _cus:
+        _cus[idx] = torch.cuda.get_device_properties(idx).multi_processor_count
+    cus = _cus[idx] // 2 if (plan_flags() & _lib.PLAN_SHARED_HALF) else _cus[idx]
+    grid = max(8, cus & ~7)
+    nt = (pk.Cout + 255) // 256
+    tiles = ((rows + 255) // 256) * nt
+    r, rem = divmod(tiles, grid)
+    if r < 1 or rem == 0 or 2 * rem > grid:
+        return None
+    m_lo = (r * grid // nt) * 256
+    hi = rows - m_lo
+    if m_lo <= 0 or hi <= 0:
+        return None
+    t128 = ((hi + 127) // 128) * ((pk.Cout + 127) // 128)
+    best = 0
+    for s_ in range(2, 9):
+        if kt % s_ or kt // s_ < 4:
+            continue
+        best = s_
+        if t128 * s_ >= 2 * grid:
+            break
+    if not best or hi * pk.Cout * 4 * best >= (1 << 31):
+        return None
+    return m_lo, best
+
+
+_TAIL_MIN_KTILES = 12      # (K >= 768 in fp16)
 
 
 def _linear_splits(rows, K, pk, x):
