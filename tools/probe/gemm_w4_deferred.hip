@@ -1,3 +1,6 @@
+// MEASURED DEAD END, kept as a reference (tools/probe, not built into the library): round 4's second form of gemm_w4.hip.
+// Swapped in as tlxcv_amd/csrc/gemm_w4.hip it passes tests/test_gemm_gpu.py -k w4 and the ViT-B/16 Linear shapes against torch
+// (DESIGN 5.3), and measures slower than both the first form and the 8-wave kernels: K-loop-only forward 10.7 ms vs 9.1 / 8.5.
 // Persistent 256 x 256 tile GEMM on FOUR waves — one per SIMD, each with the whole 512-register file — for the
 // MFMA-bound Linear layers of ViT / Swin in fp16 (reference vision_transformer.py:81-87, 112-123; swin_transformer.py:192-229):
 //     Y[m][n] = act( sum_k X[m][k] * Wp[n][k] + shift[n] + R[m][n] )           (scale == nullptr: Linear layers)
@@ -11,7 +14,7 @@
 // Here a wave owns 128 x 128 outputs (16 blocks of v_mfma_f32_32x32x16_f16 = 256 accumulators, AGPRs) and the other 256
 // registers hold: two sets of 8 fragments (k-step s + 1 is read from LDS while k-step s multiplies) and the finished tile,
 // rounded to fp16, in 128 PENDING registers.  Nothing of a tile's epilogue runs at the tile's end except that conversion:
-//   * the bias is the C operand of a tile's first MFMAs (read from a double-buffered LDS table, staged by LDS-DMA);
+//   * the bias (from a double-buffered LDS table, staged by LDS-DMA) is added as the block is converted;
 //   * the residual is added BY THE MATRIX PIPE: acc(32 ch x 32 px) += I(32 x 16) . R(16 ch x 32 px) for the two 16-channel
 //     groups of a block — the residual's rows in HBM are exactly B fragments (8 consecutive channels of a pixel), the identity
 //     slices are two constant A fragments; 2 MFMAs per block (+4 % at K = 768), no VALU, one rounding (exact fp32 add);
@@ -71,9 +74,10 @@ template <int POL> static __device__ __forceinline__ void w4_store16(__amdgpu_bu
 template <int B> static __device__ __forceinline__ void w4_mma(u32x4 a, u32x4 b) {
     asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(a), "v"(b), "i"(16 * B), "i"(16 * B + 15) : W4_AGPRS);
 }
-// acc[B] = a . b + c   (first MFMA of an output tile: c = the bias block)
-template <int B> static __device__ __forceinline__ void w4_mma_init(u32x4 a, u32x4 b, f32x16 c) {
-    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 a[%c3:%c4], %0, %1, %2" ::"v"(a), "v"(b), "v"(c), "i"(16 * B), "i"(16 * B + 15) : W4_AGPRS);
+// acc[B] = a . b   (first MFMA of an output tile; the C / D operands of an MFMA are both accumulator registers or both not,
+// so the bias cannot enter here as a VGPR block: it is added when the finished block leaves the accumulators)
+template <int B> static __device__ __forceinline__ void w4_mma_zero(u32x4 a, u32x4 b) {
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 a[%c2:%c3], %0, %1, 0" ::"v"(a), "v"(b), "i"(16 * B), "i"(16 * B + 15) : W4_AGPRS);
 }
 // acc[B] -> 16 VGPRs (the wait states after the last MFMA that wrote the block: a 16-pass MFMA's result may be read 18 states later)
 template <int B> static __device__ __forceinline__ f32x16 w4_acc_read() {
@@ -213,16 +217,21 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const Gemm256Args a) {
                 o[hh] = __builtin_bit_cast(u32x4, v);
             }
         } else if constexpr (ACT == TLXMI_ACT_GELU) {
+            // one pair at a time: each pair's input is tied to the previous pair's result by an empty asm, so the scheduler cannot
+            // open all 8 polynomial chains of a unit at once (80 live registers; the kernel has ~40 to spare)
+            unsigned chain = 0;
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
-                half8v v = __builtin_bit_cast(half8v, o[hh]);
 #pragma unroll
-                for (int e = 0; e < 8; e += 2) {
-                    const f32x2v g2 = gelu_fast2(f32x2v{(float)v[e], (float)v[e + 1]});
-                    v[e] = (half_t)g2[0];
-                    v[e + 1] = (half_t)g2[1];
+                for (int e = 0; e < 4; ++e) {
+                    unsigned w = o[hh][e];
+                    asm volatile("" : "+v"(w) : "v"(chain));
+                    const half2v h2 = __builtin_bit_cast(half2v, w);
+                    const f32x2v g2 = gelu_fast2(f32x2v{(float)h2[0], (float)h2[1]});
+                    const half2v r2 = half2v{(half_t)g2[0], (half_t)g2[1]};
+                    chain = __builtin_bit_cast(unsigned, r2);
+                    o[hh][e] = chain;
                 }
-                o[hh] = __builtin_bit_cast(u32x4, v);
             }
         }
         const int rowok = (live && m < a.M && !(DBG & 16)) ? 0 : OOB;
@@ -291,7 +300,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const Gemm256Args a) {
     int bm0 = 0, bn0 = 0, pbm0 = 0, pbn0 = 0;
     bool have_prev = false;
     // One K tile.  V = 0..8: step V of the tile's drain / residual schedule; V = 9: none.
-    //   V = 0      : first K tile of an output tile — the accumulators start from the bias (C operand read from the LDS table)
+    //   V = 0      : first K tile of an output tile — the accumulators start from 0 (C operand of the first MFMAs)
     //   V = 0 .. 7 : drain units 2V, 2V + 1 of the previous tile; with a residual, load the fragments of blocks 2V, 2V + 1
     //   V = 1 .. 8 : with a residual, add blocks 2V - 2, 2V - 1 (loaded one K tile earlier)
     auto ktile = [&](auto v_tag, int i) {
@@ -321,16 +330,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const Gemm256Args a) {
                 wn[r] = *reinterpret_cast<const u32x4*>(kb + (wf0 ^ (32 * (s + 1))) + r * 4096);
                 xn[r] = *reinterpret_cast<const u32x4*>(kb + (xf0 ^ (32 * (s + 1))) + r * 4096);
                 if constexpr (V == 0 && s == 0) {
-                    // the bias of channels 64h + 16r .. + 15 as the C operand of this row of blocks
-                    const int ln = lane_now();
-                    const float* tb = reinterpret_cast<const float*>(smem + TAB + (i & 1) * 1024) + 128 * wc + 64 * (ln >> 5) + 16 * r;
-                    f32x16 c;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const f32x4 q4 = *reinterpret_cast<const f32x4*>(tb + 4 * e);
-                        c[4 * e] = q4[0]; c[4 * e + 1] = q4[1]; c[4 * e + 2] = q4[2]; c[4 * e + 3] = q4[3];
-                    }
-                    w4_unroll<4>([&](auto p_tag) { w4_mma_init<r * 4 + decltype(p_tag)::value>(wf[r], xf[decltype(p_tag)::value], c); });
+                    w4_unroll<4>([&](auto p_tag) { w4_mma_zero<r * 4 + decltype(p_tag)::value>(wf[r], xf[decltype(p_tag)::value]); });
                 } else {
                     w4_unroll<4>([&](auto p_tag) { w4_mma<r * 4 + decltype(p_tag)::value>(wf[r], xf[decltype(p_tag)::value]); });
                 }
@@ -380,18 +380,27 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const Gemm256Args a) {
         ktile(IntTag<7>{}, i);
         ktile(IntTag<8>{}, i);
         for (int kt = 9; kt < ks; ++kt) ktile(IntTag<9>{}, i);
-        // the finished tile -> fp16 pending registers (the only epilogue work that is not hidden: 128 conversions)
-        w4_unroll<16>([&](auto b_tag) {
-            constexpr int B = decltype(b_tag)::value, ci = B >> 2, pi = B & 3;
-            const f32x16 v = w4_acc_read<B>();
-            half8v h0, h1;
+        // the finished tile -> fp16 pending registers (the only epilogue work that is not hidden: 256 register reads, the bias, 128 conversions)
+        w4_unroll<4>([&](auto c_tag) {
+            constexpr int ci = decltype(c_tag)::value;
+            // the bias of channels 64h + 16 ci .. + 15 (table slot i & 1: staged two K tiles before the tile began)
+            const int ln = lane_now();
+            const float* tb = reinterpret_cast<const float*>(smem + TAB + (i & 1) * 1024) + 128 * wc + 64 * (ln >> 5) + 16 * ci;
+            f32x4 b4[4];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                h0[e] = (half_t)v[e];
-                h1[e] = (half_t)v[8 + e];
-            }
-            pend[pi][ci][0] = __builtin_bit_cast(u32x4, h0);
-            pend[pi][ci][1] = __builtin_bit_cast(u32x4, h1);
+            for (int e = 0; e < 4; ++e) b4[e] = *reinterpret_cast<const f32x4*>(tb + 4 * e);
+            w4_unroll<4>([&](auto p_tag) {
+                constexpr int pi = decltype(p_tag)::value;
+                const f32x16 v = w4_acc_read<ci * 4 + pi>();
+                half8v h0, h1;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    h0[e] = (half_t)(v[e] + b4[e >> 2][e & 3]);
+                    h1[e] = (half_t)(v[8 + e] + b4[2 + (e >> 2)][e & 3]);
+                }
+                pend[pi][ci][0] = __builtin_bit_cast(u32x4, h0);
+                pend[pi][ci][1] = __builtin_bit_cast(u32x4, h1);
+            });
         });
         have_prev = true;
     }
@@ -427,7 +436,7 @@ template <int ACT, bool RES, int DBG = 0> static int launch_w4(const Gemm256Args
 
 // fp16 Linear layers (no BatchNorm scale) with >= 9 K tiles: the drain / residual schedule of a tile takes its first nine
 bool gemm_w4_ok(int dtype, const Gemm256Args& a) {
-    if (dtype != TLXMI_F16 || a.ksteps < 9 || a.ln_fused || a.rowstats || a.conv || a.kslices > 1 || a.scale) return false;
+    if (dtype != TLXMI_F16 || a.ksteps < 9 || a.conv || a.kslices > 1 || a.scale) return false;
     if (a.res && (a.flags & TLXMI_EPI_RES_AFTER_ACT)) return false;
     if (a.act != TLXMI_ACT_NONE && a.act != TLXMI_ACT_RELU && a.act != TLXMI_ACT_GELU) return false;
     return true;
