@@ -691,7 +691,9 @@ def _linear_splits(rows, K, pk, x):
     if not _options["splitk"] or rows > 512 or pk.Cin != K or pk.Cin_pad != K:
         return 0
     es = x.element_size()
-    if K * es < 8192 or pk.Cout * K * es < 8000000 or (pk.Cout * es) % 16:      # a filter of >= 8 MB with K >= 4096 (fp16)
+    if K * es < 4096 or pk.Cout * K * es < 3000000 or (pk.Cout * es) % 16:      # a filter of >= 3 MB with K >= 2048 (fp16): VGG / AlexNet
+        # heads (round 2) and, round 4, ResNet's 2048 -> 1000 head (32 tiles of 64 x 64 per half batch, each walking all of K: 3.403 ->
+        # 3.387 ms per ResNet-50 forward, tools/ab_tmp.py)
         return 0
     idx = x.device.index if x.device.index is not None else torch.cuda.current_device()
     if idx not in _cus:
