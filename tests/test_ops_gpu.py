@@ -123,6 +123,28 @@ def test_attention(dev, dtype, B, N, heads, hd, swin):
     torch.testing.assert_close(got.float().cpu(), want, **t)
 
 
+@pytest.mark.parametrize("N", [65, 96, 100, 128, 129, 150, 197, 200, 224, 225, 256])
+def test_vit_attention_with_k_v_staged_by_lds_dma(dev, N):
+    """attn_dma_kernel (head dim 64, no bias / mask, 65 .. 256 tokens: every key-tile count and both padding-mask variants):
+    against the fp32 reference on the fp16-rounded inputs, against the register-staged kernel it replaces (TLXMI_ATTN_DMA=0,
+    tuning flavour) bit for bit — same arithmetic, only the staging differs — and reproducible."""
+    from tlxcv_amd._lib import tuning
+    rng = np.random.default_rng(N)
+    B, heads, hd = 5, 3, 64
+    qkv = prep(rnd(rng, (B, N, 3 * heads * hd)), torch.float16)
+    want = _ref_attention(qkv, heads, hd ** -0.5, None, None)
+    x = qkv.half().to(dev)
+    got = E.attention(x, heads, hd ** -0.5)
+    torch.testing.assert_close(got.float().cpu(), want, atol=4e-3, rtol=4e-3)
+    assert torch.equal(E.attention(x, heads, hd ** -0.5), got)
+    with tuning(TLXMI_ATTN_DMA="0"):
+        old = E.attention(x, heads, hd ** -0.5)
+    with tuning(TLXMI_ATTN_DMA="1"):
+        new = E.attention(x, heads, hd ** -0.5)
+    torch.cuda.synchronize()
+    assert torch.equal(old, new) and torch.equal(new, got)
+
+
 @pytest.mark.parametrize("B,N,heads,hd,masked", [(8, 49, 4, 32, True), (4, 49, 16, 32, False), (6, 130, 2, 64, True), (2, 197, 3, 96, False)])
 def test_attention_with_presummed_table(dev, B, N, heads, hd, masked):
     """tlxmi_attention_comb: bias + mask summed and padded by the caller (swin_transformer.py:205-220)."""

@@ -27,6 +27,7 @@ struct AttnArgs {
     int B, N, heads, hd, nW;
     float scale;
     const float* comb;   // bias + mask pre-summed and padded: [max(nW,1)][heads][NP][NP], NP = 32 * ceil(N / 32)
+    int debug = 0;       // (the same struct as in attention_mfma.hip: keep the two definitions identical)
 };
 
 template <typename T>

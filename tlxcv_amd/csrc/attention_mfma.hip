@@ -30,6 +30,7 @@ struct AttnArgs {
     int B, N, heads, hd, nW;
     float scale;
     const float* comb;   // bias + mask pre-summed and padded: [max(nW,1)][heads][NP][NP], NP = 32 * ceil(N / 32)
+    int debug = 0;       // tuning flavour only (TLXMI_ATTN_DBG; results are wrong): 1 no K / V staging, 2 one query tile per wave only
 };
 
 typedef __fp16 fp16x4 __attribute__((ext_vector_type(4)));
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const AttnArgs a) {
     // ---- stage K and V (zero rows for padded keys); loads are issued in batches ahead of the LDS writes
     // (TLXMI_ATTN_BATCH, tuning flavour: loads in flight per thread and operand; all PER of them = one memory latency per workgroup)
     constexpr int ITEMS = NP * CPR, PER = (ITEMS + 255) / 256, BATCH = PER < ATTN_STAGE_BATCH ? PER : ATTN_STAGE_BATCH;
-    for (int b0 = 0; b0 < PER; b0 += BATCH) {
+    for (int b0 = 0; b0 < (TLXMI_DBG(a, 1) ? 0 : PER); b0 += BATCH) {
         u32x4 kv[BATCH], vv[BATCH];
 #pragma unroll
         for (int u = 0; u < BATCH; ++u) {
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const AttnArgs a) {
     const int klane = li * SR + g * 16;
 
 #pragma unroll 1
-    for (int qt = wv; qt < nqt; qt += 4) {
+    for (int qt = wv; qt < (TLXMI_DBG(a, 2) ? (nqt < 4 ? nqt : 4) : nqt); qt += 4) {
         const int query = qt * 16 + li;
         const bool qok = query < N;
         // next tile's Q rows travel while this tile computes
@@ -252,6 +253,196 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const AttnArgs a) {
                     vf[4 + r] = (half_t)vhi[dt][r];
                 }
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, o[dt], 0, 0, 0);
+            }
+            if (pr + 1 < NT / 2) {
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) { vlo[dt] = nlo[dt]; vhi[dt] = nhi[dt]; }
+            }
+        }
+        if (qok) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                half4v ov;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ov[r] = (half_t)(o[dt][r] * inv);
+                *reinterpret_cast<half4v*>(obase + (size_t)query * heads * HD + dt * 16 + 4 * g) = ov;
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qcur[ks] = qnext[ks];
+    }
+}
+
+// The same computation for head dim 64 without bias / mask (ViT-B/16: 197 tokens, vision_transformer.py:112-123) with K and V
+// staged by LDS-DMA (round 4).  Whole-forward ablation (tools/ab_graph.py TLXMI_ATTN_DBG): the forward loses 1.26 ms of 10.8 when
+// the K / V staging of attn_mfma_kernel is removed — a workgroup there runs [load batch 1, write, load batch 2, write | barrier |
+// compute]: two exposed memory latencies and 57 KB through VGPRs and ds_write_b128 before its first MFMA.  Here every wave issues
+// its 14 pieces (8 keys x 128 B each, K then V) at once, straight into LDS, after its first Q fragments: one latency, no register
+// round trip.  LDS-DMA writes lane-linear kilobytes, so the rows cannot be padded; they are 128 B with chunk c of row r in slot
+// c ^ f(r), f(r) = ((r >> 1) & 3) << 1 (applied to the SOURCE chunk a lane fetches): conflict-free both for the ds_read_b128
+// K-fragment reads (a 16-lane group holds the even slots c ^ {0,2,4,6} of one chunk family and the odd ones of the other, at both
+// row parities) and for the ds_read_b64_tr_b16 V reads (a 32-lane half covers rows 4g + q, g = 0, 1: the four same-parity rows
+// carry f = 0, 2, 4, 6, so {2dt, 2dt + 1} ^ f are 8 distinct slots x 2 halves x 2 parities = all 64 banks).  56 KB per
+// workgroup instead of 72: still two per CU.  NTL = key tiles kept in LDS (NT, or NT - 1 when the last one is wholly padding).
+// Measured on the forward (two half batches): equal to the register-staged kernel within 0.3 % — the 1.26 ms are the
+// BYTES (they compete with the other half batch's GEMM for HBM), not the staging mechanics; K / V as one contiguous block per
+// (image, head) instead of 128-B pieces of the packed qkv rows: equal too.
+template <int NT, int KF, int NTL>
+__global__ __launch_bounds__(256, 2) void attn_dma_kernel(const AttnArgs a) {
+    constexpr int HD = 64, SR = 128, NP = 16 * NTL, KS = 2, DT = 4;
+    constexpr int OOB = (int)0x80000000;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;
+    char* Vs = smem + NP * SR;
+
+    const int N = a.N, heads = a.heads;
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int g = lane >> 4, li = lane & 15;
+    const size_t tok_ld = (size_t)3 * heads * HD;   // elements between tokens of the packed qkv
+    const half_t* qbase = reinterpret_cast<const half_t*>(a.qkv) + (size_t)b * N * tok_ld + (size_t)h * HD;
+
+    // ---- Q fragments of this wave's first query tile: issued BEFORE the DMA pieces (the vector-memory counter is in order: a
+    // load behind them would wait for them)
+    const int nqt = (N + 15) >> 4;
+    u32x4 qcur[KS];
+    {
+        const int query = wv * 16 + li;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            qcur[ks] = u32x4{0u, 0u, 0u, 0u};
+            if (query < N) qcur[ks] = *reinterpret_cast<const u32x4*>(qbase + (size_t)query * tok_ld + ks * 32 + g * 8);
+        }
+    }
+    // ---- K and V: piece p = keys 8p .. 8p + 7; lane l -> key 8p + (l >> 3), slot l & 7, source chunk (l & 7) ^ f(key); wave w
+    // takes pieces w, w + 4, ...; keys past the sequence are an out-of-range offset (zero rows, no traffic)
+    {
+        const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<void*>(a.qkv), 0, (unsigned)((size_t)a.B * N * tok_ld * 2), 0x00020000);
+        const int lc = (lane & 7) ^ (((lane >> 4) & 3) << 1);
+        const int base = (int)(((size_t)b * N * tok_ld + (size_t)h * HD) * 2) + lc * 16;
+        const int krow = lane >> 3;
+        typedef __attribute__((address_space(3))) void* lds_ptr_t;
+#pragma unroll
+        for (int which = 1; which <= 2; ++which)      // 1: K, 2: V (the packed qkv row is [q | k | v] x [heads][hd])
+#pragma unroll
+            for (int j = 0; j < (NP / 8 + 3) / 4; ++j) {
+                const int p = wv + 4 * j;
+                const int key = 8 * p + krow;
+                const int off = (p < NP / 8 && key < N) ? base + (int)(key * tok_ld * 2) + which * heads * HD * 2 : OOB;
+                if (p < NP / 8)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr_t)((which == 1 ? Ks : Vs) + p * 1024), 16, off, 0, 0, 0);
+            }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    half_t* obase = reinterpret_cast<half_t*>(a.out) + (size_t)b * N * heads * HD + (size_t)h * HD;
+
+    // transposing V reads: lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of a 16-column block
+    const int vrow = 4 * g + (li >> 2);
+    const int vf = ((2 * g + (li >> 3)) & 3) << 1;                       // f(32 pr + 4g + q [+ 16])
+    auto load_v = [&](int pr, fp16x4 (&lo)[DT], fp16x4 (&hi)[DT]) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const char* a0 = Vs + (pr * 32 + vrow) * SR + (((2 * dt + ((li & 3) >> 1)) ^ vf) << 4) + (li & 1) * 8;
+            lo[dt] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16x4*)(a0));
+            hi[dt] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16x4*)(a0 + (2 * pr + 1 < NTL ? 16 * SR : 0)));   // P is 0 there
+        }
+    };
+    const int kf_ = ((li >> 1) & 3) << 1;                                  // f(16 kt + li)
+    auto k_addr = [&](int kt, int ks) { return Ks + (kt * 16 + li) * SR + (((4 * ks + g) ^ kf_) << 4); };
+
+#pragma unroll 1
+    for (int qt = wv; qt < nqt; qt += 4) {
+        const int query = qt * 16 + li;
+        const bool qok = query < N;
+        u32x4 qnext[KS];
+        {
+            const int nq = query + 64;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                qnext[ks] = u32x4{0u, 0u, 0u, 0u};
+                if (qt + 4 < nqt && nq < N)
+                    qnext[ks] = *reinterpret_cast<const u32x4*>(qbase + (size_t)nq * tok_ld + ks * 32 + g * 8);
+            }
+        }
+        float s[NT][4];
+        float mx = -INFINITY;
+        u32x4 kf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) kf[ks] = *reinterpret_cast<const u32x4*>(k_addr(0, ks));
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            if (kt >= NTL) {      // a key tile wholly past the sequence, not in LDS (NTL < NT)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[kt][r] = -INFINITY;
+                continue;
+            }
+            u32x4 kn[KS];
+            if (kt + 1 < NTL) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) kn[ks] = *reinterpret_cast<const u32x4*>(k_addr(kt + 1, ks));
+            }
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8v, kf[ks]),
+                                                             __builtin_bit_cast(half8v, qcur[ks]), acc, 0, 0, 0);
+            const bool full_tile = kt < KF || kt * 16 + 16 <= N;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt * 16 + 4 * g + r;
+                float v = acc[r];
+                if (kt >= KF && !full_tile && key >= N) v = -INFINITY;
+                s[kt][r] = v;
+                mx = fmaxf(mx, v);
+            }
+            if (kt + 1 < NTL) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) kf[ks] = kn[ks];
+            }
+        }
+        fp16x4 vlo[DT], vhi[DT];
+        load_v(0, vlo, vhi);
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float ec = a.scale * 1.44269504088896340736f;
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __builtin_amdgcn_exp2f(fmaf(s[kt][r], ec, -mx * ec));
+                s[kt][r] = p;
+                sum += p;
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.f / sum;
+        f32x4 o[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int pr = 0; pr < NT / 2; ++pr) {
+            fp16x4 nlo[DT], nhi[DT];
+            if (pr + 1 < NT / 2) load_v(pr + 1, nlo, nhi);
+            half8v pf;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pf[r] = (half_t)s[2 * pr][r];
+                pf[4 + r] = (half_t)s[2 * pr + 1][r];
+            }
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                half8v vfr;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    vfr[r] = (half_t)vlo[dt][r];
+                    vfr[4 + r] = (half_t)vhi[dt][r];
+                }
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vfr, pf, o[dt], 0, 0, 0);
             }
             if (pr + 1 < NT / 2) {
 #pragma unroll
@@ -693,11 +884,30 @@ template <int HD, int NT> static int launch_win(const AttnArgs& a, hipStream_t s
 }
 
 template <int HD, int NT, int ADD, int KF> static int launch_kf(const AttnArgs& a, hipStream_t st) {
+    if constexpr (HD == 64 && ADD == 0 && NT >= 8) {      // ViT: K / V by LDS-DMA (TLXMI_ATTN_DMA=0, tuning flavour: the register-staged kernel)
+        if (tune_int("TLXMI_ATTN_DMA", 1) && (size_t)a.B * a.N * 3 * a.heads * HD * 2 < (1ull << 31)) {
+            AttnArgs b = a;
+            b.debug = (int)tune_int("TLXMI_ATTN_DBG", 0);
+            // an odd count of key tiles (ViT: 197 tokens = 13) keeps and multiplies only those (-0.4 % of the ViT-B/16 forward).
+            // 52 KB would fit three workgroups per CU: measured +6 % (168 registers: 148 B of scratch in the query loop)
+            auto go = [&](auto ntl) -> int {
+                constexpr int NTL = decltype(ntl)::value;
+                const size_t lds = (size_t)2 * 16 * NTL * 128;
+                if (int rc = raise_lds_limit(reinterpret_cast<const void*>(&attn_dma_kernel<NT, KF, NTL>), 160 * 1024, "attention")) return rc;
+                hipLaunchKernelGGL((attn_dma_kernel<NT, KF, NTL>), dim3(a.B * a.heads), dim3(256), lds, st, b);
+                return 0;
+            };
+            if (int rc = (a.N <= 16 * (NT - 1) && !tune_int("TLXMI_ATTN_EVEN", 0)) ? go(IntTag<NT - 1>{}) : go(IntTag<NT>{})) return rc;
+            return check_launch("attention(dma)");
+        }
+    }
     constexpr int SR = HD * 2 + 32;
     const size_t lds = (size_t)2 * 16 * NT * SR + (ADD == 1 ? (size_t)a.N * a.N * sizeof(float) : 0);
     if (lds > 64 * 1024)
         if (int rc = raise_lds_limit(reinterpret_cast<const void*>(&attn_mfma_kernel<HD, NT, ADD, KF>), 160 * 1024, "attention")) return rc;
-    hipLaunchKernelGGL((attn_mfma_kernel<HD, NT, ADD, KF>), dim3(a.B * a.heads), dim3(256), lds, st, a);
+    AttnArgs b = a;
+    b.debug = (int)tune_int("TLXMI_ATTN_DBG", 0);
+    hipLaunchKernelGGL((attn_mfma_kernel<HD, NT, ADD, KF>), dim3(a.B * a.heads), dim3(256), lds, st, b);
     return check_launch("attention(mfma)");
 }
 

@@ -1,2 +1,2 @@
-python tools/ab_graph.py opt:tail_splitk 0,1 vit_b16 256 2>&1 | grep batch
-python tools/ab_graph.py opt:tail_splitk 0,1 swin_b 128 2>&1 | grep batch
+python tools/ab_graph.py TLXMI_ATTN_EVEN 1,0 vit_b16 256 2>&1 | grep batch
+python tools/ab_graph.py TLXMI_ATTN_EVEN 1,0 vit_b16 256 2>&1 | grep batch

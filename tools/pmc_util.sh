@@ -23,7 +23,10 @@ for c in ("MfmaUtil", "LdsBankConflict"):
             a = agg[row["Kernel_Name"][:96]]
             a[c] = a.get(c, 0.0) + float(row["Counter_Value"])
             a["n_" + c] = a.get("n_" + c, 0) + 1
-lines = [f"{wl}: per-kernel averages over the launches of one bench.py run (rocprofv3 --pmc, one counter per pass)",
+import os
+sys.path.insert(0, os.getcwd())
+import bench
+lines = [f"{wl}: per-kernel averages over the launches of one bench.py run (rocprofv3 --pmc, one counter per pass); csrc_sha {bench.csrc_sha()}",
          f"{'launches':>8s} {'MfmaUtil %':>11s} {'LdsBankConflict %':>18s}  kernel"]
 for k, a in sorted(agg.items(), key=lambda kv: -kv[1].get("n_MfmaUtil", 0) * kv[1].get("MfmaUtil", 0.0)):
     n = a.get("n_MfmaUtil", 0)
