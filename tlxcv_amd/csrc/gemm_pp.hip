@@ -93,8 +93,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
         const int nb = a.mtiles * a.ntiles, id = a.kslices > 1 ? (int)blockIdx.x % nb : (int)blockIdx.x;
         const int xcd = id & 7, qd = nb >> 3, rm = nb & 7;
         const int L = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (id >> 3);
-        tile_m = L / a.ntiles;
-        tile_n = L - tile_m * a.ntiles;
+        // column panels of a.gn N tiles (gemm_stream.hip's walk): the filter panel stays in the XCD's L2 while its row tiles pass
+        const int per = a.mtiles * a.gn, p = L / per, r = L - p * per;
+        const int gh = a.ntiles - p * a.gn < a.gn ? a.ntiles - p * a.gn : a.gn;
+        tile_m = r / gh;
+        tile_n = p * a.gn + r - tile_m * gh;
     }
     const int bm0 = tile_m * BM, bn0 = tile_n * BN;
     // split K: this copy of the tile grid multiplies K tiles kt0 .. kt0 + ks - 1 (a K tile past the slice is a zero fill)
@@ -449,6 +452,7 @@ template <typename T, int HM, int HN, bool CONV> static int launch_pp_t(const Ge
     a.mtiles = (a.M + 128 * HM - 1) / (128 * HM);
     a.ntiles = (a.Cout + 128 * HN - 1) / (128 * HN);
     a.gn = a.ntiles;
+    if (const long g = tune_int("TLXMI_GS_PANEL", 3); !CONV && g > 0 && g < a.ntiles) a.gn = (int)g;
     const size_t lds = (size_t)(HM + HN == 4 ? 8 : 9) * 128 * 128 + 2 * 256 * sizeof(float);
     const void* fn = reinterpret_cast<const void*>(&gemm_pp_kernel<T, HM, HN, CONV>);
     if (int rc = raise_lds_limit(fn, (int)lds, "gemm_pp")) return rc;

@@ -123,9 +123,13 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
         const int n = half ? nb - a.tiles_full : a.tiles_full, j = half ? id - a.tiles_full : id;      // walk each kind's list
         const int xcd = j & 7, qd = n >> 3, rm = n & 7;
         const int L = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (j >> 3);
-        const int tm = L / a.ntiles;
+        // column panels of a.gn N tiles (all of them: one panel), N fastest inside a panel, the panel's row tiles top to bottom
+        const int mt = half ? n / a.ntiles : (a.m_full >> 8);
+        const int per = mt * a.gn, p = L / per, r = L - p * per;
+        const int gh = a.ntiles - p * a.gn < a.gn ? a.ntiles - p * a.gn : a.gn;
+        const int tm = r / gh;
         bm0 = half ? a.m_full + tm * 128 : tm * 256;
-        bn0 = (L - tm * a.ntiles) * 256;
+        bn0 = (p * a.gn + r - tm * gh) * 256;
         return true;
     };
 
@@ -151,7 +155,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
         const int n = (row & ~31) | (((row >> 2) & 3) << 3) | (((row >> 4) & 1) << 2) | (row & 3);
         const int xrow = TLXMI_DBG(a, 8) ? ((bm0 + row) & 2047) : bm0 + row;      // (ablation bit 8: every X row from the first 2048 — L2-resident operand, timing only)
         xo = (ok && !(th && half)) ? xrow * a.x_ld * ES : OOB;      // a half-height tile has no X1
-        wo = ok ? (bn0 + n) * a.Kp_bytes : OOB;
+        wo = ok ? ((TLXMI_DBG(a, 32) ? 0 : bn0) + n) * a.Kp_bytes : OOB;      // (ablation bit 32: every tile multiplies filter rows 0 .. 255 — L2-resident filter, timing only)
     };
     char* const lbase = smem + wid * 1024;
     // (an offset that is out of range stays out of range after the small additions: x_bytes, w_bytes < 2^31)
@@ -491,6 +495,7 @@ template <typename T, int ACT, bool RES> static int launch_gs(const Gemm256Args&
     a.mtiles = (a.M + 255) / 256;
     a.ntiles = (a.Cout + 255) / 256;
     a.gn = a.ntiles;
+    if (const long g = tune_int("TLXMI_GS_PANEL", 3); g > 0 && g < a.ntiles) a.gn = (int)g;
     const size_t lds = (size_t)8 * 128 * 128 + 2 * 2048;   // two K tiles, channel tables
     const void* fn = reinterpret_cast<const void*>(&gemm_stream_kernel<T, ACT, RES>);
     if (int rc = raise_lds_limit(fn, (int)lds, "gemm_stream")) return rc;
