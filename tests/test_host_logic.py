@@ -229,6 +229,8 @@ def test_linear_tail_plan_matches_the_round_arithmetic():
         def element_size(self):
             return 2
     engine._cus[0] = 256
+    assert engine._linear_tail(50432, 768, PK(768, 768), X()) is None                 # off by default (measured slower)
+    engine.set_option("tail_splitk", True)
     try:
         assert engine._linear_tail(50432, 768, PK(768, 768), X())[0] == 170 * 256
         assert engine._linear_tail(50432, 3072, PK(3072, 768), X()) == (170 * 256, 2)
@@ -238,4 +240,5 @@ def test_linear_tail_plan_matches_the_round_arithmetic():
         with engine.shared_plan("half"):
             assert engine._linear_tail(25216, 768, PK(768, 768), X())[0] == 85 * 256
     finally:
+        engine.set_option("tail_splitk", False)
         engine._cus.pop(0, None)
