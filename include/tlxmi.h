@@ -428,6 +428,10 @@ int tlxmi_window_reverse(const void* win, const void* res, void* y, int dtype, i
  * channel blocks in the order (0,0),(1,0),(0,1),(1,1). */
 int tlxmi_patch_merge_gather(const void* x, void* y, int dtype, int B, int H, int W, int C,
                              void* stream);
+/* the same gather + LayerNorm over the 4C merged channels in one pass (swin_transformer.py:381-388: PatchMerging's
+ * cat + self.norm): y[B*(H/2)*(W/2)][4C]; gamma / beta fp32 [4C], 16-byte aligned. */
+int tlxmi_patch_merge_layernorm(const void* x, const float* gamma, const float* beta, void* y, int dtype, int B, int H,
+                                int W, int C, float eps, void* stream);
 
 /* nearest x2 upsample written at a channel offset of a wider NHWC buffer (yolov3.py:250-256:
  * interpolate(scale_factor=2) + concat).  y has pixel stride y_ld; channels [c_off, c_off+C). */

@@ -249,6 +249,24 @@ def test_patch_merge_gather(dev, dtype):
 
 
 @DT
+@pytest.mark.parametrize("shape", [(2, 8, 6, 16), (3, 14, 14, 128), (5, 28, 28, 256), (2, 6, 10, 24), (1, 4, 4, 512)], ids=lambda s: "x".join(map(str, s)))
+def test_patch_merge_layernorm(dev, dtype, shape):
+    """tlxmi_patch_merge_layernorm (swin_transformer.py:381-388): bit for bit the two launches it replaces (gather, then LayerNorm
+    over 4C), and the torch reference on the same rounded input; widths of every LayerNorm lane layout (64 .. 2048 channels)."""
+    rng = np.random.default_rng(11)
+    x = prep(rnd(rng, shape), dtype)
+    B, H, W, Cc = shape
+    g, b = rnd(rng, (4 * Cc,), 0.5) + 1.0, rnd(rng, (4 * Cc,), 0.5)
+    xd = x.to(dtype).to(dev)
+    got = E.patch_merge_layernorm(xd, g.to(dev), b.to(dev), 1e-5)
+    two = E.layernorm(E.patch_merge_gather(xd).view(B, (H // 2) * (W // 2), 4 * Cc), g.to(dev), b.to(dev), 1e-5)
+    assert got.shape == (B, (H // 2) * (W // 2), 4 * Cc) and torch.equal(got, two)
+    cat = torch.cat([x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]], -1).reshape(B, -1, 4 * Cc)
+    want = F.layer_norm(cat, (4 * Cc,), g, b, 1e-5)
+    torch.testing.assert_close(got.float().cpu(), want, **(dict(atol=1e-4, rtol=1e-4) if dtype == torch.float32 else dict(atol=4e-3, rtol=4e-3)))
+
+
+@DT
 def test_upsample_concat(dev, dtype):
     rng = np.random.default_rng(10)
     a, b = prep(rnd(rng, (1, 16, 5, 4)), dtype), prep(rnd(rng, (1, 24, 10, 8)), dtype)

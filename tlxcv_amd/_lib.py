@@ -92,6 +92,7 @@ PROTOTYPES = {
     "tlxmi_window_partition": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "tlxmi_window_reverse": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "tlxmi_patch_merge_gather": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "tlxmi_patch_merge_layernorm": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp],
     "tlxmi_upsample2x_nearest": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "tlxmi_copy_channels": [_vp, _vp, _i, _l, _i, _i, _i, _vp],
     "tlxmi_argmax_lastdim": [_vp, _i, _l, _i, _i, _vp, _vp],

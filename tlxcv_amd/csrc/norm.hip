@@ -76,14 +76,25 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
     auto load_group = [&](long r0, u32x4 (&raw)[RW][NCH], u32x4 (&rsd)[RR][RN], long (&wrow)[RW]) {
 #pragma unroll
         for (int r = 0; r < RW; ++r) {
-            wrow[r] = (wm.mode != 0 && r0 + r < rows) ? win_row(wm, r0 + r) : 0;
+            wrow[r] = ((wm.mode == 1 || wm.mode == 2) && r0 + r < rows) ? win_row(wm, r0 + r) : 0;
             const long srow = wm.mode == 2 ? wrow[r] : r0 + r;
+            long pix = 0;      // mode 3: the (0, 0) source pixel of merged row r0 + r
+            if (wm.mode == 3 && r0 + r < rows) {
+                const unsigned Wo = (unsigned)wm.W >> 1, HoWo = ((unsigned)wm.H >> 1) * Wo;
+                const unsigned ub = (unsigned)(r0 + r) / HoWo, p = (unsigned)(r0 + r) - ub * HoWo, ho = p / Wo, wo = p - ho * Wo;
+                pix = ((long)ub * wm.H + 2 * ho) * wm.W + 2 * wo;
+            }
 #pragma unroll
             for (int i = 0; i < NCH; ++i) {
                 const int ch = lane + LPR * i;
                 raw[r][i] = u32x4{0u, 0u, 0u, 0u};
                 if constexpr (HASRES) rsd[r][i] = u32x4{0u, 0u, 0u, 0u};
                 if (ch < nch && r0 + r < rows) {
+                    if (wm.mode == 3) {      // PatchMerging gather: chunk -> block q = (dh, dw) = (q & 1, q >> 1) of wm.ws chunks
+                        const int q = (ch >= wm.ws) + (ch >= 2 * wm.ws) + (ch >= 3 * wm.ws);
+                        raw[r][i] = *reinterpret_cast<const u32x4*>(x + (pix + (q & 1) * wm.W + (q >> 1)) * x_ld + (ch - q * wm.ws) * V);
+                        continue;
+                    }
                     raw[r][i] = *reinterpret_cast<const u32x4*>(x + srow * x_ld + ch * V);
                     if constexpr (HASRES) rsd[r][i] = *reinterpret_cast<const u32x4*>(res + (r0 + r) * x_ld + ch * V);
                 }
@@ -305,6 +316,21 @@ extern "C" int tlxmi_layernorm_window_partition(const void* x, const float* gamm
     const long rows = (long)B * H * W;
     if (dt == TLXMI_F16) return launch_ln<half_t>(x, gamma, beta, win, rows, C, C, C, eps, as_stream(stream), nullptr, wm);
     return launch_ln<float>(x, gamma, beta, win, rows, C, C, C, eps, as_stream(stream), nullptr, wm);
+}
+
+// PatchMerging's gather + LayerNorm(4C) in one pass (swin_transformer.py:381-388): y[B * H/2 * W/2][4C] = LN(cat(x0, x1, x2, x3))
+extern "C" int tlxmi_patch_merge_layernorm(const void* x, const float* gamma, const float* beta, void* y, int dt, int B, int H,
+                                           int W, int C, float eps, void* stream) {
+    TLXMI_REQUIRE(x && y && aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta), TLXMI_ERR_BAD_ARG, "patch_merge_layernorm: bad buffer");
+    TLXMI_REQUIRE(dt == TLXMI_F16 || dt == TLXMI_F32, TLXMI_ERR_BAD_ARG, "patch_merge_layernorm: bad dtype");
+    TLXMI_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && H % 2 == 0 && W % 2 == 0, TLXMI_ERR_BAD_ARG, "patch_merge_layernorm: H=%d W=%d must be even", H, W);
+    const int V = 16 / (int)elt_size(dt);
+    TLXMI_REQUIRE(C % V == 0, TLXMI_ERR_ALIGNMENT, "patch_merge_layernorm: C=%d must be whole 16-byte chunks", C);
+    TLXMI_REQUIRE((long)B * H * W < (1l << 31), TLXMI_ERR_UNSUPPORTED, "patch_merge_layernorm: more than 2^31 rows");
+    const WinMap wm{3, H, W, C / V, 0};
+    const long rows = (long)B * (H / 2) * (W / 2);
+    if (dt == TLXMI_F16) return launch_ln<half_t>(x, gamma, beta, y, rows, 4 * C, C, 4 * C, eps, as_stream(stream), nullptr, wm);
+    return launch_ln<float>(x, gamma, beta, y, rows, 4 * C, C, 4 * C, eps, as_stream(stream), nullptr, wm);
 }
 
 extern "C" int tlxmi_window_reverse_layernorm(const void* win, const void* res, const float* gamma, const float* beta,

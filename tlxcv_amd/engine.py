@@ -1052,6 +1052,16 @@ def window_reverse_layernorm(win, res, gamma, beta, eps, ws, shift):
     return s, y
 
 
+def patch_merge_layernorm(x, gamma, beta, eps):
+    """(B,H,W,C) -> LayerNorm over 4C of PatchMerging's 2 x 2 gather + concat, (B, H/2 * W/2, 4C), in one pass."""
+    need_gpu(x, "input")
+    B, H, W, Cc = x.shape
+    y = torch.empty((B, (H // 2) * (W // 2), 4 * Cc), dtype=x.dtype, device=x.device)
+    _lib.call("tlxmi_patch_merge_layernorm", _p(x), _p(_f32(gamma)), _p(_f32(beta)), _p(y), dt_code(x.dtype), B, H, W, Cc,
+              C.c_float(eps), _stream())
+    return y
+
+
 def patch_merge_gather(x):
     need_gpu(x, "input")
     B, H, W, Cc = x.shape

@@ -11,7 +11,7 @@ bias (+ shift mask) -> softmax -> @v -> proj -> window_reverse -> roll back -> r
   * the attention core is one fused MFMA kernel on the packed qkv matrix that adds the pre-gathered
     (heads, 49, 49) bias table and the (nW, 49, 49) shift mask in registers;
   * qkv / proj / fc1(+GELU) / fc2(+residual) are the implicit-GEMM kernel with fused epilogues;
-  * PatchMerging's strided 2x2 gather + concat is one copy kernel, then LayerNorm and the GEMM.
+  * PatchMerging's strided 2x2 gather + concat + LayerNorm is one pass (tlxmi_patch_merge_layernorm), then the GEMM.
 Quirks kept on purpose: the -100.0 (not -inf) mask, and the PatchMerging reduction bias (:369-370).
 """
 
@@ -199,6 +199,9 @@ class PatchMerging(nn.Module):
         B, L, C = x.shape
         assert L == H * W, 'input feature has wrong size'
         assert H % 2 == 0 and W % 2 == 0, 'x size ({}*{}) are not even.'.format(H, W)
+        if isinstance(self.norm, nn.LayerNorm):      # gather + concat + norm in one pass (:381-388)
+            g = E.patch_merge_layernorm(x.view(B, H, W, C), self.norm.gamma.detach(), self.norm.beta.detach(), self.norm.epsilon)
+            return self.reduction.run(g)                                           # :389
         g = E.patch_merge_gather(x.view(B, H, W, C)).view(B, H * W // 4, 4 * C)    # :381-387
         return self.reduction.run(self.norm(g))                                    # :388-389
 

@@ -1,19 +1,38 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch, tlxcv_amd
-from tlxcv_amd import _lib, engine as E
+import torch
+import tlxcv_amd
+from tlxcv_amd import seeded, models, engine as E
 dev = torch.device("cuda:0")
-g = torch.Generator().manual_seed(0)
-for B in (256, 128):
-    qkv = torch.randn((B, 197, 2304), generator=g).half().to(dev)
-    res = {}
-    for rep in range(5):
-        for dbg in ("0", "1", "2", "3"):
-            with _lib.tuning(TLXMI_ATTN_DBG=dbg):
-                E.attention(qkv, 12, 0.125)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(10): E.attention(qkv, 12, 0.125)
-                e1.record(); torch.cuda.synchronize()
-                res.setdefault(dbg, []).append(e0.elapsed_time(e1) * 100)
-    print(f"attention B={B}: " + "  ".join(f"dbg{d} {sorted(v)[2]:6.1f} us" for d, v in res.items()), flush=True)
+tlxcv_amd.set_precision("fp16")
+m = models.swintransformer_base_patch4_window7_224()
+m.load_dict(seeded.fill(seeded.shapes_of(m), 1))
+m = m.to(dev).set_eval()
+bs = 128
+x = torch.from_numpy(seeded.image_batch(32, 0)).to(dev).repeat(bs // 32, 1, 1, 1).contiguous()
+fused = E.patch_merge_layernorm
+def two(x, g, b, eps):
+    B, H, W, Cc = x.shape
+    return E.layernorm(E.patch_merge_gather(x).view(B, (H // 2) * (W // 2), 4 * Cc), E._f32(g), E._f32(b), eps)
+graphs = {}
+for name, fn in (("fused", fused), ("two", two)):
+    E.patch_merge_layernorm = fn
+    for _ in range(3):
+        m(x)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        y = m(x)
+    g.replay(); torch.cuda.synchronize()
+    graphs[name] = (g, y.clone())
+print("equal outputs:", torch.equal(graphs["fused"][1], graphs["two"][1]))
+ts = {k: [] for k in graphs}
+for rep in range(9):
+    for k, (g, _) in graphs.items():
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            g.replay()
+        e1.record(); torch.cuda.synchronize()
+        ts[k].append(e0.elapsed_time(e1) / 10)
+print("  ".join(f"{k}: {sorted(t)[len(t)//2]:.3f} ms" for k, t in ts.items()))
