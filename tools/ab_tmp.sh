@@ -1,3 +1,3 @@
-bash tools/refresh_profiles.sh
-for wl in resnet50 vit_b16 swin_b; do bash tools/pmc_util.sh $wl > gpurun_out/util_$wl.log 2>&1; tail -n 3 gpurun_out/util_$wl.log | cut -c1-200; done
-python bench.py > gpurun_out/bench.log 2>&1; tail -n 1 gpurun_out/bench.log | cut -c1-300
+python tools/ab_graph.py TLXMI_DEBUG 0,16 vit_b16 256 2>&1 | grep batch
+python tools/ab_graph.py TLXMI_DEBUG 0,16 vit_b16 256 2>&1 | grep batch
+python tools/ab_graph.py TLXMI_DEBUG 0,16 swin_b 128 2>&1 | grep batch
