@@ -99,6 +99,12 @@ int tlxmi_nchw_to_nhwc(const void* src, int src_dtype, void* dst, int dst_dtype,
  * (K 448 -> 256, 2048 -> 768, 128 -> 48 halves) with filters re-indexed once on the host side. */
 int tlxmi_nchw_to_nhwc_s2d(const void* src, int src_dtype, void* dst, int dst_dtype, int N, int C, int H,
                            int W, int b, int Cpad, void* stream);
+/* Patch rows for a patch-embedding conv run as a Linear (vision_transformer.py:197-204 proj + :321-323 cat / pos_embed):
+ * dst [N][lead + (H/ps)(W/ps)][C*ps*ps], element (c*ps + ky)*ps + kx of patch (py, px) = src[n][c][py*ps+ky][px*ps+kx] (the
+ * conv filter [Cout][C][ps][ps] flattened is the Linear weight); the `lead` rows in front of each image's patches (the cls
+ * token's slot) are zero.  ps a multiple of 8; src / dst 16-byte aligned. */
+int tlxmi_patchify(const void* src, int src_dtype, void* dst, int dst_dtype, int N, int C, int H, int W, int ps,
+                   int lead, void* stream);
 /* dst: [N][C][H][W] contiguous; src: NHWC with pixel stride ld (>= C). */
 int tlxmi_nhwc_to_nchw(const void* src, int src_dtype, int ld, void* dst, int dst_dtype, int N, int C,
                        int H, int W, void* stream);

@@ -267,6 +267,25 @@ def test_patch_merge_layernorm(dev, dtype, shape):
 
 
 @DT
+@pytest.mark.parametrize("shape,ps,lead", [((2, 3, 32, 48), 16, 1), ((3, 3, 64, 64), 32, 0), ((1, 4, 16, 24), 8, 2), ((5, 3, 224, 224), 16, 1)],
+                         ids=lambda v: "x".join(map(str, v)) if isinstance(v, tuple) else str(v))
+def test_patchify(dev, dtype, shape, ps, lead):
+    """tlxmi_patchify: patch rows in the flattened-filter order, zero rows in front of each image — exact (a copy + one rounding);
+    and conv2d(x, w, stride = ps) == rows @ w.reshape(Cout, -1).T, the identity vision_transformer.py's PatchEmbed path relies on."""
+    rng = np.random.default_rng(12)
+    x = rnd(rng, shape)
+    N, Cc, H, W = shape
+    got = E.patchify(x.to(dev), ps, lead, dtype)
+    Hp, Wp = H // ps, W // ps
+    want = x.reshape(N, Cc, Hp, ps, Wp, ps).permute(0, 2, 4, 1, 3, 5).reshape(N, Hp * Wp, Cc * ps * ps).to(dtype)
+    assert got.shape == (N, lead + Hp * Wp, Cc * ps * ps)
+    assert torch.equal(got[:, lead:].cpu(), want) and not got[:, :lead].any()
+    w = rnd(rng, (8, Cc, ps, ps))
+    torch.testing.assert_close(F.conv2d(want.float().reshape(N, Hp, Wp, Cc, ps, ps).permute(0, 3, 1, 4, 2, 5).reshape(N, Cc, H, W), w, stride=ps)
+                               .permute(0, 2, 3, 1).reshape(N, Hp * Wp, 8), want.float() @ w.reshape(8, -1).t(), atol=2e-3, rtol=2e-3)
+
+
+@DT
 def test_upsample_concat(dev, dtype):
     rng = np.random.default_rng(10)
     a, b = prep(rnd(rng, (1, 16, 5, 4)), dtype), prep(rnd(rng, (1, 24, 10, 8)), dtype)

@@ -51,6 +51,31 @@ def test_fp16_384_tracks_golden(dev, fp16_mode):
     check_fp16_logits(y, g["logits"], g["argmax"], "vit_b16_384_b1")
 
 
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+def test_patch_embedding_as_one_linear_equals_the_conv_path(dev, prec):
+    """The two arms of forward_features' patch embedding — tlxmi_patchify + ONE Linear over all token rows with the per-row
+    residual [cls + pos[0] - bias | pos[1:]] (default), and the space-to-depth conv writing rows 1.. of each image + the cls row —
+    against the golden logits and against each other."""
+    import tlxcv_amd
+    from tlxcv_amd import engine as E
+    tlxcv_amd.set_precision(prec)
+    try:
+        g = np.load(os.path.join(GOLDEN, "vit_b16_b2.npz"))
+        m = build("vit_base_patch16_224", int(g["weight_seed"]), dev)
+        x = torch.from_numpy(seeded.image_batch(2, int(g["input_seed"]))).to(dev)
+        ys = {}
+        for arm in (True, False):
+            E.set_option("patch_linear", arm)
+            ys[arm] = m(x).float().cpu().numpy()
+        tol = 1e-4 if prec == "fp32" else 3e-2
+        assert np.abs(ys[True] - ys[False]).max() <= tol
+        assert np.abs(ys[True] - g["logits"]).max() <= tol and np.abs(ys[False] - g["logits"]).max() <= tol
+        assert (ys[True].argmax(-1) == g["argmax"]).all() and (ys[False].argmax(-1) == g["argmax"]).all()
+    finally:
+        E.set_option("patch_linear", True)
+        tlxcv_amd.set_precision("fp16")
+
+
 def test_wrong_image_size_asserts(dev, fp16_mode):
     m = build("vit_base_patch16_224", 2, dev)
     with pytest.raises(AssertionError, match="doesn't match"):      # vision_transformer.py:217-219

@@ -675,6 +675,85 @@ extern "C" int tlxmi_nchw_to_nhwc(const void* src, int sdt, void* dst, int ddt, 
     return check_launch("nchw_to_nhwc");
 }
 
+// Patch rows for a patch-embedding conv run as a Linear (vision_transformer.py:197-204, 321-323): src [N][C][H][W] ->
+// dst [N][lead + (H/ps)(W/ps)][C*ps*ps], element (c*ps + ky)*ps + kx of patch (py, px) = src[n][c][py*ps + ky][px*ps + kx] — the
+// order of the conv filter [Cout][C][ps][ps] flattened, so the filter IS the Linear weight.  The `lead` rows in front of every
+// image's patches (the cls token's slot) are zero.  A thread moves 8 elements; a wave = ps/8 x ps x (512 / ps^2) items = whole
+// 128-byte lines of the image on the read side (two neighbouring patches' 64 B of one image row) and 512 contiguous bytes per
+// patch and channel on the write side.
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void patchify_kernel(const TS* __restrict__ src, TD* __restrict__ dst, int N, int C, int H, int W,
+                                                       int ps, int lead, long items, long zero_items) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int Hp = H / ps, Wp = W / ps, G = ps >> 3, K = C * ps * ps, rows = lead + Hp * Wp;
+    if (i >= items) {      // the zero rows: K / 8 chunks per lead row
+        const long z = i - items;
+        if (z >= zero_items) return;
+        const int kc = K >> 3;
+        const long r = z / kc;
+        const int q = (int)(z - r * kc);
+        const long n = r / lead;
+        const int l = (int)(r - n * lead);
+        TD* d = dst + (n * rows + l) * K + 8 * q;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d[e] = (TD)0.f;
+        return;
+    }
+    // i = ((((n * Hp + py) * C + c) * Wp + px) * ps + ky) * G + g
+    long t = i;
+    const int g = (int)(t % G); t /= G;
+    const int ky = (int)(t % ps); t /= ps;
+    const int px = (int)(t % Wp); t /= Wp;
+    const int c = (int)(t % C); t /= C;
+    const int py = (int)(t % Hp);
+    const long n = t / Hp;
+    const TS* sp = src + ((n * C + c) * H + py * ps + ky) * (long)W + px * ps + 8 * g;
+    TD* dp = dst + (n * rows + lead + py * Wp + px) * K + (c * ps + ky) * ps + 8 * g;
+    float v[8];
+    if constexpr (sizeof(TS) == 4) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(sp), b = *reinterpret_cast<const f32x4*>(sp + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
+    } else {
+        const half8v h = *reinterpret_cast<const half8v*>(sp);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)h[e];
+    }
+    if constexpr (sizeof(TD) == 2) {
+        half8v h;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h[e] = (half_t)v[e];
+        *reinterpret_cast<half8v*>(dp) = h;
+    } else {
+        *reinterpret_cast<f32x4*>(dp) = f32x4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(dp + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    }
+}
+
+extern "C" int tlxmi_patchify(const void* src, int sdt, void* dst, int ddt, int N, int C, int H, int W, int ps, int lead,
+                              void* stream) {
+    TLXMI_REQUIRE(src && dst, TLXMI_ERR_BAD_ARG, "patchify: null buffer");
+    TLXMI_REQUIRE(DT_OK(sdt) && DT_OK(ddt), TLXMI_ERR_BAD_ARG, "patchify: bad dtype");
+    TLXMI_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && ps >= 8 && ps % 8 == 0 && H % ps == 0 && W % ps == 0 && lead >= 0,
+                  TLXMI_ERR_BAD_ARG, "patchify: H=%d W=%d must be multiples of the patch %d, itself a multiple of 8", H, W, ps);
+    TLXMI_REQUIRE(aligned16(src) && aligned16(dst), TLXMI_ERR_ALIGNMENT, "patchify: buffers must be 16-byte aligned");
+    const long items = (long)N * C * (H / ps) * (W / ps) * ps * (ps / 8);
+    const long zero_items = (long)N * lead * ((long)C * ps * ps / 8);
+    const long blocks = (items + zero_items + 255) / 256;
+    TLXMI_REQUIRE(blocks < (1l << 31), TLXMI_ERR_UNSUPPORTED, "patchify: too many elements");
+    const dim3 g((unsigned)blocks), blk(256);
+    hipStream_t st = as_stream(stream);
+    if (sdt == TLXMI_F32 && ddt == TLXMI_F16)
+        hipLaunchKernelGGL((patchify_kernel<float, half_t>), g, blk, 0, st, (const float*)src, (half_t*)dst, N, C, H, W, ps, lead, items, zero_items);
+    else if (sdt == TLXMI_F32 && ddt == TLXMI_F32)
+        hipLaunchKernelGGL((patchify_kernel<float, float>), g, blk, 0, st, (const float*)src, (float*)dst, N, C, H, W, ps, lead, items, zero_items);
+    else if (sdt == TLXMI_F16 && ddt == TLXMI_F16)
+        hipLaunchKernelGGL((patchify_kernel<half_t, half_t>), g, blk, 0, st, (const half_t*)src, (half_t*)dst, N, C, H, W, ps, lead, items, zero_items);
+    else
+        hipLaunchKernelGGL((patchify_kernel<half_t, float>), g, blk, 0, st, (const half_t*)src, (float*)dst, N, C, H, W, ps, lead, items, zero_items);
+    return check_launch("patchify");
+}
+
 extern "C" int tlxmi_nchw_to_nhwc_s2d(const void* src, int sdt, void* dst, int ddt, int N, int C, int H, int W, int b,
                                       int Cpad, void* stream) {
     TLXMI_REQUIRE(src && dst, TLXMI_ERR_BAD_ARG, "nchw_to_nhwc_s2d: null buffer");

@@ -26,6 +26,8 @@ _options = {"splitk": True,       # classifier heads: K slices side by side (tlx
             "seam256": True,      # bottleneck seams with a 256-channel conv3 input (ResNet-50 layer3, 14 x 14) fused too
             "two_streams": True,  # large batches as two half batches on two HIP streams (two_streams(), below)
             "conv_splitk": True,  # convs with few pixels and a long K on K slices (tlxmi_conv2d_splitk)
+            "patch_linear": True, # ViT patch embedding as one Linear over all token rows (tlxmi_patchify + the persistent GEMM); off = the
+                                  # space-to-depth implicit GEMM writing rows 1.. of each image (the A/B and the parity tests' other arm)
             "tail_splitk": False} # Linear layers: the rows of a short last round of 256 x 256 tiles on K slices (_linear_tail): built,
                                   # parity-green, measured a LOSS on the ViT-B/16 forward (10.63 -> 11.61 ms for every K >= 768,
                                   # 10.91 for fc2 only: two more launches + the fp32 partial planes cost more than the idle round)
@@ -264,6 +266,22 @@ def nchw_to_nhwc_s2d(x, b, dtype=None):
     x = x.contiguous()
     y = torch.empty((N, H // b, W // b, cpad), dtype=dtype, device=x.device)
     _lib.call("tlxmi_nchw_to_nhwc_s2d", _p(x), dt_code(x.dtype), _p(y), dt_code(dtype), N, Cc, H, W, b, cpad, _stream())
+    return y
+
+
+def patchify(x, ps, lead=0, dtype=None):
+    """(N,C,H,W) -> (N, lead + (H/ps)(W/ps), C*ps*ps) patch rows in the order of the flattened conv filter [Cout][C][ps][ps]; the `lead`
+    rows in front of each image's patches are zero (tlxmi_patchify)."""
+    need_gpu(x, "input")
+    dtype = dtype or _precision
+    N, Cc, H, W = x.shape
+    if ps % 8 or H % ps or W % ps:
+        raise RuntimeError(f"patchify needs a patch size that is a multiple of 8 and divides H, W; got {ps} on {H}x{W}")
+    if x.dtype not in (torch.float16, torch.float32):
+        x = x.float()
+    x = x.contiguous()
+    y = torch.empty((N, lead + (H // ps) * (W // ps), Cc * ps * ps), dtype=dtype, device=x.device)
+    _lib.call("tlxmi_patchify", _p(x), dt_code(x.dtype), _p(y), dt_code(dtype), N, Cc, H, W, ps, lead, _stream())
     return y
 
 

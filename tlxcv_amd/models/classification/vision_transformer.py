@@ -3,9 +3,11 @@
 Same factories / constructor arguments / parameter tree as the reference
 (tlxcv/models/classification/vision_transformer.py:64-447).  Forward differences (all fusions, no
 change of arithmetic):
-  * PatchEmbed conv (k=s=patch, bias) writes straight into rows 1..P of the (B, 1+P, D) token
-    matrix with `+ pos_embed[1:]` in its epilogue (reference: conv -> flatten -> transpose ->
-    concat cls -> add pos_embed, :206-220, :321-323); row 0 is the constant cls_token+pos_embed[0].
+  * PatchEmbed conv + flatten + transpose + concat cls + add pos_embed (:206-220, :321-323) is ONE Linear over all B * (1 + P)
+    token rows: patch rows in the flattened filter's order with a zero row in each image's cls slot (tlxmi_patchify), the conv
+    filter as the weight, the per-row residual [cls + pos[0] - bias | pos[1:]] (round 4; patch sizes that are multiples of 8).
+    Otherwise (and with set_option("patch_linear", False)): the conv on a space-to-depth image writes straight into rows 1..P of
+    the token matrix with `+ pos_embed[1:]` in its epilogue, and row 0 is the constant cls_token + pos_embed[0].
   * Attention (:112-123) = qkv GEMM(+bias) -> one fused softmax(q k^T * scale) v kernel on the
     packed qkv matrix -> proj GEMM with bias and the residual add of Block.forward (:173) fused.
   * Mlp (:81-87) = fc1 GEMM with bias+exact-erf GELU epilogue -> fc2 GEMM with bias + residual (:174).
@@ -185,6 +187,28 @@ class VisionTransformer(nn.Module):
         row0 = self._cached("row0", lambda: (self.cls_token.detach()[0, 0] + self.pos_embed.detach()[0, 0])
                             .to(dt).contiguous())                                                         # (D,)
         tok = torch.empty((B, P + 1, D), dtype=dt, device=x.device)
+        ps, conv = pe.patch_size[0], pe.proj
+        if (E.option("patch_linear") and self.data_format == "channels_first" and pe.patch_size[0] == pe.patch_size[1] and ps % 8 == 0 and B * (P + 1) < (1 << 20)
+                and not x.permute(0, 2, 3, 1).is_contiguous() and (x.shape[1] * ps * ps) % 8 == 0
+                and tuple(conv.stride) == tuple(pe.patch_size) and tuple(conv.padding) == (0, 0) and not conv.same):
+            # The patch-embedding conv as ONE Linear over all B * (1 + P) token rows (vision_transformer.py:197-204, 321-323): patch
+            # rows in the flattened filter's order with a zero row in the cls slot (tlxmi_patchify), the filter as the Linear weight,
+            # and a per-row residual [cls + pos[0] - bias | pos[1:]] — the zero row yields bias + (cls + pos[0] - bias).  It runs on the
+            # persistent GEMM like proj (same shape) instead of the generic implicit GEMM: ViT-B/16 batch 256 forward 11.01 -> 10.93 ms.
+            pk = conv._cached(("patch_linear", dt), lambda: E.PackedFilter(conv.filters.detach().reshape(D, -1).contiguous(), dt))
+            bias = conv._cached("bias", lambda: E._f32(conv.biases)) if conv.biases is not None else None
+
+            def rows_res():
+                first = self.cls_token.detach()[0, 0].float() + self.pos_embed.detach()[0, 0].float()
+                if conv.biases is not None:
+                    first = first - conv.biases.detach().float()
+                one = torch.cat((first[None], self.pos_embed.detach()[0, 1:].float()), 0).to(dt)      # (1 + P, D)
+                return one[None].expand(B, P + 1, D).contiguous()
+            res = self._cached(("patch_res", B, dt), rows_res, deps=(conv,))
+            E.linear(E.patchify(x, ps, 1, dt), pk, bias, res=res, out=tok)
+            for blk in self.blocks:
+                blk.run_inplace(tok)
+            return E.layernorm_rows(tok, B, D, (P + 1) * D, self.norm.gamma.detach(), self.norm.beta.detach(), self.norm.epsilon)
         # rows 1..P: conv + bias + pos_embed[1:]   (vision_transformer.py:206-220, 321-323)
         kw = dict(res=pos, out=tok[:, 1:], out_ld=D, y_nstride=(P + 1) * D, res_bcast=True, res_ld=D)
         fold = 4 if pe.patch_size[0] % 4 == 0 else (2 if pe.patch_size[0] % 2 == 0 else 0)
