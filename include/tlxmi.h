@@ -105,6 +105,12 @@ int tlxmi_nchw_to_nhwc_s2d(const void* src, int src_dtype, void* dst, int dst_dt
  * token's slot) are zero.  ps a multiple of 8; src / dst 16-byte aligned. */
 int tlxmi_patchify(const void* src, int src_dtype, void* dst, int dst_dtype, int N, int C, int H, int W, int ps,
                    int lead, void* stream);
+/* Swin's patch embedding in one pass (swin_transformer.py:471-505: Conv2d(3 -> D, kernel 4, stride 4) -> flatten -> transpose ->
+ * LayerNorm(D)).  x [N][3][H][W] fp32 / fp16; w [D][64] fp16 with k = 16 c + 4 ky + kx for k < 48 and zeros above (the conv filter
+ * [D][3][4][4] flattened and padded); bias / gamma / beta fp32 [D] or null (gamma == beta == null: no LayerNorm); y [N*H/4*W/4][D]
+ * fp16.  D in {96, 128, 192, 256}; H, W multiples of 4; all buffers 16-byte aligned. */
+int tlxmi_patch_embed4(const void* x, int x_dtype, const void* w, const float* bias, const float* gamma,
+                       const float* beta, void* y, int N, int H, int W, int D, float eps, void* stream);
 /* dst: [N][C][H][W] contiguous; src: NHWC with pixel stride ld (>= C). */
 int tlxmi_nhwc_to_nchw(const void* src, int src_dtype, int ld, void* dst, int dst_dtype, int N, int C,
                        int H, int W, void* stream);

@@ -285,6 +285,29 @@ def test_patchify(dev, dtype, shape, ps, lead):
                                .permute(0, 2, 3, 1).reshape(N, Hp * Wp, 8), want.float() @ w.reshape(8, -1).t(), atol=2e-3, rtol=2e-3)
 
 
+@pytest.mark.parametrize("D", [96, 128, 192, 256])
+@pytest.mark.parametrize("shape,norm,xdt", [((2, 3, 32, 48), True, torch.float32), ((3, 3, 224, 224), True, torch.float32),
+                                            ((1, 3, 8, 12), False, torch.float32), ((2, 3, 56, 40), True, torch.float16)],
+                         ids=["2x32x48", "3x224x224", "1x8x12-nonorm", "2x56x40-fp16in"])
+def test_swin_patch_embedding_in_one_pass(dev, fp16_mode, D, shape, norm, xdt):
+    """tlxmi_patch_embed4 (swin_transformer.py:471-505: conv 4 x 4 / 4 + bias -> tokens -> LayerNorm) against torch in fp32 on the
+    fp16-rounded image and filter; a token count that is not a multiple of the 16-token wave tile; reproducible."""
+    rng = np.random.default_rng(13)
+    x = rnd(rng, shape).to(xdt)
+    w, b = rnd(rng, (D, 3, 4, 4), 0.3), rnd(rng, (D,), 0.5)
+    g, be = rnd(rng, (D,), 0.5) + 1.0, rnd(rng, (D,), 0.5)
+    w64 = E.patch_embed4_filter(w.to(dev))
+    assert w64.shape == (D, 64) and not w64[:, 48:].any()
+    got = E.patch_embed4(x.to(dev), w64, b.to(dev), g.to(dev) if norm else None, be.to(dev) if norm else None, 1e-5)
+    N, _, H, W = shape
+    assert got.shape == (N, (H // 4) * (W // 4), D) and got.dtype == torch.float16
+    want = F.conv2d(x.half().float(), w.half().float(), b, stride=4).flatten(2).transpose(1, 2)
+    if norm:
+        want = F.layer_norm(want, (D,), g, be, 1e-5)
+    torch.testing.assert_close(got.float().cpu(), want, atol=6e-3, rtol=6e-3)
+    assert torch.equal(E.patch_embed4(x.to(dev), w64, b.to(dev), g.to(dev) if norm else None, be.to(dev) if norm else None, 1e-5), got)
+
+
 @DT
 def test_upsample_concat(dev, dtype):
     rng = np.random.default_rng(10)

@@ -60,6 +60,7 @@ PROTOTYPES = {
     "tlxmi_nchw_to_nhwc": [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "tlxmi_nchw_to_nhwc_s2d": [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "tlxmi_patchify": [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "tlxmi_patch_embed4": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
     "tlxmi_nhwc_to_nchw": [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp],
     "tlxmi_pack_filter": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     "tlxmi_fold_bn": [_vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp],

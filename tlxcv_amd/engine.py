@@ -28,6 +28,7 @@ _options = {"splitk": True,       # classifier heads: K slices side by side (tlx
             "conv_splitk": True,  # convs with few pixels and a long K on K slices (tlxmi_conv2d_splitk)
             "patch_linear": True, # ViT patch embedding as one Linear over all token rows (tlxmi_patchify + the persistent GEMM); off = the
                                   # space-to-depth implicit GEMM writing rows 1.. of each image (the A/B and the parity tests' other arm)
+            "patch_embed4": True, # Swin patch embedding (conv 4 x 4 / 4 + LayerNorm) as one pass over the NCHW image (tlxmi_patch_embed4, fp16)
             "tail_splitk": False} # Linear layers: the rows of a short last round of 256 x 256 tiles on K slices (_linear_tail): built,
                                   # parity-green, measured a LOSS on the ViT-B/16 forward (10.63 -> 11.61 ms for every K >= 768,
                                   # 10.91 for fc2 only: two more launches + the fp32 partial planes cost more than the idle round)
@@ -282,6 +283,29 @@ def patchify(x, ps, lead=0, dtype=None):
     x = x.contiguous()
     y = torch.empty((N, lead + (H // ps) * (W // ps), Cc * ps * ps), dtype=dtype, device=x.device)
     _lib.call("tlxmi_patchify", _p(x), dt_code(x.dtype), _p(y), dt_code(dtype), N, Cc, H, W, ps, lead, _stream())
+    return y
+
+
+def patch_embed4_filter(w_oihw):
+    """Conv filter (D, 3, 4, 4) -> the (D, 64) fp16 image tlxmi_patch_embed4 reads: k = 16 c + 4 ky + kx, zeros above 48."""
+    w = _f32(w_oihw)
+    D = w.shape[0]
+    out = torch.zeros((D, 64), dtype=torch.float16, device=w.device)
+    out[:, :48] = w.reshape(D, 48).to(torch.float16)
+    return out
+
+
+def patch_embed4(x, w64, bias, gamma, beta, eps):
+    """(N,3,H,W) fp32 / fp16 -> (N, H/4 * W/4, D) fp16 = LayerNorm(conv4x4/4(x) + bias) (no LayerNorm when gamma is None), one pass."""
+    need_gpu(x, "input")
+    if x.dtype not in (torch.float16, torch.float32):
+        x = x.float()
+    x = x.contiguous()
+    N, Cc, H, W = x.shape
+    D = w64.shape[0]
+    y = torch.empty((N, (H // 4) * (W // 4), D), dtype=torch.float16, device=x.device)
+    _lib.call("tlxmi_patch_embed4", _p(x), dt_code(x.dtype), _p(w64), _p(_f32(bias)), _p(_f32(gamma)), _p(_f32(beta)), _p(y), N, H, W, D,
+              C.c_float(eps), _stream())
     return y
 
 

@@ -246,6 +246,16 @@ class PatchEmbed(nn.Module):
         self.norm = layer_norm(embed_dim) if layer_norm is not None else None
 
     def forward(self, x):
+        conv, D = self.proj, self.embed_dim
+        if (E.option("patch_embed4") and E.precision() == torch.float16 and tuple(self.patch_size) == (4, 4) and self.in_chans == 3
+                and D in (96, 128, 192, 256) and x.dim() == 4 and x.shape[2] % 4 == 0 and x.shape[3] % 4 == 0 and x.dtype in (torch.float16, torch.float32)
+                and not x.permute(0, 2, 3, 1).is_contiguous() and (self.norm is None or isinstance(self.norm, nn.LayerNorm))):
+            # conv + flatten + transpose + norm (:498-504) in one pass over the image: the layer is HBM traffic only
+            w64 = conv._cached("pe4", lambda: E.patch_embed4_filter(conv.filters))
+            bias = conv._cached("bias", lambda: E._f32(conv.biases)) if conv.biases is not None else None
+            if self.norm is None:
+                return E.patch_embed4(x, w64, bias, None, None, 0.0)
+            return E.patch_embed4(x, w64, bias, self.norm.gamma.detach(), self.norm.beta.detach(), self.norm.epsilon)
         if self.patch_size[0] % 4 == 0 and not x.permute(0, 2, 3, 1).is_contiguous():
             y = self.proj.run_stem(x, 4)                                           # 4x4/4 conv == 1x1 conv on 48 folded channels
         else:
