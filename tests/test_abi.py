@@ -68,6 +68,37 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     assert lib.tlxmi_packed_filter_bytes(0, 3, 7, 7, 0) == 0
 
 
+def test_round4_entry_points_reject_bad_arguments_without_a_gpu():
+    """tlxmi_patchify / tlxmi_patch_embed4 / tlxmi_patch_merge_layernorm validate before any HIP call: null and misaligned buffers,
+    sizes the kernels' index arithmetic does not cover, dtypes — each with its own error code and message."""
+    from tlxcv_amd import _lib
+    lib = _lib.load()
+    buf = (ctypes.c_char * 4096)()
+    base = ctypes.addressof(buf)
+    base += (-base) % 16
+    p, q = ctypes.c_void_p(base), ctypes.c_void_p(base + 2048)
+    odd = ctypes.c_void_p(base + 8)
+    F16, F32 = 0, 1
+    # patchify(src, sdt, dst, ddt, N, C, H, W, ps, lead, stream)
+    assert lib.tlxmi_patchify(None, F32, q, F16, 1, 3, 32, 32, 16, 1, None) == -1 and b"null" in lib.tlxmi_last_error()
+    assert lib.tlxmi_patchify(p, F32, q, F16, 1, 3, 32, 32, 12, 1, None) == -1 and b"multiple of 8" in lib.tlxmi_last_error()
+    assert lib.tlxmi_patchify(p, F32, q, F16, 1, 3, 30, 32, 16, 1, None) == -1
+    assert lib.tlxmi_patchify(p, 7, q, F16, 1, 3, 32, 32, 16, 1, None) == -1 and b"dtype" in lib.tlxmi_last_error()
+    assert lib.tlxmi_patchify(odd, F32, q, F16, 1, 3, 32, 32, 16, 1, None) == -3 and b"aligned" in lib.tlxmi_last_error()
+    # patch_embed4(x, xdt, w, bias, gamma, beta, y, N, H, W, D, eps, stream)
+    f = ctypes.c_float(1e-5)
+    assert lib.tlxmi_patch_embed4(None, F32, p, None, None, None, q, 1, 8, 8, 128, f, None) == -1
+    assert lib.tlxmi_patch_embed4(p, F32, p, None, None, None, q, 1, 8, 10, 128, f, None) == -1 and b"multiples of 4" in lib.tlxmi_last_error()
+    assert lib.tlxmi_patch_embed4(p, F32, p, None, p, None, q, 1, 8, 8, 128, f, None) == -1        # gamma without beta
+    assert lib.tlxmi_patch_embed4(p, F32, p, None, None, None, q, 1, 8, 8, 100, f, None) == -2 and b"D=100" in lib.tlxmi_last_error()
+    assert lib.tlxmi_patch_embed4(p, F32, p, odd, None, None, q, 1, 8, 8, 128, f, None) == -1      # misaligned bias
+    # patch_merge_layernorm(x, gamma, beta, y, dt, B, H, W, C, eps, stream)
+    assert lib.tlxmi_patch_merge_layernorm(None, p, p, q, F16, 1, 4, 4, 16, f, None) == -1
+    assert lib.tlxmi_patch_merge_layernorm(p, p, p, q, F16, 1, 5, 4, 16, f, None) == -1 and b"even" in lib.tlxmi_last_error()
+    assert lib.tlxmi_patch_merge_layernorm(p, p, p, q, F16, 1, 4, 4, 12, f, None) == -3 and b"16-byte" in lib.tlxmi_last_error()
+    assert lib.tlxmi_patch_merge_layernorm(p, p, p, q, 9, 1, 4, 4, 16, f, None) == -1
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from tlxcv_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)
