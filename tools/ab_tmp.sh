@@ -1,4 +1,3 @@
-python -m pytest tests/test_ops_gpu.py -q -k "patch_embedding" 2>&1 | tail -n 5
-python -m pytest tests/test_swin_gpu.py tests/test_models_gpu.py -q -k "swin" 2>&1 | tail -n 3
-python tools/ab_graph.py opt:patch_embed4 0,1 swin_b 128 2>&1 | grep batch
-python tools/ab_graph.py opt:patch_embed4 0,1 swin_b 128 2>&1 | grep batch
+bash tools/refresh_profiles.sh
+for wl in resnet50 vit_b16 swin_b; do bash tools/pmc_util.sh $wl > gpurun_out/util_$wl.log 2>&1; tail -n 2 gpurun_out/util_$wl.log | cut -c1-200; done
+python bench.py > gpurun_out/bench.log 2>&1; tail -n 1 gpurun_out/bench.log | cut -c1-300

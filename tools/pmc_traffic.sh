@@ -24,8 +24,8 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             if row["Counter_Name"] != c:
                 continue
             s += float(row["Counter_Value"]); k += 1      # every kernel of the run: all of them are forwards of the model
-            if "to_nhwc_s2d" in row["Kernel_Name"]:
-                f += 1          # one layout transform per forward and stream: counts the forwards of the run
+            if any(m in row["Kernel_Name"] for m in ("to_nhwc_s2d", "patchify_kernel", "patch_embed4_kernel")):
+                f += 1          # one layout transform / patch pass per forward and stream: counts the forwards of the run
     tot[c] = s; n[c] = k; fwd[c] = f
 # ResNet-50 / ViT-B/16 (batch 256) and Swin-B (batch 128) run as two half batches on two streams (engine.two_streams): two
 # transforms a forward
