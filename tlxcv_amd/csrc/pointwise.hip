@@ -134,31 +134,47 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_s2d_rows_kernel(const TS* __
 
 // The RGB stem case (b = 2, C = 3, fp32 image, W even): per (channel, row parity) one 8-byte load brings the two
 // horizontal neighbours, six loads per output pixel instead of twelve, consecutive lanes read consecutive 8 bytes.
-template <typename TD>
-__global__ __launch_bounds__(128) void nchw3_to_nhwc_s2d2_kernel(const float* __restrict__ src, TD* __restrict__ dst, int H, int W,
-                                                               int Cpad, int cb) {
+// A thread makes PPT output pixels 256 apart in the flattened (image, row, column) order — all 12 / 24 loads in flight before the
+// first conversion, every lane busy, 8 KB of contiguous output per workgroup and pass (round 4: one 112-pixel row per 128-thread
+// workgroup ran 2.4 TB/s on 128 images; this form: tools/stem_micro.py).
+template <typename TD, int PPT>
+__global__ __launch_bounds__(256) void nchw3_to_nhwc_s2d2_kernel(const float* __restrict__ src, TD* __restrict__ dst, int H, int W,
+                                                               int Cpad, long pixels) {
     constexpr int V = Chunk<TD>::N;
     const int H2 = H >> 1, W2 = W >> 1;
-    // one output row (or a 128-pixel piece of it) per workgroup: image / row indices are scalar arithmetic
-    const int row = blockIdx.x / cb, w2 = (blockIdx.x - row * cb) * 128 + threadIdx.x;   // row = n*H2 + h2
-    if (w2 >= W2) return;
-    const int n = row / H2, h2 = row - n * H2;
     const long HW = (long)H * W;
-    const float* sp = src + (long)n * 3 * HW + (long)(2 * h2) * W + 2 * w2;
-    float v16[16];
+    const unsigned per_img = (unsigned)(H2 * W2);
+    const long p0 = ((long)blockIdx.x * PPT) * 256 + threadIdx.x;
+    float2 t[PPT][3][2];
 #pragma unroll
-    for (int e = 12; e < 16; ++e) v16[e] = 0.f;
+    for (int q = 0; q < PPT; ++q) {
+        const long p = p0 + 256 * q;
+        const unsigned pu = p < pixels ? (unsigned)p : 0u;      // (pixels < 2^31: entry point)
+        const unsigned n = pu / per_img, r = pu - n * per_img, h2 = r / (unsigned)W2, w2 = r - h2 * (unsigned)W2;
+        const float* sp = src + (long)n * 3 * HW + (long)(2 * h2) * W + 2 * w2;
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
+        for (int c = 0; c < 3; ++c)
 #pragma unroll
-        for (int ph = 0; ph < 2; ++ph) {
-            const float2 t = *reinterpret_cast<const float2*>(sp + c * HW + (long)ph * W);
-            v16[(ph * 2 + 0) * 3 + c] = t.x;
-            v16[(ph * 2 + 1) * 3 + c] = t.y;
-        }
-    TD* dp = dst + ((long)row * W2 + w2) * Cpad;
+            for (int ph = 0; ph < 2; ++ph) t[q][c][ph] = *reinterpret_cast<const float2*>(sp + c * HW + (long)ph * W);
+    }
 #pragma unroll
-    for (int cg = 0; cg < 16 / V; ++cg) Chunk<TD>::store(dp + cg * V, v16 + cg * V);
+    for (int q = 0; q < PPT; ++q) {
+        const long p = p0 + 256 * q;
+        if (p >= pixels) break;
+        float v16[16];
+#pragma unroll
+        for (int e = 12; e < 16; ++e) v16[e] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph) {
+                v16[(ph * 2 + 0) * 3 + c] = t[q][c][ph].x;
+                v16[(ph * 2 + 1) * 3 + c] = t[q][c][ph].y;
+            }
+        TD* dp = dst + p * Cpad;
+#pragma unroll
+        for (int cg = 0; cg < 16 / V; ++cg) Chunk<TD>::store(dp + cg * V, v16 + cg * V);
+    }
 }
 
 template <typename TS, typename TD>
@@ -767,9 +783,12 @@ extern "C" int tlxmi_nchw_to_nhwc_s2d(const void* src, int sdt, void* dst, int d
     TLXMI_REQUIRE(blocks < (1l << 31), TLXMI_ERR_UNSUPPORTED, "nchw_to_nhwc_s2d: too many rows");
     dim3 g((unsigned)blocks), blk(128);
     hipStream_t st = as_stream(stream);
-    if (sdt == TLXMI_F32 && b == 2 && C == 3 && Cpad == 16 && W % 2 == 0 && ((uintptr_t)src % 8) == 0) {
-        if (ddt == TLXMI_F16) hipLaunchKernelGGL((nchw3_to_nhwc_s2d2_kernel<half_t>), g, blk, 0, st, (const float*)src, (half_t*)dst, H, W, Cpad, cb);
-        else hipLaunchKernelGGL((nchw3_to_nhwc_s2d2_kernel<float>), g, blk, 0, st, (const float*)src, (float*)dst, H, W, Cpad, cb);
+    if (sdt == TLXMI_F32 && b == 2 && C == 3 && Cpad == 16 && W % 2 == 0 && ((uintptr_t)src % 8) == 0 && (long)N * (H / 2) * (W / 2) < (1l << 31)) {
+        constexpr int PPT = 2;
+        const long pixels = (long)N * (H / 2) * (W / 2);
+        const dim3 g2((unsigned)((pixels + 256 * PPT - 1) / (256 * PPT))), b2(256);
+        if (ddt == TLXMI_F16) hipLaunchKernelGGL((nchw3_to_nhwc_s2d2_kernel<half_t, PPT>), g2, b2, 0, st, (const float*)src, (half_t*)dst, H, W, Cpad, pixels);
+        else hipLaunchKernelGGL((nchw3_to_nhwc_s2d2_kernel<float, PPT>), g2, b2, 0, st, (const float*)src, (float*)dst, H, W, Cpad, pixels);
         return check_launch("nchw_to_nhwc_s2d");
     }
     {
