@@ -13,6 +13,7 @@ for wl in resnet50 vit_b16 swin_b; do
   cp gpurun_out/layers_$wl.txt profiles/$R/${wl}_layer_times.txt
   cp gpurun_out/traffic_$wl/traffic.json profiles/$R/traffic_$wl.json
   grep '^{"metric"' gpurun_out/prof_$wl/bench.log >> profiles/$R/bench_lines_under_rocprof.jsonl
+  [ -f gpurun_out/util_$wl/util.txt ] && cp gpurun_out/util_$wl/util.txt profiles/$R/util_$wl.txt      # tools/pmc_util.sh
 done
 if [ -f gpurun_out/bench.log ]; then
   : > profiles/$R/bench_lines.jsonl
