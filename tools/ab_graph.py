@@ -7,7 +7,7 @@ import tlxcv_amd
 from tlxcv_amd import seeded, models, engine as E, _lib
 _lib.tuning().__enter__()
 
-var, vals = sys.argv[1], sys.argv[2].split(",")
+var, vals = sys.argv[1], (sys.argv[2].split(";") if ";" in sys.argv[2] else sys.argv[2].split(","))
 wl = sys.argv[3] if len(sys.argv) > 3 else "resnet50"
 bs = int(sys.argv[4]) if len(sys.argv) > 4 else 256
 dev = torch.device("cuda:0")
