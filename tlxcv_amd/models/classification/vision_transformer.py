@@ -204,6 +204,7 @@ class VisionTransformer(nn.Module):
                     first = first - conv.biases.detach().float()
                 one = torch.cat((first[None], self.pos_embed.detach()[0, 1:].float()), 0).to(dt)      # (1 + P, D)
                 return one[None].expand(B, P + 1, D).contiguous()
+            # one (B * (1 + P), D) tensor per batch size seen, kept for the life of the model: a captured hipGraph holds its address
             res = self._cached(("patch_res", B, dt), rows_res, deps=(conv,))
             E.linear(E.patchify(x, ps, 1, dt), pk, bias, res=res, out=tok)
             for blk in self.blocks:
