@@ -142,3 +142,21 @@ def test_product_library_reads_no_environment_knob():
         with _lib.tuning(TLXMI_TILE="3") as lib:
             assert os.environ["TLXMI_TILE"] == "3" and lib.tlxmi_version() == 100 and _lib.load() is lib
         assert "TLXMI_TILE" not in os.environ and _lib.load() is not lib
+
+
+def test_product_loader_ignores_TLXMI_LIB_and_ships_no_tuning_only_kernel():
+    """the product LOADER reads no environment variable either (a fresh interpreter with TLXMI_LIB pointing somewhere
+    else still loads the in-tree libtlxmi.so), and the kernels the dispatcher never picks (gemm_w4.hip) are in the tuning flavour only."""
+    from tlxcv_amd import _lib
+    code = ("import os, tlxcv_amd._lib as L; lib = L.load(); "
+            "assert L.LIB_PATH.endswith(os.path.join('tlxcv_amd', 'libtlxmi.so')), L.LIB_PATH; "
+            "assert lib._name == L.LIB_PATH, lib._name; print('ok')")
+    env = dict(os.environ, TLXMI_LIB="/nonexistent/libtlxmi_other.so")
+    out = subprocess.check_output([sys.executable, "-c", code], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))).decode()
+    assert out.strip().endswith("ok")
+    syms = subprocess.check_output(["nm", "-C", _lib.LIB_PATH]).decode()
+    assert "gemm_w4" not in syms
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"gemm_w4" not in blob
+    if os.path.exists(_lib.TUNE_LIB_PATH):
+        assert "gemm_w4" in subprocess.check_output(["nm", "-C", _lib.TUNE_LIB_PATH]).decode()

@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("TLXMI_LIB") or os.path.join(_HERE, "libtlxmi.so")   # TLXMI_LIB: A/B two builds on one box
+LIB_PATH = os.path.join(_HERE, "libtlxmi.so")   # the product loader reads no environment variable (two builds on one box: TLXMI_TUNE_LIB
+                                                # of the tuning loader below, tools/ab_oldnew.sh)
 
 F16, F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_RELU6, ACT_LEAKY, ACT_HARDSWISH, ACT_HARDSIGMOID, ACT_GELU, ACT_SIGMOID, ACT_SILU = range(9)

@@ -863,10 +863,12 @@ template <typename T> static int dispatch(const ConvArgs& a, hipStream_t st, boo
         g.act = a.act; g.act_param = a.act_param; g.flags = a.flags; g.mtiles = g.ntiles = 0;
         g.x_bytes = a.x_bytes; g.w_bytes = a.w_bytes; g.y_bytes = a.y_bytes;
         g.res_bytes = a.res ? (unsigned)((long long)a.M * a.res_ld * (long long)sizeof(T)) : 0u;
-        if (best == 11) {
+        if (best == 11) {      // gemm_w4.hip is part of the tuning flavour only (make tune): the product never dispatches it (eff = 0)
+#ifdef TLXMI_TUNING
             g.ksteps = a.Kp_bytes / 128;
             if (gemm_w4_ok(sizeof(T) == 2 ? TLXMI_F16 : TLXMI_F32, g))
                 return launch_gemm_w4(sizeof(T) == 2 ? TLXMI_F16 : TLXMI_F32, g, st, cus);
+#endif
             best = 8;
         }
         if (best == 8) {

@@ -492,6 +492,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
 template <typename T, int ACT, bool RES> static int launch_gs(const Gemm256Args& a0, hipStream_t st, int cus) {
     Gemm256Args a = a0;
     a.debug = (int)tune_int("TLXMI_DEBUG", 0);     // ablation bits: tuning flavour only (TLXMI_DBG is `false` in the product)
+    if (const long only = tune_int("TLXMI_DEBUG_COUT", 0); only > 0 && only != a.Cout) a.debug = 0;      // ... on the launches with this Cout only
     a.mtiles = (a.M + 255) / 256;
     a.ntiles = (a.Cout + 255) / 256;
     a.gn = a.ntiles;
