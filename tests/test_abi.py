@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
 def test_version_and_error_string():
     from tlxcv_amd import _lib
     lib = _lib.load()
-    assert lib.tlxmi_version() == 100
+    assert lib.tlxmi_version() == 101
     assert isinstance(lib.tlxmi_last_error(), bytes)
 
 
@@ -140,7 +140,7 @@ def test_product_library_reads_no_environment_knob():
     if os.path.exists(_lib.TUNE_LIB_PATH):
         assert "getenv" in subprocess.check_output(["nm", "-D", "--undefined-only", _lib.TUNE_LIB_PATH]).decode()
         with _lib.tuning(TLXMI_TILE="3") as lib:
-            assert os.environ["TLXMI_TILE"] == "3" and lib.tlxmi_version() == 100 and _lib.load() is lib
+            assert os.environ["TLXMI_TILE"] == "3" and lib.tlxmi_version() == 101 and _lib.load() is lib
         assert "TLXMI_TILE" not in os.environ and _lib.load() is not lib
 
 

@@ -199,3 +199,133 @@ def test_linear_k128_filter_in_registers(dev, K, Cout, epi):
     torch.cuda.synchronize()
     torch.testing.assert_close(got.view(M, Cout).float().cpu(), want, **tol(torch.float16))
     torch.testing.assert_close(got.float(), old.float(), atol=2e-3, rtol=2e-3)
+
+
+# ---- classifier heads: few rows, large filter -> K slices side by side + deterministic reduction (tlxmi_linear_splitk, engine._linear_splits;
+# vgg.py:36-60, alexnet.py:50-60, resnet.py:234-237 — round 4 widened the rule to the ResNet 2048 -> 1000 heads at <= 512 rows)
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32], ids=["fp16", "fp32"])
+@pytest.mark.parametrize("shape,act,res", [((64, 25088, 512), E.ACT_RELU, False), ((256, 4096, 1000), E.ACT_NONE, False),
+                                           ((4, 4096, 4096), E.ACT_RELU, False), ((130, 9216, 520), E.ACT_NONE, True),
+                                           ((1, 8192, 1000), E.ACT_NONE, False), ((256, 2048, 1000), E.ACT_NONE, False),
+                                           ((128, 2048, 1000), E.ACT_NONE, False)], ids=lambda v: str(v).replace(" ", ""))
+def test_linear_splitk(dev, dtype, shape, act, res):
+    M, K, Cout = shape
+    rng = np.random.default_rng(71)
+    x = rnd(rng, (M, K))
+    w = rnd(rng, (Cout, K), (1.0 / K) ** 0.5)
+    b = rnd(rng, (Cout,), 0.2)
+    r = rnd(rng, (M, Cout)) if res else None
+    if dtype == torch.float16:
+        x, w = q16(x), q16(w)
+        r = q16(r) if r is not None else None
+    want = x @ w.t() + b
+    if r is not None:
+        want = want + r
+    if act == E.ACT_RELU:
+        want = torch.relu(want)
+    pk = E.PackedFilter(w.to(dev), dtype)
+    xd = x.to(dtype).to(dev)
+    assert E._linear_splits(M, K, pk, xd) >= 2          # the shapes above take the split path
+    got = E.linear(xd, pk, b.to(dev), r.to(dtype).to(dev) if r is not None else None, act)
+    got2 = E.linear(xd, pk, b.to(dev), r.to(dtype).to(dev) if r is not None else None, act)
+    torch.cuda.synchronize()
+    assert torch.equal(got, got2)                         # fixed summation order
+    # partial sums are fp32 in both modes: the only fp16 rounding is the final store (half an ulp of the result)
+    t = dict(atol=1e-4, rtol=1e-4) if dtype == torch.float32 else dict(atol=1e-3, rtol=1e-3)
+    torch.testing.assert_close(got.float().cpu(), want, **t)
+    if dtype == torch.float16:
+        # the split path equals the unsplit GEMM (fp32 accumulate, one rounding) to fp16 rounding of the result
+        E.set_option("splitk", False)
+        try:
+            plain = E.linear(xd, pk, b.to(dev), r.to(dtype).to(dev) if r is not None else None, act)
+        finally:
+            E.set_option("splitk", True)
+        torch.testing.assert_close(got.float().cpu(), plain.float().cpu(), atol=1e-3, rtol=1e-3)
+
+
+# ---- LayerNorm folded AROUND the Linear layers (round 5: tlxmi_linear_stats -> tlxmi_ln_finalize -> tlxmi_linear_ln; reference
+# vision_transformer.py:172-175: x = x + attn(norm1(x)); x = x + mlp(norm2(x))).  The producer's outputs must equal the plain Linear's
+# bit for bit, its row statistics the LayerNorm's, and the consumer the oracle's Linear(LayerNorm(x)) — on ragged row counts, several
+# tiles per workgroup, the half-height tail tiles, a planned half device, rows far from zero mean, gamma / beta / bias present.
+LN_CASES = [(2304, 768, 768, 2304), (12544, 512, 512, 2048), (3136 + 9, 1024, 1024, 3072), (25216, 768, 768, 3072), (25216 + 77, 3072, 768, 2304), (12544, 2048, 512, 1536), (50432, 768, 768, 768),
+            (4096 + 5, 1408, 1024, 4096)]
+
+
+@pytest.mark.parametrize("plan", [None, "half"], ids=["device", "half_device"])
+@pytest.mark.parametrize("case", LN_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_layernorm_folded_around_linears(dev, case, plan):
+    M, K, D, N2 = case
+    rng = np.random.default_rng(M % 89)
+    x = q16(rnd(rng, (M, K)))
+    w = q16(rnd(rng, (D, K), (1.0 / K) ** 0.5))
+    b = rnd(rng, (D,), 0.2)
+    r = q16(rnd(rng, (M, D)))
+    r[5] += 40.0                 # rows far from zero mean: the variance must not cancel away
+    r[M - 3] -= 25.0
+    r[M // 2, :32] *= 30.0       # one 32-channel slot that dominates its row
+    gamma = torch.from_numpy(rng.uniform(0.5, 1.5, D).astype(np.float32))
+    beta = rnd(rng, (D,), 0.3)
+    w2 = rnd(rng, (N2, D), (1.0 / D) ** 0.5)
+    b2 = rnd(rng, (N2,), 0.2)
+    eps = 1e-6
+    y_ref = x @ w.t() + b + r                                       # fp32
+    xd, rd = x.half().to(dev), r.half().to(dev)
+    pk = E.PackedFilter(w.to(dev), torch.float16)
+    with E.shared_plan(plan):
+        plain = E.linear(xd, pk, b.to(dev), res=rd)
+        y, part = E.linear_stats(xd, pk, b.to(dev), res=rd)
+        y2, part2 = E.linear_stats(xd, pk, b.to(dev), res=rd)
+        rowab = E.ln_finalize(part, D, eps)
+        prep = E.LinearLN(w2.to(dev), b2.to(dev), gamma.to(dev), beta.to(dev), torch.float16)
+        outs = {act: E.linear_ln(y, prep, rowab, act) for act in (E.ACT_NONE, E.ACT_GELU)}
+        # without a residual (the patch-embedding producer of a model whose position table is folded elsewhere)
+        y0, part0 = E.linear_stats(xd, pk, b.to(dev))
+    torch.cuda.synchronize()
+    assert torch.equal(y, y2) and torch.equal(part, part2)          # bit-reproducible
+    # the plain Linear of the dispatcher (possibly other tiles, another summation order): equal to rounding
+    torch.testing.assert_close(y.float(), plain.float(), atol=4e-3, rtol=4e-3)
+    torch.testing.assert_close(y.float().cpu(), y_ref, **tol(torch.float16))
+    torch.testing.assert_close(y0.float().cpu(), x @ w.t() + b, **tol(torch.float16))
+    # partial sums: (sum, sum of squares) of the fp32 values before the store's rounding, per 32-channel slot
+    slots = y_ref.view(M, D // 32, 32)
+    want_s, want_q = slots.sum(-1).t().contiguous(), (slots * slots).sum(-1).t().contiguous()
+    sc = float(y_ref.abs().max())
+    torch.testing.assert_close(part[..., 0].cpu(), want_s, atol=2e-3 * sc, rtol=2e-3)
+    torch.testing.assert_close(part[..., 1].cpu(), want_q, atol=2e-3 * sc * sc, rtol=4e-3)
+    s0 = (x @ w.t() + b).view(M, D // 32, 32)
+    torch.testing.assert_close(part0[..., 0].cpu(), s0.sum(-1).t().contiguous(), atol=2e-3 * sc, rtol=2e-3)
+    # row affine of the LayerNorm
+    yf = y.float().cpu()
+    mean, var = yf.mean(1), yf.var(1, unbiased=False)
+    rstd = 1.0 / torch.sqrt(var + eps)
+    torch.testing.assert_close(rowab[:, 0].cpu(), rstd, atol=0, rtol=2e-3)
+    torch.testing.assert_close(rowab[:, 1].cpu(), -mean * rstd, atol=3e-3, rtol=2e-3)
+    # consumer: Linear(LayerNorm(y)) of the oracle on the stored fp16 rows
+    ln = OF.layernorm({"n.gamma": gamma, "n.beta": beta}, "n", yf, eps)
+    for act, got in outs.items():
+        want = ln @ w2.t() + b2
+        if act == E.ACT_GELU:
+            want = torch.nn.functional.gelu(want)
+        # LN output O(1), K = D terms: the folded form rounds W * gamma instead of LN(y); allow a few fp16 ulps of the O(1) sum
+        torch.testing.assert_close(got.float().cpu(), want, atol=6e-3, rtol=6e-3)
+
+
+def test_folded_layernorm_refuses_what_the_persistent_kernel_does_not_take(dev):
+    """tlxmi_linear_ln_supported and the UNSUPPORTED returns agree: fp32, Cout % 32, short K with a residual, an activation on the producer."""
+    lib = _load()
+    assert lib.tlxmi_linear_ln_supported(0, 25216, 768, 768, 0, 1) == 1
+    assert lib.tlxmi_linear_ln_supported(0, 25216, 512, 512, 0, 1) == 1          # 8 K tiles: the one-tile-per-workgroup kernel (gemm_pp LNF)
+    assert lib.tlxmi_linear_ln_supported(0, 25216, 512, 1536, 0, 0) == 1
+    assert lib.tlxmi_linear_ln_supported(1, 25216, 768, 768, 0, 0) == 0          # fp32: the stand-alone LayerNorm keeps the reference's order
+    assert lib.tlxmi_linear_ln_supported(0, 25216, 768, 200, 0, 0) == 0
+    assert lib.tlxmi_linear_ln_supported(0, 25216, 768, 3072, E.ACT_GELU, 0) == 1
+    assert lib.tlxmi_linear_ln_supported(0, 25216, 768, 3072, E.ACT_RELU, 0) == 0
+    x = torch.zeros((512, 200), dtype=torch.float16, device=dev)
+    pk = E.PackedFilter(torch.zeros((200, 200), device=dev), torch.float16)
+    with pytest.raises(RuntimeError, match="outside"):
+        E.linear_stats(x, pk, None)
+
+
+def _load():
+    from tlxcv_amd import _lib
+    return _lib.load()

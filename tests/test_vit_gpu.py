@@ -96,3 +96,50 @@ def test_vit_384_runs_the_long_sequence_attention(dev, fp32_mode):
     y = m(x.to(dev)).cpu().numpy()
     assert np.abs(y - ref).max() <= 1e-4
     assert (y.argmax(1) == ref.argmax(1)).all()
+
+
+@pytest.mark.parametrize("batch", [16, 64])
+def test_layernorm_folded_into_the_gemms_tracks_golden(dev, fp16_mode, batch):
+    """Round 5: norm1 / norm2 of every block (vision_transformer.py:172-175) without a LayerNorm launch — statistics out of the
+    proj / fc2 / patch-embedding epilogues, the normalisation in the qkv / fc1 epilogues (engine option "lnfold").  The golden
+    images of vit_b16_b2 planted in a filler batch big enough for the folded path (>= 2048 token rows; 64: the two-stream forward):
+    both arms against the reference-file logits, and against each other."""
+    from tlxcv_amd import engine as E
+    g = np.load(os.path.join(GOLDEN, "vit_b16_b2.npz"))
+    m = build("vit_base_patch16_224", int(g["weight_seed"]), dev)
+    gold = seeded.image_batch(2, int(g["input_seed"]))
+    x = seeded.image_batch(batch, 123)
+    rows = [1, batch - 1]
+    x[rows] = gold
+    x = torch.from_numpy(x).to(dev)
+    ys, launches = {}, {}
+    try:
+        for arm in (True, False):
+            E.set_option("lnfold", arm)
+            n0 = _count_ln(m)
+            ys[arm] = m(x).float().cpu().numpy()
+            launches[arm] = _count_ln(m) - n0
+    finally:
+        E.set_option("lnfold", True)
+    assert launches[True] == 0 and launches[False] >= 24 * (2 if batch >= 64 else 1)      # the folded arm ran no LayerNorm module
+    for arm in (True, False):
+        check_fp16_logits(ys[arm][rows], g["logits"], g["argmax"], "vit_b16_b2")
+    span = float(g["logits"].max() - g["logits"].min())
+    assert np.abs(ys[True] - ys[False]).max() <= 0.006 * span
+
+
+_LN_CALLS = [0]
+
+
+def _count_ln(m):
+    """Calls of nn.LayerNorm.forward so far (the folded path never calls the module)."""
+    from tlxcv_amd.tlx import nn
+    if not getattr(nn.LayerNorm, "_counted", False):
+        fwd = nn.LayerNorm.forward
+
+        def counted(self, x):
+            _LN_CALLS[0] += 1
+            return fwd(self, x)
+        nn.LayerNorm.forward = counted
+        nn.LayerNorm._counted = True
+    return _LN_CALLS[0]

@@ -89,6 +89,9 @@ PROTOTYPES = {
     "tlxmi_layernorm": [_vp, _vp, _vp, _vp, _i, _l, _i, _i, _i, _f, _vp],
     "tlxmi_layernorm_window_partition": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp],
     "tlxmi_window_reverse_layernorm": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp],
+    "tlxmi_linear_stats": [_i, _l, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _u, _vp],
+    "tlxmi_ln_finalize": [_vp, _i, _l, _i, _f, _vp, _vp],
+    "tlxmi_linear_ln": [_i, _l, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _u, _vp],
     "tlxmi_attention": [C.POINTER(AttnDesc), _vp, _vp, _vp, _vp, _vp],
     "tlxmi_attention_comb": [C.POINTER(AttnDesc), _vp, _vp, _vp, _vp],
     "tlxmi_mha": [C.POINTER(MhaDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -113,6 +116,7 @@ _SPECIAL = {
     "tlxmi_preprocess_u8_workspace_bytes": ([C.POINTER(PreprocDesc)], C.c_size_t),
     "tlxmi_multiclass_nms_workspace_bytes": ([_i, _i], C.c_size_t),
     "tlxmi_bottleneck_seam_supported": ([_i, _i, _i, _i], C.c_int),
+    "tlxmi_linear_ln_supported": ([_i, _l, _i, _i, _i, _i], C.c_int),
 }
 ALL_SYMBOLS = sorted(list(PROTOTYPES) + list(_SPECIAL))
 

@@ -138,6 +138,24 @@ __device__ __forceinline__ f32x2v gelu_fast2(f32x2v x) {
     return x * phi;
 }
 
+// Four per-lane quantities a, b, c, d, each to be summed over the four lanes px, px + 16, px + 32, px + 48 that hold the 8-channel parts of
+// one row (the MFMA accumulator layout of the 256 x 256 GEMM kernels): v_permlane16_swap(A, B) trades A's odd 16-lane rows with B's even
+// ones, so A + B afterwards is [A0 + A1, B0 + B1, A2 + A3, B2 + B3] by lane row — one swap and one add take TWO quantities one level up —
+// and v_permlane32_swap joins the halves: the lane in row g returns the total of the g-th quantity (a, b, c, d for g = 0..3).
+// (The swap builtins return a two-element vector; its elements are copied to scalars before any bit cast: hipcc of ROCm 7.2 reads
+// element 0 for every __builtin_bit_cast(T, vec[i]) on a vector-element lvalue, DESIGN 5.2 pitfall 1.)
+__device__ __forceinline__ float ln_row_tree(float a, float b, float c, float d) {
+    const auto r01 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+    const unsigned a01 = r01[0], b01 = r01[1];
+    const float t01 = __builtin_bit_cast(float, a01) + __builtin_bit_cast(float, b01);
+    const auto r23 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, c), __builtin_bit_cast(unsigned, d), false, false);
+    const unsigned c23 = r23[0], d23 = r23[1];
+    const float t23 = __builtin_bit_cast(float, c23) + __builtin_bit_cast(float, d23);
+    const auto r4 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, t01), __builtin_bit_cast(unsigned, t23), false, false);
+    const unsigned lo = r4[0], hi = r4[1];
+    return __builtin_bit_cast(float, lo) + __builtin_bit_cast(float, hi);
+}
+
 // ---- wave64 reductions --------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -1177,6 +1177,93 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, int splits,
 }
 }  // namespace tlxmi
 
+// ------------------------------------------------------------------------------------------
+// LayerNorm folded AROUND the Linear layers of a transformer block (vision_transformer.py:144-175 norm1 -> attn.qkv, norm2 -> mlp.fc1;
+// swin_transformer.py:310-337), fp16, on the persistent 256 x 256 GEMM kernel (gemm_stream.hip):
+//   producer  tlxmi_linear_stats: y = x W^T + bias (+ res), and from the same epilogue the per-row partial (sum y, sum y^2) of every
+//             32-channel slot -> partials[Cout / 32][rows][2] (the LayerNorm that follows needs no pass over y);
+//   finalize  tlxmi_ln_finalize (norm.hip): slots -> rowab[rows][2] = (rstd, -mean * rstd);
+//   consumer  tlxmi_linear_ln: y = act(rowab[m][0] * (x W'^T) + rowab[m][1] * c1[n] + c2[n]) on the RAW rows x, with the caller's
+//             W' = W * gamma (packed), c1[n] = sum_k W'[n][k] (of the values as packed), c2[n] = bias[n] + sum_k W[n][k] * beta[k].
+// The normalised activations are never written or read.  Shapes / options the persistent kernel does not take return
+// TLXMI_ERR_UNSUPPORTED (tlxmi_linear_ln_supported asks first) and the caller keeps tlxmi_layernorm + tlxmi_conv2d.
+// ------------------------------------------------------------------------------------------
+namespace tlxmi {
+static int fill_ln_gemm(Gemm256Args& g, const char* who, int dtype, int64_t rows, int K, int Cout, int x_ld, int y_ld, const void* x,
+                        const void* w_packed, void* y) {
+    TLXMI_REQUIRE(x && w_packed && y, TLXMI_ERR_BAD_ARG, "%s: null buffer", who);
+    TLXMI_REQUIRE(dtype == TLXMI_F16 || dtype == TLXMI_F32, TLXMI_ERR_BAD_ARG, "%s: bad dtype %d", who, dtype);
+    TLXMI_REQUIRE(rows > 0 && K > 0 && Cout > 0 && x_ld >= K && y_ld >= Cout, TLXMI_ERR_BAD_ARG, "%s: bad extent", who);
+    if (dtype != TLXMI_F16) return fail(TLXMI_ERR_UNSUPPORTED, "%s: fp16 only (fp32 runs tlxmi_layernorm + tlxmi_conv2d)", who);
+    TLXMI_REQUIRE((K * 2) % 16 == 0 && (x_ld * 2) % 16 == 0 && (y_ld * 2) % 16 == 0 && aligned16(x) && aligned16(w_packed) && aligned16(y),
+                  TLXMI_ERR_ALIGNMENT, "%s: rows must be whole 16-byte chunks", who);
+    const long long xb = (long long)rows * x_ld * 2, yb = (long long)rows * y_ld * 2;
+    const int kchunks = K * 2 / 16, ktiles = (kchunks + 7) / 8;
+    if (!(Cout % 32 == 0 && Cout >= 256 && ktiles >= 2 && xb < (1ll << 31) && yb < (1ll << 31) && rows < (1ll << 27)))
+        return fail(TLXMI_ERR_UNSUPPORTED, "%s: shape %lld x %d -> %d is outside the persistent 256 x 256 GEMM kernel", who, (long long)rows, K, Cout);
+    g.debug = 0;
+    g.conv = 0;
+    g.x = (const char*)x; g.w = (const char*)w_packed; g.y = (char*)y; g.scale = nullptr; g.shift = nullptr; g.res = nullptr;
+    g.M = (int)rows; g.Cout = Cout; g.x_ld = x_ld; g.y_ld = y_ld; g.res_ld = 0;
+    g.kchunks = kchunks; g.Kp_bytes = ktiles * 128; g.ksteps = ktiles;
+    g.act = TLXMI_ACT_NONE; g.act_param = 0.f; g.flags = 0; g.mtiles = g.ntiles = 0; g.gn = 1;
+    g.x_bytes = (unsigned)xb; g.y_bytes = (unsigned)yb; g.res_bytes = 0;
+    g.w_bytes = (unsigned)(((size_t)(Cout + 127) / 128 * 128) * (size_t)g.Kp_bytes);
+    return TLXMI_OK;
+}
+static int ln_plan_cus(unsigned flags) {
+    return (flags & TLXMI_PLAN_SHARED_HALF) ? (num_cus() / 2 > 0 ? num_cus() / 2 : 1) : num_cus();
+}
+}  // namespace tlxmi
+
+extern "C" int tlxmi_linear_ln_supported(int dtype, int64_t rows, int K, int Cout, int act, int with_res) {
+    using namespace tlxmi;
+    if (dtype != TLXMI_F16 || rows <= 0 || rows >= (1ll << 27) || K <= 0 || Cout < 256 || Cout % 32 || (K * 2) % 16) return 0;
+    const int ktiles = (K * 2 / 16 + 7) / 8;
+    if (ktiles < 2) return 0;      // (a residual with fewer than 11 K tiles runs on the one-tile-per-workgroup kernel, gemm_pp.hip LNF)
+    if (act != TLXMI_ACT_NONE && !(act == TLXMI_ACT_GELU && !with_res)) return 0;
+    return 1;
+}
+
+extern "C" int tlxmi_linear_stats(int dtype, int64_t rows, int K, int Cout, int x_ld, int y_ld, const void* x, const void* w_packed,
+                                  const float* bias, const void* res, int res_ld, void* y, float* partials, unsigned flags, void* stream) {
+    using namespace tlxmi;
+    Gemm256Args g;
+    if (int rc = fill_ln_gemm(g, "linear_stats", dtype, rows, K, Cout, x_ld, y_ld, x, w_packed, y)) return rc;
+    TLXMI_REQUIRE(partials && ((uintptr_t)partials & 7) == 0, TLXMI_ERR_BAD_ARG, "linear_stats: partials must be an 8-byte aligned buffer");
+    TLXMI_REQUIRE(!res || (res_ld >= Cout && (res_ld * 2) % 16 == 0 && aligned16(res)), TLXMI_ERR_BAD_ARG, "linear_stats: bad residual");
+    if ((long long)(Cout / 32) * rows * 8 >= (1ll << 31)) return fail(TLXMI_ERR_UNSUPPORTED, "linear_stats: partial sums exceed 2 GiB");
+    g.shift = bias;
+    g.res = (const char*)res;
+    g.res_ld = res ? res_ld : 0;
+    g.res_bytes = res ? (unsigned)((long long)rows * res_ld * 2) : 0u;
+    if (res && (long long)rows * res_ld * 2 >= (1ll << 31)) return fail(TLXMI_ERR_UNSUPPORTED, "linear_stats: residual exceeds 2 GiB");
+    g.stats_out = partials;
+    g.flags = flags & (TLXMI_PLAN_SHARED_HALF | TLXMI_PLAN_SHARED_FULL);
+    // the persistent kernel where it applies; a residual with a short K (its residual steps need 11 K tiles: Swin-B stage 3 proj,
+    // K = 512) on the one-tile-per-workgroup form of the same K loop
+    if (int rc = gemm_stream_ok(dtype, g) ? launch_gemm_stream(dtype, g, as_stream(stream), ln_plan_cus(flags)) : launch_gemm_pp(dtype, g, as_stream(stream))) return rc;
+    return check_launch("linear_stats");
+}
+
+extern "C" int tlxmi_linear_ln(int dtype, int64_t rows, int K, int Cout, int x_ld, int y_ld, const void* x, const void* w_packed,
+                               const float* c1, const float* c2, const float* rowab, int act, void* y, unsigned flags, void* stream) {
+    using namespace tlxmi;
+    Gemm256Args g;
+    if (int rc = fill_ln_gemm(g, "linear_ln", dtype, rows, K, Cout, x_ld, y_ld, x, w_packed, y)) return rc;
+    TLXMI_REQUIRE(c1 && c2 && rowab && ((uintptr_t)rowab & 15) == 0, TLXMI_ERR_BAD_ARG, "linear_ln: c1 / c2 / rowab (16-byte aligned) are required");
+    TLXMI_REQUIRE(act == TLXMI_ACT_NONE || act == TLXMI_ACT_GELU, TLXMI_ERR_UNSUPPORTED, "linear_ln: activation %d (none or GELU)", act);
+    g.scale = c1;
+    g.shift = c2;
+    g.rowstats = rowab;
+    g.act = act;
+    g.flags = flags & (TLXMI_PLAN_SHARED_HALF | TLXMI_PLAN_SHARED_FULL);
+    // TLXMI_LN_GELU_PP (tuning flavour): 1 = GELU layers on the one-tile-per-workgroup kernel (its epilogue is not squeezed between MFMAs)
+    const bool on_pp = !gemm_stream_ok(dtype, g) || (act == TLXMI_ACT_GELU && tune_int("TLXMI_LN_GELU_PP", 0));
+    if (int rc = on_pp ? launch_gemm_pp(dtype, g, as_stream(stream)) : launch_gemm_stream(dtype, g, as_stream(stream), ln_plan_cus(flags))) return rc;
+    return check_launch("linear_ln");
+}
+
 extern "C" int tlxmi_linear_splitk(int dtype, int64_t rows, int K, int Cout, int x_ld, const void* x, const void* w_packed,
                                    int splits, void* partials, const float* scale, const float* shift, const void* res,
                                    int res_ld, int act, float act_param, uint32_t flags, void* y, int y_ld, void* stream) {

@@ -11,6 +11,13 @@ struct Gemm256Args {
     const float* scale;
     const float* shift;
     const char* res;
+    // LayerNorm folded around the Linear layers (gemm_stream.hip only; fp16):
+    //   rowstats  [M][2] per-row (a, b) = (rstd, -mean * rstd): y = act(a * acc + b * scale[n] + shift[n]) — the CONSUMER of a LayerNorm
+    //             whose gamma is folded into the packed filter (scale = c1[n] = sum_k W'[n][k], shift = c2[n] = bias + W beta);
+    //   stats_out [Cout / 32][M][2] per-row partial (sum y, sum y^2) over each 32-channel slot of the outputs this launch stores — the
+    //             PRODUCER side: the next LayerNorm's statistics without a pass over y (tlxmi_ln_finalize adds the slots up).
+    const float* rowstats = nullptr;
+    float* stats_out = nullptr;
     int M, Cout, x_ld, y_ld, res_ld;
     int kchunks;   // true 16-byte chunks per row
     int ksteps;    // 64-byte steps (packed pitch / 64)

@@ -71,7 +71,11 @@ template <> struct MmaPP<float> {
 // mask of the taps that fall inside the image (bit clear -> out-of-range descriptor offset -> zero fill).
 // HN = W half tiles per K tile: (HM, HN) = (2, 1) is the mirror image of (1, 2) — a 256 x 128 tile for layers with 128
 // output channels (3x3 convs of ResNet's 28 x 28 stage): phases (0,0) and (1,0), X1 taking W1's place in the DMA order.
-template <typename T, int HM, int HN, bool CONV>
+// LNF (fp16, plain GEMM rows): the LayerNorm fold of gemm_stream.hip in this kernel's end-of-tile epilogue — a.rowstats: per-row (a, b)
+// applied as y = act(a * acc + b * scale[n] + shift[n]) (the consumer of a folded LayerNorm); a.stats_out: per-row partial (sum, sum of
+// squares) of the outputs over each 32-channel slot (the producer).  Used where the persistent kernel does not apply: a residual with
+// fewer than 11 K tiles (Swin-B stage 3 proj: K = 512), fewer tiles than CUs.
+template <typename T, int HM, int HN, bool CONV, bool LNF = false>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
     static_assert(HM + HN >= 3 && HM <= 2 && HN <= 2, "tile is 256x256, 128x256 or 256x128");
     constexpr int ES = (int)sizeof(T);
@@ -383,14 +387,33 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
                         for (int hh = 0; hh < ES / 2; ++hh) rr[pi][hh] = pp_load16(rsrd, ro + 16 * hh);
                     }
                 }
+                f32x2 rab[4];
+                if constexpr (LNF) {
+                    if (a.rowstats) {
+#pragma unroll
+                        for (int pi = 0; pi < 4; ++pi) {
+                            const int m = bm0 + 128 * h + 64 * wr + prow(pi) * 16 + px;
+                            rab[pi] = m < a.M ? *reinterpret_cast<const f32x2*>(a.rowstats + 2 * (size_t)m) : f32x2{0.f, 0.f};
+                        }
+                    }
+                }
+                float st_s[4], st_q[4];
 #pragma unroll
                 for (int pi = 0; pi < 4; ++pi) {
                     const int m = bm0 + 128 * h + 64 * wr + prow(pi) * 16 + px;
                     float v[8], rv[8];
+                    if (LNF && a.rowstats) {
 #pragma unroll
-                    for (int bb = 0; bb < 4; ++bb) {
-                        v[bb] = acc[2 * g][4 * h + pi][bb] * sc[bb] + sf[bb];
-                        v[4 + bb] = acc[2 * g + 1][4 * h + pi][bb] * sc[4 + bb] + sf[4 + bb];
+                        for (int bb = 0; bb < 4; ++bb) {
+                            v[bb] = acc[2 * g][4 * h + pi][bb] * rab[pi][0] + (rab[pi][1] * sc[bb] + sf[bb]);
+                            v[4 + bb] = acc[2 * g + 1][4 * h + pi][bb] * rab[pi][0] + (rab[pi][1] * sc[4 + bb] + sf[4 + bb]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int bb = 0; bb < 4; ++bb) {
+                            v[bb] = acc[2 * g][4 * h + pi][bb] * sc[bb] + sf[bb];
+                            v[4 + bb] = acc[2 * g + 1][4 * h + pi][bb] * sc[4 + bb] + sf[4 + bb];
+                        }
                     }
                     if (a.res) {
                         if constexpr (ES == 2) {
@@ -422,6 +445,13 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] += rv[e];
                     }
+                    if constexpr (LNF) {
+                        float ss = v[0], qq = v[0] * v[0];
+#pragma unroll
+                        for (int e = 1; e < 8; ++e) { ss += v[e]; qq = __builtin_fmaf(v[e], v[e], qq); }
+                        st_s[pi] = ss;
+                        st_q[pi] = qq;
+                    }
                     const int yo = m < a.M ? (m * a.y_ld + ch0) * ES : OOB;   // OOB stores are dropped by the range check
                     if constexpr (ES == 2) {
                         half8v hv;
@@ -439,6 +469,17 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
                         else pp_store16_nt(ysrd, __builtin_bit_cast(u32x4, f1), yo + 16);
                     }
                 }
+                if constexpr (LNF) {
+                    if (a.stats_out) {
+                        // the four lanes (fg = 0..3) of a row hold its 32 channels of this slot: three lane-swap steps per four quantities
+                        // (gemm_stream.hip STATS); lane row fg ends with the total of sub-tile pi = fg -> rows 16 fg + px = lane, 512 B per wave
+                        auto tree = [&](const float (&x)[4]) -> float { return ln_row_tree(x[0], x[1], x[2], x[3]); };
+                        const float ts = tree(st_s), tq = tree(st_q);
+                        const int m = bm0 + 128 * h + 64 * wr + lane;
+                        const int slot = (bn0 + 128 * g + 32 * wc) >> 5;
+                        if (m < a.M) *reinterpret_cast<f32x2*>(a.stats_out + 2 * ((size_t)slot * a.M + m)) = f32x2{ts, tq};
+                    }
+                }
             }
         }
     };
@@ -446,7 +487,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
 }
 
 // Preconditions as launch_gemm256 (checked by conv_igemm.hip's dispatcher); a.ksteps = packed pitch / 128.
-template <typename T, int HM, int HN, bool CONV> static int launch_pp_t(const Gemm256Args& a0, hipStream_t st) {
+template <typename T, int HM, int HN, bool CONV, bool LNF = false> static int launch_pp_t(const Gemm256Args& a0, hipStream_t st) {
     Gemm256Args a = a0;
     a.debug = (int)tune_int("TLXMI_DEBUG", 0);     // ablation bits: tuning flavour only (TLXMI_DBG is `false` in the product)
     a.mtiles = (a.M + 128 * HM - 1) / (128 * HM);
@@ -454,7 +495,7 @@ template <typename T, int HM, int HN, bool CONV> static int launch_pp_t(const Ge
     a.gn = a.ntiles;
     if (const long g = tune_int("TLXMI_GS_PANEL", 3); !CONV && g > 0 && g < a.ntiles) a.gn = (int)g;
     const size_t lds = (size_t)(HM + HN == 4 ? 8 : 9) * 128 * 128 + 2 * 256 * sizeof(float);
-    const void* fn = reinterpret_cast<const void*>(&gemm_pp_kernel<T, HM, HN, CONV>);
+    const void* fn = reinterpret_cast<const void*>(&gemm_pp_kernel<T, HM, HN, CONV, LNF>);
     if (int rc = raise_lds_limit(fn, (int)lds, "gemm_pp")) return rc;
     void* args[] = {&a};
     hipError_t e = hipLaunchKernel(fn, dim3((unsigned)(a.mtiles * a.ntiles * (a.kslices > 1 ? a.kslices : 1))), dim3(512), args, lds, st);
@@ -466,6 +507,10 @@ int launch_gemm_pp(int dtype, const Gemm256Args& a, hipStream_t st) {
     if (a.conv) {
         if (dtype == TLXMI_F16) return launch_pp_t<half_t, 2, 2, true>(a, st);
         return launch_pp_t<float, 2, 2, true>(a, st);
+    }
+    if (a.rowstats || a.stats_out) {      // LayerNorm fold (fp16, Cout % 32 == 0: checked by the entry points in conv_igemm.hip)
+        if (dtype != TLXMI_F16 || (a.Cout & 31) || a.kslices > 1) return fail(TLXMI_ERR_UNSUPPORTED, "gemm_pp: the LayerNorm fold is fp16, Cout %% 32 == 0");
+        return launch_pp_t<half_t, 2, 2, false, true>(a, st);
     }
     if (dtype == TLXMI_F16) return launch_pp_t<half_t, 2, 2, false>(a, st);
     return launch_pp_t<float, 2, 2, false>(a, st);

@@ -97,14 +97,25 @@ template <int N> __device__ __forceinline__ void gs_vmcnt() {
 
 // ACT: TLXMI_ACT_NONE / RELU / GELU (other activations, and exact-erf GELU in fp32, stay on gemm_pp.hip).
 // RES: a.res is added (before the activation; a.scale must be null) — needs >= 11 K tiles.
-template <typename T, int ACT, bool RES>
+// ROWAFF: the CONSUMER of a folded LayerNorm — per-row (a, b) = (rstd, -mean * rstd) of a.rowstats applied in the epilogue,
+//   y = act(a[m] * acc + b[m] * c1[n] + c2[n]) with c1 = a.scale, c2 = a.shift; one more table piece per tile (256 rows x 8 B).
+// STATS: the PRODUCER — every quadrant epilogue also adds up its 8 channels x 4 rows per lane (sum, sum of squares of the fp32
+//   values before the rounding), reduces the four lanes of a row with three lane-swap steps per four quantities and stores
+//   (sum, sum^2) of row m over the 32 channels of slot (bn0 + 128 G + 32 wc) / 32 at a.stats_out[slot][m]: 512 contiguous
+//   bytes per wave, one more store per quadrant (S + 1 in every counted wait).
+// (the ablation branches of the tuning flavour exist in the plain variants only: with them the LayerNorm-fold variants spill — 880 bytes
+//  of scratch per lane for GELU + ROWAFF, i.e. a vmcnt(0) drain per reload — and tools/ab_graph.py would time an artefact)
+#define GS_DBG(args, bit) (!ROWAFF && !STATS && TLXMI_DBG(args, bit))
+template <typename T, int ACT, bool RES, bool ROWAFF = false, bool STATS = false>
 __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
     constexpr int ES = (int)sizeof(T);
     constexpr int HALF = 128 * 128;            // bytes of a half tile
     constexpr int RX0 = 0, RX1 = HALF, RW0 = 2 * HALF, RW1 = 3 * HALF;   // regions of a K tile
     constexpr int TABLE = 8 * HALF;            // two tables of 8 x 256 B behind the two K tiles
     constexpr int OOB = (int)0x80000000;
-    constexpr int S = ES == 2 ? 4 : 8, R = ES, TT = 2;   // R: loads of one residual step (2 pixel rows x 8 channels per lane)
+    constexpr int ROWTAB = TABLE + 2 * 2048;   // ROWAFF: two tables of 256 rows x (a, b) behind the channel tables
+    constexpr int SY = ES == 2 ? 4 : 8;        // 16-byte stores of a quadrant's outputs
+    constexpr int S = SY + (STATS ? 1 : 0), R = ES, TT = ROWAFF ? 3 : 2;   // R: loads of one residual step (2 pixel rows x 8 channels per lane)
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int t = threadIdx.x, lane = t & 63;
@@ -138,6 +149,8 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
     const __amdgpu_buffer_rsrc_t rsrd = gs_srd(a.res ? a.res : a.y, a.res ? a.res_bytes : 0u);
     const __amdgpu_buffer_rsrc_t hsrd = gs_srd(a.shift, a.shift ? (unsigned)a.Cout * 4u : 0u);   // null: zero fill
     const __amdgpu_buffer_rsrc_t ssrd = a.scale ? gs_srd(a.scale, (unsigned)a.Cout * 4u) : gs_srd(g_ones4, 16u);
+    const __amdgpu_buffer_rsrc_t rowsrd = gs_srd(a.rowstats, (ROWAFF && a.rowstats) ? (unsigned)a.M * 8u : 0u);               // null: zero fill
+    const __amdgpu_buffer_rsrc_t stsrd = gs_srd(a.stats_out, (STATS && a.stats_out) ? (unsigned)(a.Cout >> 5) * (unsigned)a.M * 8u : 0u);   // null: dropped
 
     // ---- loader (gemm_pp.hip): piece = 8 rows x 128 B; wave w fills pieces w, w+8 of a half tile
     const int lrow = lane >> 3;
@@ -153,9 +166,9 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
         const bool ok = tile_origin(i, bm0, bn0, th);
         const int row = 128 * half + 8 * wid + lrow;
         const int n = (row & ~31) | (((row >> 2) & 3) << 3) | (((row >> 4) & 1) << 2) | (row & 3);
-        const int xrow = TLXMI_DBG(a, 8) ? ((bm0 + row) & 2047) : bm0 + row;      // (ablation bit 8: every X row from the first 2048 — L2-resident operand, timing only)
+        const int xrow = GS_DBG(a, 8) ? ((bm0 + row) & 2047) : bm0 + row;      // (ablation bit 8: every X row from the first 2048 — L2-resident operand, timing only)
         xo = (ok && !(th && half)) ? xrow * a.x_ld * ES : OOB;      // a half-height tile has no X1
-        wo = ok ? ((TLXMI_DBG(a, 32) ? 0 : bn0) + n) * a.Kp_bytes : OOB;      // (ablation bit 32: every tile multiplies filter rows 0 .. 255 — L2-resident filter, timing only)
+        wo = ok ? ((GS_DBG(a, 32) ? 0 : bn0) + n) * a.Kp_bytes : OOB;      // (ablation bit 32: every tile multiplies filter rows 0 .. 255 — L2-resident filter, timing only)
     };
     char* const lbase = smem + wid * 1024;
     // (an offset that is out of range stays out of range after the small additions: x_bytes, w_bytes < 2^31)
@@ -184,6 +197,10 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
             const int off = ok ? (bn0 + 32 * wid + 4 * lane) * 4 : OOB;
             gs_dma16(hsrd, dst, off);
             gs_dma16(ssrd, dst + 128, a.scale ? off : 0);
+        }
+        // ROWAFF: (a, b) of rows 32w .. 32w+31 of the tile, two rows per lane (rows past M: zero fill)
+        if constexpr (ROWAFF) {
+            if (lane < 16) gs_dma16(rowsrd, smem + ROWTAB + (i & 1) * 2048 + wid * 256, ok ? (bm0 + 32 * wid + 2 * lane) * 8 : OOB);
         }
     };
 
@@ -216,6 +233,24 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
         for (int q = 0; q < S; ++q) gs_store16_wb(ysrd, u32x4{0u, 0u, 0u, 0u}, OOB);
     };
 
+    // ROWAFF: the (a, b) pairs of this lane's four rows (sub-tiles pi = 0..3 of half h) are read from the row table in the LOAD segment of
+    // the phase whose MFMA segment runs the first epilogue of that half — p1 of the last K tile for h = 0 (E00, E01), p3 for h = 1 (E11, and
+    // E10 one phase later) — by ONE asm block with its own lgkmcnt(0): eight registers live across two phases.  (Read inside the MFMA
+    // segment, one ds_read_b64 right in front of its use, the pairs of sub-tile 1 of h = 1 came back with b = 0 in lanes 48 - 63 for the
+    // low halves of the packed FMAs on some launches — tools/dbg notes in DESIGN 5.4; the table itself was right.)
+    f32x2 rab[4];
+    auto rowab_fetch = [&](int h, int tpar) {
+        if constexpr (ROWAFF) {
+            const int ln = lane_now();
+            const unsigned la = (unsigned)(uintptr_t)(lds_ptr_gs_t)(smem + ROWTAB + tpar * 2048 + (128 * h + 64 * wr + (ln & 15)) * 8);
+            asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:128\n\tds_read_b64 %2, %4 offset:256\n\tds_read_b64 %3, %4 offset:384\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(rab[0]), "=&v"(rab[1]), "=&v"(rab[2]), "=&v"(rab[3])
+                         : "v"(la)
+                         : "memory");
+        }
+    };
+
     // ---- quadrant epilogue: lane (fg, px) owns channels 128g + 32wc + 8fg .. +7 of pixel rows
     // 128h + 64wr + 16pi + px.  Always S stores (suppressed ones go to an out-of-range offset).
     auto epi = [&](auto h_tag, auto g_tag, int bm0, int bn0, int tpar, bool live) {
@@ -226,10 +261,10 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
         const int ch0 = bn0 + col;
         // (branch-free selects on purpose: an exec-masked branch would cut the MFMA segment this runs in into basic blocks and
         //  the scheduler could no longer put the arithmetic between the MFMAs)
-        const int chm = (live && !TLXMI_DBG(a, 2)) ? ((ch0 - a.Cout) >> 31) : 0;      // -1: a real channel (Cout is a multiple of 8 on this path)
-        if TLXMI_DBG(a, 1) {   // ablation: stores without the arithmetic
+        const int chm = (live && !GS_DBG(a, 2)) ? ((ch0 - a.Cout) >> 31) : 0;      // -1: a real channel (Cout is a multiple of 8 on this path)
+        if GS_DBG(a, 1) {   // ablation: stores without the arithmetic
 #pragma unroll
-            for (int pi = 0; pi < 4 * (ES / 2); ++pi) gs_store16_nt(ysrd, __builtin_bit_cast(u32x4, acc[2 * G][4 * H + (pi & 3)]), OOB);
+            for (int pi = 0; pi < S; ++pi) gs_store16_nt(ysrd, __builtin_bit_cast(u32x4, acc[2 * G][4 * H + (pi & 3)]), OOB);
             return;
         }
         const float* tb = reinterpret_cast<const float*>(smem + TABLE + tpar * 2048 + (4 * G + wc) * 256) + 8 * fg;
@@ -239,18 +274,28 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
             s0 = *reinterpret_cast<const f32x4*>(tb + 32);
             s1 = *reinterpret_cast<const f32x4*>(tb + 36);
         }
+        float st_s[4], st_q[4];      // STATS: this lane's 8 channels of row pi
 #pragma unroll
         for (int pi = 0; pi < 4; ++pi) {
             const int m = bm0 + 128 * H + 64 * wr + 16 * pi + px;
             float v[8];
+            if constexpr (ROWAFF) {   // y = a[m] * acc + b[m] * c1[n] + c2[n]   (rab: rowab_fetch, one or two phases ago)
+                const f32x2 ab = rab[pi];
 #pragma unroll
-            for (int bb = 0; bb < 4; ++bb) {
-                if constexpr (RES) {
-                    v[bb] = acc[2 * G][4 * H + pi][bb] + h0[bb];
-                    v[4 + bb] = acc[2 * G + 1][4 * H + pi][bb] + h1[bb];
-                } else {
-                    v[bb] = acc[2 * G][4 * H + pi][bb] * s0[bb] + h0[bb];
-                    v[4 + bb] = acc[2 * G + 1][4 * H + pi][bb] * s1[bb] + h1[bb];
+                for (int bb = 0; bb < 4; ++bb) {
+                    v[bb] = acc[2 * G][4 * H + pi][bb] * ab[0] + (ab[1] * s0[bb] + h0[bb]);
+                    v[4 + bb] = acc[2 * G + 1][4 * H + pi][bb] * ab[0] + (ab[1] * s1[bb] + h1[bb]);
+                }
+            } else {
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) {
+                    if constexpr (RES) {
+                        v[bb] = acc[2 * G][4 * H + pi][bb] + h0[bb];
+                        v[4 + bb] = acc[2 * G + 1][4 * H + pi][bb] + h1[bb];
+                    } else {
+                        v[bb] = acc[2 * G][4 * H + pi][bb] * s0[bb] + h0[bb];
+                        v[4 + bb] = acc[2 * G + 1][4 * H + pi][bb] * s1[bb] + h1[bb];
+                    }
                 }
             }
             if constexpr (ACT == TLXMI_ACT_GELU && ES == 2) {
@@ -264,9 +309,16 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = apply_act_t<ACT>(v[e], a.act_param);
             }
+            if constexpr (STATS) {      // channels past Cout are zeros here (zero filter rows, zero-filled shift / residual)
+                float ss = v[0], qq = v[0] * v[0];
+#pragma unroll
+                for (int e = 1; e < 8; ++e) { ss += v[e]; qq = __builtin_fmaf(v[e], v[e], qq); }
+                st_s[pi] = ss;
+                st_q[pi] = qq;
+            }
             const int okm = chm & ((m - a.M) >> 31);
             int yo = (((m * a.y_ld + ch0) * ES) & okm) | (OOB & ~okm);   // out-of-range stores are dropped
-            if TLXMI_DBG(a, 16) {   // ablation (wrong data, right byte count): this store instruction writes 8 whole 128-byte lines
+            if GS_DBG(a, 16) {   // ablation (wrong data, right byte count): this store instruction writes 8 whole 128-byte lines
                 const int mm = bm0 + 128 * H + 64 * wr + 16 * pi + 8 * (col >> 7) + (ln >> 3), cc = bn0 + (128 * (G ^ (col >> 7)) + 64 * (wc >> 1) + 8 * (ln & 7));
                 yo = (mm < a.M && cc < a.Cout && live) ? (mm * a.y_ld + cc) * ES : OOB;
             }
@@ -274,7 +326,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
                 half8v hv;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) hv[e] = (half_t)v[e];
-                if (!TLXMI_DBG(a, 4)) gs_store16_wb(ysrd, __builtin_bit_cast(u32x4, hv), yo);      // (bit 4, A/B: non-temporal)
+                if (!GS_DBG(a, 4)) gs_store16_wb(ysrd, __builtin_bit_cast(u32x4, hv), yo);      // (bit 4, A/B: non-temporal)
                 else gs_store16_nt(ysrd, __builtin_bit_cast(u32x4, hv), yo);
             } else {
                 f32x4 f0, f1;
@@ -283,6 +335,18 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
                 gs_store16_nt(ysrd, __builtin_bit_cast(u32x4, f0), yo);
                 gs_store16_nt(ysrd, __builtin_bit_cast(u32x4, f1), yo + 16);
             }
+        }
+        if constexpr (STATS) {
+            // lanes (fg = 0..3, px) hold the four 8-channel parts of row px of sub-tile pi.  v_permlane16_swap(A, B) trades A's odd lane
+            // rows with B's even ones, so A + B afterwards = [A0+A1, B0+B1, A2+A3, B2+B3] by lane row: one swap and one add take TWO
+            // quantities one level up; v_permlane32_swap joins the halves: lane row g ends with the 32-channel total of sub-tile pi = g.
+            auto tree = [&](const float (&x)[4]) -> float { return ln_row_tree(x[0], x[1], x[2], x[3]); };
+            const float ts = tree(st_s), tq = tree(st_q);
+            const int m = bm0 + 128 * H + 64 * wr + ln;            // row of sub-tile fg, pixel px: 16 * fg + px = the lane index
+            const int slot = (bn0 + 128 * G + 32 * wc) >> 5;
+            const int okm = chm & ((m - a.M) >> 31);
+            const int so = (((slot * a.M + m) * 8) & okm) | (OOB & ~okm);
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2{__builtin_bit_cast(unsigned, ts), __builtin_bit_cast(unsigned, tq)}, stsrd, so, 0, 0);
         }
     };
     // Residual step r = 0..7 covers quadrant (r>>1) in the phase order (0,0) (0,1) (1,1) (1,0), pixel sub-tiles
@@ -406,6 +470,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
         GS_SYNC();
         // ---- p1: quadrant (0,1)
         read_w(kb, RW1, w1f);
+        if constexpr (MODE == GS_LAST) rowab_fetch(0, i & 1);
         dma_x(RX1, para, xa, kta);
         adv_a();
         gs_vmcnt<(MODE == GS_K0_AFTER ? 8 + 4 * S + TT : 8 + RQ)>();
@@ -426,6 +491,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
         }
         GS_SYNC();
         // ---- p3: quadrant (1,0)
+        if constexpr (MODE == GS_LAST && !HF) rowab_fetch(1, i & 1);
         dma_w(RW0, parb, wb, ktb);
         adv_b();
         gs_vmcnt<(MODE == GS_K0_AFTER ? 8 + 2 * S : MODE == GS_LAST ? 8 + 2 * S + TT : 8 + RQ)>();
@@ -485,11 +551,12 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
 #undef GS_MMA
 #undef GS_MMA_E
 #undef GS_SYNC
+#undef GS_DBG
 }
 
 // Preconditions as launch_gemm256 (conv_igemm.hip's dispatcher) plus: a.ksteps = packed pitch / 128 >= 2;
 // with a residual: fp16, a.scale == nullptr, residual added before the activation, a.ksteps >= 11.
-template <typename T, int ACT, bool RES> static int launch_gs(const Gemm256Args& a0, hipStream_t st, int cus) {
+template <typename T, int ACT, bool RES, bool ROWAFF = false, bool STATS = false> static int launch_gs(const Gemm256Args& a0, hipStream_t st, int cus) {
     Gemm256Args a = a0;
     a.debug = (int)tune_int("TLXMI_DEBUG", 0);     // ablation bits: tuning flavour only (TLXMI_DBG is `false` in the product)
     if (const long only = tune_int("TLXMI_DEBUG_COUT", 0); only > 0 && only != a.Cout) a.debug = 0;      // ... on the launches with this Cout only
@@ -497,8 +564,8 @@ template <typename T, int ACT, bool RES> static int launch_gs(const Gemm256Args&
     a.ntiles = (a.Cout + 255) / 256;
     a.gn = a.ntiles;
     if (const long g = tune_int("TLXMI_GS_PANEL", 3); g > 0 && g < a.ntiles) a.gn = (int)g;
-    const size_t lds = (size_t)8 * 128 * 128 + 2 * 2048;   // two K tiles, channel tables
-    const void* fn = reinterpret_cast<const void*>(&gemm_stream_kernel<T, ACT, RES>);
+    const size_t lds = (size_t)8 * 128 * 128 + 2 * 2048 + (ROWAFF ? 2 * 2048 : 0);   // two K tiles, channel tables, row tables
+    const void* fn = reinterpret_cast<const void*>(&gemm_stream_kernel<T, ACT, RES, ROWAFF, STATS>);
     if (int rc = raise_lds_limit(fn, (int)lds, "gemm_stream")) return rc;
     int maxgrid = cus & ~7;         // one workgroup per CU; a multiple of 8 keeps a virtual block on its XCD
     if (maxgrid < 8) maxgrid = 8;
@@ -531,6 +598,15 @@ template <typename T, int ACT, bool RES> static int launch_gs(const Gemm256Args&
 
 template <typename T> static int launch_gs_t(const Gemm256Args& a, hipStream_t st, int cus) {
     if constexpr (sizeof(T) == 2) {
+        // LayerNorm folded around the Linear layers (gemm_stream_ok: fp16; consumer: no residual, NONE / GELU; producer: NONE)
+        if (a.rowstats) {
+            if (a.act == TLXMI_ACT_GELU) return launch_gs<T, TLXMI_ACT_GELU, false, true, false>(a, st, cus);
+            return launch_gs<T, TLXMI_ACT_NONE, false, true, false>(a, st, cus);
+        }
+        if (a.stats_out) {
+            if (a.res) return launch_gs<T, TLXMI_ACT_NONE, true, false, true>(a, st, cus);
+            return launch_gs<T, TLXMI_ACT_NONE, false, false, true>(a, st, cus);
+        }
         if (a.res) {
             if (a.act == TLXMI_ACT_RELU) return launch_gs<T, TLXMI_ACT_RELU, true>(a, st, cus);
             return launch_gs<T, TLXMI_ACT_NONE, true>(a, st, cus);
@@ -547,6 +623,8 @@ bool gemm_stream_ok(int dtype, const Gemm256Args& a) {
     if (a.ksteps < 2) return false;
     if (a.act != TLXMI_ACT_NONE && a.act != TLXMI_ACT_RELU && !(a.act == TLXMI_ACT_GELU && dtype == TLXMI_F16 && !a.res)) return false;
     if (a.res && (dtype != TLXMI_F16 || a.scale != nullptr || (a.flags & TLXMI_EPI_RES_AFTER_ACT) || a.ksteps < 11)) return false;
+    if (a.rowstats && (dtype != TLXMI_F16 || a.res || a.stats_out || !a.scale || !a.shift || (a.act != TLXMI_ACT_NONE && a.act != TLXMI_ACT_GELU))) return false;
+    if (a.stats_out && (dtype != TLXMI_F16 || a.act != TLXMI_ACT_NONE || (a.Cout & 31))) return false;
     return true;
 }
 

@@ -29,6 +29,10 @@ _options = {"splitk": True,       # classifier heads: K slices side by side (tlx
             "patch_linear": True, # ViT patch embedding as one Linear over all token rows (tlxmi_patchify + the persistent GEMM); off = the
                                   # space-to-depth implicit GEMM writing rows 1.. of each image (the A/B and the parity tests' other arm)
             "patch_embed4": True, # Swin patch embedding (conv 4 x 4 / 4 + LayerNorm) as one pass over the NCHW image (tlxmi_patch_embed4, fp16)
+            "lnfold": True,       # LayerNorm folded AROUND the Linear layers of a transformer block (fp16, round 5): proj / fc2 / the patch embedding
+                                  # emit the row statistics of the residual stream from their epilogues (tlxmi_linear_stats), qkv / fc1 apply
+                                  # the normalisation in theirs (tlxmi_linear_ln); off = LayerNorm launches + plain Linear layers (the parity
+                                  # tests' other arm)
             "tail_splitk": False} # Linear layers: the rows of a short last round of 256 x 256 tiles on K slices (_linear_tail): built,
                                   # parity-green, measured a LOSS on the ViT-B/16 forward (10.63 -> 11.61 ms for every K >= 768,
                                   # 10.91 for fc2 only: two more launches + the fp32 partial planes cost more than the idle round)
@@ -752,6 +756,92 @@ def _linear_splits(rows, K, pk, x):
     if best and rows * pk.Cout * es * best >= (1 << 31):
         return 0
     return best
+
+
+def linear_ln_supported(rows, K, Cout, dtype, act=ACT_NONE, with_res=False):
+    """Whether a Linear of this shape takes the folded-LayerNorm path (tlxmi_linear_stats with_res / tlxmi_linear_ln): fp16 on the
+    persistent 256 x 256 GEMM kernel, rows enough to fill it (below ~2 k rows the tiled kernels of the dispatcher win)."""
+    if not _options["lnfold"] or dtype != torch.float16 or rows < 2048:
+        return False
+    return bool(_lib.load().tlxmi_linear_ln_supported(F16, int(rows), int(K), int(Cout), int(act), 1 if with_res else 0))
+
+
+class LinearLN:
+    """A Linear with the LayerNorm in front of it folded in (include/tlxmi.h, tlxmi_linear_ln): packed W * gamma, c1 = row sums of the
+    values as packed, c2 = bias + W @ beta."""
+
+    def __init__(self, w_out_in, bias, gamma, beta, dtype):
+        w = w_out_in.detach().float()
+        g, b = gamma.detach().float().to(w.device), beta.detach().float().to(w.device)
+        wg = w * g[None, :]
+        self.pk = PackedFilter(wg.view(w.shape[0], w.shape[1], 1, 1).contiguous(), dtype)
+        self.c1 = wg.to(dtype).double().sum(dim=1).float().contiguous()
+        self.c2 = (w.double() @ b.double() + (bias.detach().double().to(w.device) if bias is not None else 0.0)).float().contiguous()
+        self.K, self.Cout = w.shape[1], w.shape[0]
+
+
+def _probe_pair():
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    return e0, e1
+
+
+def linear_stats(x, pk, bias=None, res=None, out=None):
+    """y = x W^T + bias (+ res) as linear(), plus the per-row partial (sum, sum of squares) of y over every 32-channel slot from the
+    same epilogue: returns (y, partials (Cout / 32, rows, 2) fp32) — the statistics of the LayerNorm that follows, without a pass
+    over y (ln_finalize turns them into the row affine of linear_ln)."""
+    need_gpu(x, "input")
+    shp = x.shape
+    if not x.is_contiguous():
+        x = x.contiguous()
+    K = shp[-1]
+    rows = x.numel() // K
+    if x.dtype != pk.dtype:
+        raise RuntimeError(f"linear_stats: input dtype {x.dtype} != packed filter dtype {pk.dtype}")
+    if res is not None and (not res.is_contiguous() or res.dtype != x.dtype):
+        raise RuntimeError("linear_stats: the residual must be a dense tensor of the input's dtype")
+    y = out if out is not None else torch.empty((*shp[:-1], pk.Cout), dtype=x.dtype, device=x.device)
+    part = torch.empty((pk.Cout // 32, rows, 2), dtype=torch.float32, device=x.device)
+    if _probe is not None:
+        e0, e1 = _probe_pair()
+    _lib.call("tlxmi_linear_stats", dt_code(x.dtype), rows, K, pk.Cout, K, pk.Cout, _p(x), _p(pk.buf), _p(bias), _p(res),
+              pk.Cout if res is not None else 0, _p(y), _p(part), plan_flags(), _stream())
+    if _probe is not None:
+        e1.record()
+        es = x.element_size()
+        _probe.append((e0, e1, (rows * K + rows * pk.Cout * (2 if res is not None else 1) + pk.Cout * K) * es + part.numel() * 4,
+                       2 * rows * pk.Cout * K, (rows, 1, 1, K, pk.Cout, 1, 1, res is not None)))
+    return y, part
+
+
+def ln_finalize(part, C, eps):
+    """partials (C / 32, rows, 2) of linear_stats -> rowab (rows, 2) = (rstd, -mean * rstd) (tlxmi_ln_finalize)."""
+    slots, rows, _ = part.shape
+    rowab = torch.empty((rows, 2), dtype=torch.float32, device=part.device)
+    _lib.call("tlxmi_ln_finalize", _p(part), slots, rows, int(C), float(eps), _p(rowab), _stream())
+    return rowab
+
+
+def linear_ln(x, prep, rowab, act=ACT_NONE):
+    """act(Linear(LayerNorm(x))) on the RAW rows x (..., K): the row affine `rowab` of ln_finalize applied in the GEMM epilogue."""
+    need_gpu(x, "input")
+    shp = x.shape
+    if not x.is_contiguous():
+        x = x.contiguous()
+    rows = x.numel() // shp[-1]
+    if rowab.shape[0] != rows:
+        raise RuntimeError(f"linear_ln: {rowab.shape[0]} row statistics for {rows} rows")
+    y = torch.empty((*shp[:-1], prep.Cout), dtype=x.dtype, device=x.device)
+    if _probe is not None:
+        e0, e1 = _probe_pair()
+    _lib.call("tlxmi_linear_ln", dt_code(x.dtype), rows, prep.K, prep.Cout, prep.K, prep.Cout, _p(x), _p(prep.pk.buf), _p(prep.c1), _p(prep.c2),
+              _p(rowab), act, _p(y), plan_flags(), _stream())
+    if _probe is not None:
+        e1.record()
+        es = x.element_size()
+        _probe.append((e0, e1, (rows * prep.K + rows * prep.Cout + prep.Cout * prep.K) * es + rows * 8,
+                       2 * rows * prep.Cout * prep.K, (rows, 1, 1, prep.K, prep.Cout, 1, 1, False)))
+    return y
 
 
 def dwconv2d(x, w_rsc, stride=1, padding=0, dilation=1, scale=None, shift=None, act=ACT_NONE, act_param=0.0, out_hw=None):

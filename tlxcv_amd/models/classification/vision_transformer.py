@@ -67,6 +67,15 @@ class Mlp(nn.Module):
         h = self.fc1.run(norm(x) if norm is not None else x, act=self.act.ACT)
         return self.fc2.run(h, res=res, out=res)       # bias + residual, written in place
 
+    def run_folded(self, x, norm, rowab, stats=True):
+        """x += fc2(act(fc1(norm(x)))) with `norm` applied in fc1's epilogue from the row statistics `rowab` of x; returns the partial
+        row statistics of the new x out of fc2's epilogue (None when stats is False: the last block)."""
+        h = self.fc1.run_ln(x, norm, rowab, act=self.act.ACT)
+        if stats:
+            return self.fc2.run_stats(h, res=x, out=x)[1]
+        self.fc2.run(h, res=x, out=x)
+        return None
+
     def forward(self, x):
         return self.run(x)
 
@@ -90,6 +99,13 @@ class Attention(nn.Module):
         qkv = self.qkv.run(norm(x) if norm is not None else x)
         a = E.attention(qkv, self.num_heads, self.scale)               # softmax(q k^T * scale) v, heads merged
         return self.proj.run(a, res=res, out=res)
+
+    def run_folded(self, x, norm, rowab):
+        """x += proj(attention(qkv(norm(x)))) with `norm` applied in qkv's epilogue from the row statistics `rowab` of x; returns the
+        partial row statistics of the new x out of proj's epilogue."""
+        qkv = self.qkv.run_ln(x, norm, rowab)
+        a = E.attention(qkv, self.num_heads, self.scale)
+        return self.proj.run_stats(a, res=x, out=x)[1]
 
     def forward(self, x):
         return self.run(x)
@@ -120,6 +136,25 @@ class Block(nn.Module):
         self.attn.run(x, res=x, norm=self.norm1)
         self.mlp.run(x, res=x, norm=self.norm2)
         return x
+
+    def folded_ok(self, x):
+        """Round 5: the two LayerNorm launches of a block replaced by row statistics out of the producing GEMM's epilogue and a row
+        affine in the consuming GEMM's (engine.linear_stats / linear_ln; vision_transformer.py:172-175)."""
+        rows, D = x.shape[0] * x.shape[1], x.shape[2]
+        a, m = self.attn, self.mlp
+        if not (isinstance(self.norm1, nn.LayerNorm) and isinstance(self.norm2, nn.LayerNorm) and hasattr(m.act, "ACT")):
+            return False
+        hid = m.fc1.out_features
+        return (E.linear_ln_supported(rows, D, 3 * D, x.dtype) and E.linear_ln_supported(rows, D, D, x.dtype, with_res=True)
+                and E.linear_ln_supported(rows, D, hid, x.dtype, act=m.act.ACT) and E.linear_ln_supported(rows, hid, D, x.dtype, with_res=True)
+                and a.qkv.out_features == 3 * D and m.act.ACT in (E.ACT_NONE, E.ACT_GELU))
+
+    def run_folded(self, x, part, last=False):
+        """run_inplace with the LayerNorms folded: `part` = partial row statistics of x (from whoever wrote x); returns those of the
+        new x (None for the last block)."""
+        D = x.shape[2]
+        part = self.attn.run_folded(x, self.norm1, E.ln_finalize(part, D, self.norm1.epsilon))
+        return self.mlp.run_folded(x, self.norm2, E.ln_finalize(part, D, self.norm2.epsilon), stats=not last)
 
     def forward(self, x):
         E.need_gpu(x, "input")
@@ -206,6 +241,12 @@ class VisionTransformer(nn.Module):
                 return one[None].expand(B, P + 1, D).contiguous()
             # one (B * (1 + P), D) tensor per batch size seen, kept for the life of the model: a captured hipGraph holds its address
             res = self._cached(("patch_res", B, dt), rows_res, deps=(conv,))
+            if len(self.blocks) and all(blk.folded_ok(tok) for blk in self.blocks) and E.linear_ln_supported(B * (P + 1), pk.Cin, D, dt, with_res=True):
+                # LayerNorm statistics ride in the epilogues of the GEMMs that write the token matrix (round 5): no LayerNorm launch
+                part = E.linear_stats(E.patchify(x, ps, 1, dt), pk, bias, res=res, out=tok)[1]
+                for i, blk in enumerate(self.blocks):
+                    part = blk.run_folded(tok, part, last=i == len(self.blocks) - 1)
+                return E.layernorm_rows(tok, B, D, (P + 1) * D, self.norm.gamma.detach(), self.norm.beta.detach(), self.norm.epsilon)
             E.linear(E.patchify(x, ps, 1, dt), pk, bias, res=res, out=tok)
             for blk in self.blocks:
                 blk.run_inplace(tok)

@@ -667,6 +667,21 @@ class Linear(Module):
             x = x.to(dt)
         return E.linear(x, pk, b, res, act, out)
 
+    # LayerNorm folded around the Linear layers of a transformer block (engine.linear_stats / linear_ln, fp16, round 5)
+    def run_stats(self, x, res=None, out=None):
+        """run() of a Linear that writes the residual stream, + the row statistics of its output -> (y, partials)."""
+        dt = E.precision()
+        pk = self._cached("pk", lambda: E.PackedFilter(self.weights.detach().t().contiguous(), dt))
+        b = self._cached("bias", lambda: E._f32(self.biases)) if self.biases is not None else None
+        return E.linear_stats(x, pk, b, res, out)
+
+    def run_ln(self, x, norm, rowab, act=E.ACT_NONE):
+        """act(self(norm(x))) on the raw rows x, `norm` (an nn.LayerNorm) folded in: rowab = engine.ln_finalize(partials of x)."""
+        dt = E.precision()
+        prep = self._cached(("ln_fold", id(norm)), lambda: E.LinearLN(self.weights.detach().t().contiguous(), self.biases.detach() if self.biases is not None else None,
+                                                                      norm.gamma, norm.beta, dt), deps=(norm,))
+        return E.linear_ln(x, prep, rowab, act)
+
     def forward(self, x):
         y = self.run(x)
         return self.act(y) if self.act is not None else y
