@@ -429,6 +429,14 @@ int tlxmi_attention(const tlxmi_attn_desc* d, const void* qkv, const float* bias
  * TLXMI_ERR_UNSUPPORTED otherwise (use tlxmi_attention). */
 int tlxmi_attention_comb(const tlxmi_attn_desc* d, const void* qkv, const float* comb, void* out, void* stream);
 
+/* Swin's windowed attention on IMAGE-order token matrices (swin_transformer.py:316-333): qkv [B / wpi][H * W][3][heads][hd] (the qkv
+ * Linear applied to the rows of the residual stream), out [B / wpi][H * W][heads * hd]; the cyclic shift, window_partition and
+ * window_reverse are row arithmetic inside the kernel.  d->B = number of windows (images * wpi, wpi = (H / ws) * (W / ws)),
+ * d->Ntok = ws * ws <= 64, d->nW = 0 (no shift mask in `comb`) or wpi; comb as tlxmi_attention_comb.  fp16. */
+int tlxmi_attention_windows(const tlxmi_attn_desc* d, const void* qkv, const float* comb, void* out, int H, int W, int ws, int shift,
+                            void* stream);
+
+
 /* ------------------------------------------------------------------------------------------
  * General multi-head attention on separate, strided Q / K / V — the core of tlx.nn.MultiheadAttention and of DETR's
  * MultiHeadAttention.forward (tlxcv/models/detection/detr.py:1003-1062): query and key lengths may differ, layouts

@@ -353,3 +353,71 @@ def test_positional_tlx_npz_checkpoint_gives_the_reference_logits(dev, fp32_mode
     y = task(x)                              # host tensor in: uploaded at the task boundary
     assert np.abs(y.cpu().numpy() - g[f"{tag}_logits"]).max() <= 1e-4
     assert (task.predict(x).cpu().numpy() == g[f"{tag}_logits"].argmax(-1)).all()
+
+
+@pytest.mark.parametrize("shift", [0, 3])
+def test_swin_blocks_without_layernorm_or_window_passes(dev, fp16_mode, shift):
+    """Round 5, SwinTransformerBlock.run_folded (swin_transformer.py:310-337): the residual stream stays in image order, norm1 / norm2
+    live in the epilogues of the GEMMs around them, roll + window_partition / window_reverse are the attention kernel's row
+    arithmetic.  Two chained blocks (the second consumes the statistics of the first's fc2) at stage-3 geometry (14 x 14 tokens,
+    512 channels, 16 heads, K = 512: the residual producer with 8 K tiles) against the oracle restatement on the fp16-rounded
+    input, and against the pass-by-pass path of the same blocks."""
+    from oracle import functional as OF
+    from tlxcv_amd import engine as E
+    from tlxcv_amd.models.classification.swin_transformer import SwinTransformerBlock
+    B, H, W, C, heads = 12, 14, 14, 512, 16
+    blks, ps = [], []
+    for i, sh in enumerate((shift, 0 if shift else 3)):
+        blk = SwinTransformerBlock(dim=C, input_resolution=(H, W), num_heads=heads, window_size=7, shift_size=sh)
+        p = seeded.fill(seeded.shapes_of(blk), 40 + i)
+        blk.load_dict(p)
+        blks.append(blk.to(dev).set_eval())
+        ps.append(p)
+    rng = np.random.default_rng(3)
+    x0 = torch.from_numpy(rng.standard_normal((B, H * W, C)).astype(np.float32)).half()
+    with torch.no_grad():
+        ref = x0.float()
+        for blk, p in zip(blks, ps):
+            ref = OF.swin_block({"b." + k: torch.from_numpy(v) for k, v in p.items()}, "b", ref, H, W, heads, 7, blk.shift_size)
+    xd = x0.to(dev)
+    assert blks[0].folded_ok(xd) and blks[1].folded_ok(xd)
+    # statistics of the input from a producer: an identity-free way is a Linear with stats; here the stand-alone pass + a dummy producer
+    # would hide bugs, so the input goes through PatchMerging-like statistics by hand: sums over 32-channel slots
+    xf = xd.float().view(B * H * W, C // 32, 32)
+    part = torch.stack([xf.sum(-1), (xf * xf).sum(-1)], -1).permute(1, 0, 2).contiguous()       # (C / 32, rows, 2)
+    x = xd.clone()
+    part = blks[0].run_folded(x, part)
+    assert blks[1].run_folded(x, part, stats=False) is None
+    y_old = blks[1].run(blks[0].run(xd.clone()))
+    torch.cuda.synchronize()
+    scale = float(ref.abs().max())
+    assert float((x.float().cpu() - ref).abs().max()) <= 6e-3 * scale
+    assert float((y_old.float().cpu() - ref).abs().max()) <= 6e-3 * scale
+    assert float((x.float() - y_old.float()).abs().max()) <= 6e-3 * scale
+
+
+@pytest.mark.parametrize("batch", [16, 64])
+def test_swin_b_folded_stages_track_golden(dev, fp16_mode, batch):
+    """Swin-B with stages 2 - 4 on the folded path where the token counts allow (batch 16: stages 2 and 3; batch 64: all three, and from
+    128 images the two-stream forward — tests/test_fullsize_gpu.py): the golden images of swin_b_b2 planted in a filler batch, both arms
+    (engine option "lnfold") against the reference-file logits and against each other."""
+    from tlxcv_amd import engine as E
+    g = np.load(os.path.join(GOLDEN, "swin_b_b2.npz"))
+    m = build("swintransformer_base_patch4_window7_224", int(g["weight_seed"]), dev)
+    gold = seeded.image_batch(2, int(g["input_seed"]))
+    x = seeded.image_batch(batch, 321)
+    rows = [0, batch - 2]
+    x[rows] = gold
+    x = torch.from_numpy(x).to(dev)
+    ys = {}
+    try:
+        for arm in (True, False):
+            E.set_option("lnfold", arm)
+            ys[arm] = m(x).float().cpu().numpy()
+    finally:
+        E.set_option("lnfold", True)
+    from util import check_fp16_logits
+    for arm in (True, False):
+        check_fp16_logits(ys[arm][rows], g["logits"], g["argmax"], "swin_b_b2")
+    span = float(g["logits"].max() - g["logits"].min())
+    assert np.abs(ys[True] - ys[False]).max() <= 0.006 * span

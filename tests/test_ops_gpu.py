@@ -4,6 +4,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from oracle import functional as OF
 from tlxcv_amd import engine as E
 from util import rnd, q16, nchw_to_engine, engine_to_nchw, tol
 
@@ -438,3 +439,41 @@ def test_swin_module_level_window_helpers_match_the_reference_definitions(dev):
         back = S.window_reverse(win, ws, H, W, Cc)
         assert back.shape == x.shape and torch.equal(back.cpu(), x)
     assert S.drop_path(x, 0.3, False) is x and S.DropPath(0.2).set_eval()(x) is x
+
+
+@pytest.mark.parametrize("shift", [0, 3])
+@pytest.mark.parametrize("geom", [(3, 14, 14, 16, 32, 7), (2, 28, 28, 8, 32, 7), (5, 7, 7, 4, 64, 7), (2, 8, 16, 3, 96, 4), (1, 56, 56, 4, 32, 7)],
+                         ids=lambda g: "x".join(map(str, g)))
+def test_window_attention_on_image_order_rows(dev, geom, shift):
+    """tlxmi_attention_windows (round 5): the attention of swin_transformer.py:192-229 with the roll, window_partition, window_reverse
+    and roll back of :316-333 as the kernel's row arithmetic — qkv and the result stay in IMAGE order.  Against the oracle's
+    roll -> swin_window_partition -> attention -> swin_window_reverse -> roll on the fp16-rounded qkv, with the relative-position
+    bias and (shifted blocks) the -100 mask of :288-305; windows of 7 x 7 and 4 x 4, head dims 32 / 64 / 96, one window per image
+    (stage 4: no shift there), odd image counts."""
+    B, H, W, heads, hd, ws = geom
+    if ws >= min(H, W):
+        shift = 0
+    shift = min(shift, ws - 1)
+    rng = np.random.default_rng(B * 131 + H)
+    C = heads * hd
+    qkv = q16(rnd(rng, (B, H * W, 3 * C)))
+    bias = rnd(rng, (heads, ws * ws, ws * ws), 0.5)
+    mask = OF.swin_attn_mask(H, W, ws, shift) if shift > 0 else None
+    # oracle: image order -> shifted windows -> attention -> back
+    x = qkv.reshape(B, H, W, 3 * C)
+    if shift > 0:
+        x = torch.roll(x, shifts=(-shift, -shift), dims=(1, 2))
+    xw = OF.swin_window_partition(x, ws).reshape(-1, ws * ws, 3 * C)
+    aw = _ref_attention(xw, heads, hd ** -0.5, bias, mask).reshape(-1, ws, ws, C)
+    y = OF.swin_window_reverse(aw, ws, H, W, C)
+    if shift > 0:
+        y = torch.roll(y, shifts=(shift, shift), dims=(1, 2))
+    want = y.reshape(B, H * W, C)
+    tab = E.attention_table(bias.to(dev), mask.to(dev) if mask is not None else None, ws * ws)
+    got = E.attention_windows(qkv.half().to(dev), heads, hd ** -0.5, tab, 0 if mask is None else mask.shape[0], H, W, ws, shift)
+    torch.testing.assert_close(got.float().cpu(), want, atol=4e-3, rtol=4e-3)
+    # and equal, bit for bit, to the window-order kernel fed by the partition pass (same arithmetic, other addresses)
+    win = E.window_partition(qkv.half().to(dev).view(B, H, W, 3 * C), ws, shift)
+    old = E.attention_comb(win, heads, hd ** -0.5, tab, 0 if mask is None else mask.shape[0])
+    back = E.window_reverse(old, B, H, W, ws, shift)
+    assert torch.equal(back.view(B, H * W, C), got)

@@ -94,6 +94,7 @@ PROTOTYPES = {
     "tlxmi_linear_ln": [_i, _l, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _u, _vp],
     "tlxmi_attention": [C.POINTER(AttnDesc), _vp, _vp, _vp, _vp, _vp],
     "tlxmi_attention_comb": [C.POINTER(AttnDesc), _vp, _vp, _vp, _vp],
+    "tlxmi_attention_windows": [C.POINTER(AttnDesc), _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "tlxmi_mha": [C.POINTER(MhaDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "tlxmi_window_partition": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "tlxmi_window_reverse": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],

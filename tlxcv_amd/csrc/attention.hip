@@ -28,6 +28,10 @@ struct AttnArgs {
     float scale;
     const float* comb;   // bias + mask pre-summed and padded: [max(nW,1)][heads][NP][NP], NP = 32 * ceil(N / 32)
     int debug = 0;       // (the same struct as in attention_mfma.hip: keep the two definitions identical)
+    // Window map (round 5; Swin, tlxmi_attention_windows): wm_ws > 0 -> qkv and out are IMAGE-order token matrices [B / wpi][wm_H * wm_W][...]
+    // and item b = img * wpi + w is the wm_ws x wm_ws window w of image img after the cyclic shift (token (iy, ix) of window (wy, wx) is
+    // pixel ((wy * ws + iy + shift) % H, (wx * ws + ix + shift) % W): swin_transformer.py:316-324, and :327-333 on the way back)
+    int wm_ws = 0, wm_H = 0, wm_W = 0, wm_shift = 0;
 };
 
 template <typename T>
@@ -328,5 +332,28 @@ extern "C" int tlxmi_attention_comb(const tlxmi_attn_desc* d, const void* qkv, c
     AttnArgs a;
     a.qkv = qkv; a.bias = nullptr; a.mask = nullptr; a.out = out; a.comb = comb;
     a.B = d->B; a.N = d->Ntok; a.heads = d->heads; a.hd = d->hd; a.nW = d->nW; a.scale = d->scale;
+    return launch_attn_mfma(a, as_stream(stream));
+}
+
+// Swin's windowed attention on IMAGE-order token matrices (round 5): qkv [Bimg][H * W][3][heads][hd] as the qkv Linear wrote it for the
+// rows of the residual stream, out [Bimg][H * W][heads * hd] in the same row order — roll(-shift) + window_partition on the way in and
+// window_reverse + roll(+shift) on the way out (swin_transformer.py:316-333) are the kernel's row arithmetic, so no launch moves
+// tokens between image order and window order.  comb: the pre-summed bias (+ mask) table of tlxmi_attention_comb, [max(nW,1)][heads]
+// [NP][NP]; nW = 0 (no shift mask) or the number of windows per image.  fp16, ws * ws <= 64 tokens, hd in {32, 64, 96}.
+extern "C" int tlxmi_attention_windows(const tlxmi_attn_desc* d, const void* qkv, const float* comb, void* out, int H, int W, int ws,
+                                       int shift, void* stream) {
+    TLXMI_REQUIRE(d && qkv && out && comb, TLXMI_ERR_BAD_ARG, "attention_windows: null argument");
+    TLXMI_REQUIRE(H > 0 && W > 0 && ws > 0 && H % ws == 0 && W % ws == 0 && shift >= 0 && shift < ws, TLXMI_ERR_BAD_ARG,
+                  "attention_windows: %d x %d tokens in windows of %d, shift %d", H, W, ws, shift);
+    const int wpi = (H / ws) * (W / ws);
+    TLXMI_REQUIRE(d->B > 0 && d->B % wpi == 0 && d->Ntok == ws * ws && d->heads > 0 && d->hd > 0 && (d->nW == 0 || d->nW == wpi), TLXMI_ERR_BAD_ARG,
+                  "attention_windows: B = %d windows of %d tokens, nW = %d for %d windows per image", d->B, d->Ntok, d->nW, wpi);
+    if (!(d->dtype == TLXMI_F16 && (d->hd == 64 || d->hd == 32 || d->hd == 96) && d->Ntok <= 64 && aligned16(qkv) && aligned16(out) && aligned16(comb)))
+        return fail(TLXMI_ERR_UNSUPPORTED, "attention_windows: fp16, hd in {32,64,96}, windows of <= 64 tokens, 16-byte aligned buffers only");
+    if ((long long)(d->B / wpi) * H * W * 3 * d->heads * d->hd * 2 >= (1ll << 40)) return fail(TLXMI_ERR_UNSUPPORTED, "attention_windows: too large");
+    AttnArgs a;
+    a.qkv = qkv; a.bias = nullptr; a.mask = nullptr; a.out = out; a.comb = comb;
+    a.B = d->B; a.N = d->Ntok; a.heads = d->heads; a.hd = d->hd; a.nW = d->nW; a.scale = d->scale;
+    a.wm_ws = ws; a.wm_H = H; a.wm_W = W; a.wm_shift = shift;
     return launch_attn_mfma(a, as_stream(stream));
 }

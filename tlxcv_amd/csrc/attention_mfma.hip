@@ -31,6 +31,10 @@ struct AttnArgs {
     float scale;
     const float* comb;   // bias + mask pre-summed and padded: [max(nW,1)][heads][NP][NP], NP = 32 * ceil(N / 32)
     int debug = 0;       // tuning flavour only (TLXMI_ATTN_DBG; results are wrong): 1 no K / V staging, 2 one query tile per wave only
+    // Window map (round 5; Swin, tlxmi_attention_windows): wm_ws > 0 -> qkv and out are IMAGE-order token matrices [B / wpi][wm_H * wm_W][...]
+    // and item b = img * wpi + w is the wm_ws x wm_ws window w of image img after the cyclic shift (token (iy, ix) of window (wy, wx) is
+    // pixel ((wy * ws + iy + shift) % H, (wx * ws + ix + shift) % W): swin_transformer.py:316-324, and :327-333 on the way back)
+    int wm_ws = 0, wm_H = 0, wm_W = 0, wm_shift = 0;
 };
 
 typedef __fp16 fp16x4 __attribute__((ext_vector_type(4)));
@@ -672,16 +676,33 @@ __global__ __launch_bounds__(256) void attn_win_kernel(const AttnArgs a, const i
 
     u32x4 kreg[PER], vreg[PER], qreg[KS];
     f32x4 treg[NT];
+    // Window map (a.wm_ws > 0, TAB form only: the workgroup is bound to ONE window position, so the image rows of its query and key
+    // tokens are per-thread constants): token tok of window wpos -> row of the image-order token matrix
+    const bool mapped = TAB && a.wm_ws > 0;
+    const int wm_nwx = mapped ? a.wm_W / a.wm_ws : 1, wm_wpi = mapped ? (a.wm_H / a.wm_ws) * wm_nwx : 1, wm_L = a.wm_H * a.wm_W;
+    auto map_row = [&](int wpos, int tok) -> int {
+        const int wy = wpos / wm_nwx, wx = wpos - wy * wm_nwx;
+        const int iy = tok / a.wm_ws, ix = tok - iy * a.wm_ws;
+        int y = wy * a.wm_ws + iy + a.wm_shift, x = wx * a.wm_ws + ix + a.wm_shift;
+        if (y >= a.wm_H) y -= a.wm_H;
+        if (x >= a.wm_W) x -= a.wm_W;
+        return y * a.wm_W + x;
+    };
+    int mq = 0, mk[PER];      // filled below once `tw` (the workgroup's window position) is known
+#pragma unroll
+    for (int u = 0; u < PER; ++u) mk[u] = 0;
     auto fetch = [&](int item) {
         const bool live = item < nitems;
         const int b = live ? item / heads : 0, h = live ? item - b * heads : 0;
-        const half_t* qbase = reinterpret_cast<const half_t*>(a.qkv) + (size_t)b * N * tok_ld + (size_t)h * HD;
+        // mapped: b = img * wpi + wpos, rows of the image; else the tokens of window b are rows b * N ...
+        const size_t row0 = mapped ? (size_t)(b / wm_wpi) * wm_L : (size_t)b * N;
+        const half_t* qbase = reinterpret_cast<const half_t*>(a.qkv) + row0 * tok_ld + (size_t)h * HD;
         const half_t* kbase = qbase + (size_t)heads * HD;
         const half_t* vbase = qbase + (size_t)2 * heads * HD;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             qreg[ks] = u32x4{0u, 0u, 0u, 0u};
-            if (live && qok) qreg[ks] = *reinterpret_cast<const u32x4*>(qbase + (size_t)query * tok_ld + ks * 32 + g * 8);
+            if (live && qok) qreg[ks] = *reinterpret_cast<const u32x4*>(qbase + (size_t)(mapped ? mq : query) * tok_ld + ks * 32 + g * 8);
         }
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
@@ -690,8 +711,9 @@ __global__ __launch_bounds__(256) void attn_win_kernel(const AttnArgs a, const i
             kreg[u] = u32x4{0u, 0u, 0u, 0u};
             vreg[u] = u32x4{0u, 0u, 0u, 0u};
             if (live && i < ITEMS && key < N) {
-                kreg[u] = *reinterpret_cast<const u32x4*>(kbase + (size_t)key * tok_ld + c * 8);
-                vreg[u] = *reinterpret_cast<const u32x4*>(vbase + (size_t)key * tok_ld + c * 8);
+                const size_t kr = mapped ? mk[u] : key;
+                kreg[u] = *reinterpret_cast<const u32x4*>(kbase + kr * tok_ld + c * 8);
+                vreg[u] = *reinterpret_cast<const u32x4*>(vbase + kr * tok_ld + c * 8);
             }
         }
 #pragma unroll
@@ -713,11 +735,19 @@ __global__ __launch_bounds__(256) void attn_win_kernel(const AttnArgs a, const i
     constexpr int G = HD == 32 ? 2 : 1;
     const bool pairs = G == 2 && !(heads & 1);
     // TAB: combo = (window position w, head group hg) = blockIdx % combos, j = blockIdx / combos
-    const int nWe = a.nW > 0 ? a.nW : 1;
+    const int nWe = mapped ? wm_wpi : (a.nW > 0 ? a.nW : 1);      // (mapped: one workgroup per window POSITION also without a mask)
     const int hgs = pairs ? heads >> 1 : heads, combos = nWe * hgs;
     const int combo = TAB ? (int)blockIdx.x % combos : 0, tj = TAB ? (int)blockIdx.x / combos : 0;
     const int tw = combo / hgs, thg = combo - tw * hgs;
     const int nimg = a.B / nWe;
+    if (mapped) {
+        mq = map_row(tw, query < N ? query : 0);
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int key = (t + u * 256) / CPR;
+            mk[u] = map_row(tw, key < N ? key : 0);
+        }
+    }
     auto item_at = [&](int n) -> int {
         if constexpr (TAB) {
             const int img = tj + (pairs ? n >> 1 : n) * spc;
@@ -731,7 +761,7 @@ __global__ __launch_bounds__(256) void attn_win_kernel(const AttnArgs a, const i
         // the table(s) of this workgroup: row-major [npc][npc] fp32 in memory -> fragment order in LDS, zeros beyond npc
         const int ntab = pairs ? 2 : 1;
         for (int tb = 0; tb < ntab; ++tb) {
-            const float* src = a.comb + ((size_t)tw * heads + (pairs ? 2 * thg + tb : thg)) * npc * npc;
+            const float* src = a.comb + ((size_t)(a.nW > 0 ? tw : 0) * heads + (pairs ? 2 * thg + tb : thg)) * npc * npc;
             for (int i = t; i < 64 * NT * 4; i += 256) {
                 const int row = i / (NT * 4), c4 = i - row * (NT * 4);
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -836,13 +866,14 @@ __global__ __launch_bounds__(256) void attn_win_kernel(const AttnArgs a, const i
                 }
             }
             if (query < N) {
-                half_t* obase = reinterpret_cast<half_t*>(a.out) + (size_t)b * N * heads * HD + (size_t)h * HD;
+                const size_t orow = mapped ? (size_t)(b / wm_wpi) * wm_L + mq : (size_t)b * N + query;      // (mapped: back to the token's image row)
+                half_t* obase = reinterpret_cast<half_t*>(a.out) + orow * heads * HD + (size_t)h * HD;
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
                     half4v ov;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) ov[r] = (half_t)(o[dt][r] * inv);
-                    *reinterpret_cast<half4v*>(obase + (size_t)query * heads * HD + dt * 16 + 4 * g) = ov;
+                    *reinterpret_cast<half4v*>(obase + dt * 16 + 4 * g) = ov;
                 }
             }
         }
@@ -861,7 +892,7 @@ template <int HD, int NT, int KF> static int launch_win_kf(const AttnArgs& a, hi
         // (44 KB of LDS with two tables: 3 workgroups per CU; measured at half batch 64, stage 1..4: 66.6 / 34.9 / 20.7 / 11.0 us
         // streaming -> 45.4 / 27.3 / 17.0 / 10.7 us; 2, 4 or 6 per CU lose 10 - 25 % to a partial second round).  A workgroup
         // with a single image still reads no more table bytes than the streaming form does for its items.
-        const int nWe = a.nW > 0 ? a.nW : 1, nimg = a.B / nWe;
+        const int nWe = a.wm_ws > 0 ? (a.wm_H / a.wm_ws) * (a.wm_W / a.wm_ws) : (a.nW > 0 ? a.nW : 1), nimg = a.B / nWe;      // (kernel: nWe)
         const long combos = (long)nWe * (pairs ? a.heads / 2 : a.heads);
         const int wpc = (int)tune_int("TLXMI_WIN_WPC", 3);
         long spc = ((long)cus * wpc) / combos;
@@ -873,6 +904,7 @@ template <int HD, int NT, int KF> static int launch_win_kf(const AttnArgs& a, hi
             return check_launch("attention(windows, resident table)");
         }
     }
+    if (a.wm_ws > 0) return fail(TLXMI_ERR_UNSUPPORTED, "attention_windows: the image-order form needs the resident-table kernel (a pre-summed table)");
     const long units = pairs ? nitems / 2 : nitems;      // head pairs (kernel: item_at)
     const long grid = units < (long)cus * 6 ? units : (long)cus * 6;
     hipLaunchKernelGGL((attn_win_kernel<HD, NT, KF, false>), dim3((unsigned)grid), dim3(256), lds, st, a, (int)nitems, 0);

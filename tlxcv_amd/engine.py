@@ -33,6 +33,8 @@ _options = {"splitk": True,       # classifier heads: K slices side by side (tlx
                                   # emit the row statistics of the residual stream from their epilogues (tlxmi_linear_stats), qkv / fc1 apply
                                   # the normalisation in theirs (tlxmi_linear_ln); off = LayerNorm launches + plain Linear layers (the parity
                                   # tests' other arm)
+            "lnfold_min_rows": 2048,  # (a number) folded Linear layers need at least this many rows (below, the tiled kernels of the dispatcher win)
+            "lnfold_min_c": 256,  # (a number) Swin: fold the LayerNorms of the stages with at least this many channels (tools/ A/B per stage)
             "tail_splitk": False} # Linear layers: the rows of a short last round of 256 x 256 tiles on K slices (_linear_tail): built,
                                   # parity-green, measured a LOSS on the ViT-B/16 forward (10.63 -> 11.61 ms for every K >= 768,
                                   # 10.91 for fc2 only: two more launches + the fp32 partial planes cost more than the idle round)
@@ -41,7 +43,12 @@ _options = {"splitk": True,       # classifier heads: K slices side by side (tlx
 def set_option(name, value):
     if name not in _options:
         raise KeyError(f"unknown option {name!r}; have {sorted(_options)}")
-    _options[name] = bool(value)
+    _options[name] = int(value) if isinstance(_options[name], int) and not isinstance(_options[name], bool) else bool(value)
+
+
+def option_value(name):
+    """A numeric option (set_option keeps the type the option was declared with)."""
+    return _options[name]
 
 
 def option(name):
@@ -761,7 +768,7 @@ def _linear_splits(rows, K, pk, x):
 def linear_ln_supported(rows, K, Cout, dtype, act=ACT_NONE, with_res=False):
     """Whether a Linear of this shape takes the folded-LayerNorm path (tlxmi_linear_stats with_res / tlxmi_linear_ln): fp16 on the
     persistent 256 x 256 GEMM kernel, rows enough to fill it (below ~2 k rows the tiled kernels of the dispatcher win)."""
-    if not _options["lnfold"] or dtype != torch.float16 or rows < 2048:
+    if not _options["lnfold"] or dtype != torch.float16 or rows < _options["lnfold_min_rows"]:
         return False
     return bool(_lib.load().tlxmi_linear_ln_supported(F16, int(rows), int(K), int(Cout), int(act), 1 if with_res else 0))
 
@@ -1143,6 +1150,20 @@ def attention_comb(qkv, heads, scale, table, nW):
     out = torch.empty((B, N, heads * hd), dtype=qkv.dtype, device=qkv.device)
     d = _lib.AttnDesc(dtype=dt_code(qkv.dtype), B=B, Ntok=N, heads=heads, hd=hd, scale=float(scale), nW=nW)
     _lib.call("tlxmi_attention_comb", C.byref(d), _p(qkv), _p(table), _p(out), _stream())
+    return out
+
+
+def attention_windows(qkv, heads, scale, table, nW, H, W, ws, shift):
+    """Swin's windowed attention on IMAGE-order rows (tlxmi_attention_windows): qkv (B, H * W, 3 * heads * hd) -> (B, H * W, heads * hd); the
+    cyclic shift and the window partition / reverse (swin_transformer.py:316-333) are row arithmetic inside the kernel.  table:
+    attention_table(); nW: 0 or the windows per image (with the shift mask in the table)."""
+    need_gpu(qkv, "qkv")
+    B, L, C3 = qkv.shape
+    hd = C3 // (3 * heads)
+    out = torch.empty((B, L, heads * hd), dtype=qkv.dtype, device=qkv.device)
+    wpi = (H // ws) * (W // ws)
+    d = _lib.AttnDesc(dtype=dt_code(qkv.dtype), B=B * wpi, Ntok=ws * ws, heads=heads, hd=hd, scale=float(scale), nW=nW)
+    _lib.call("tlxmi_attention_windows", C.byref(d), _p(qkv), _p(table), _p(out), H, W, ws, shift, _stream())
     return out
 
 

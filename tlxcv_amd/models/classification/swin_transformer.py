@@ -130,6 +130,11 @@ class WindowAttention(nn.Module):
             a = E.attention(qkv, self.num_heads, self.scale, self.bias_table(), mask)  # :202-226
         return self.proj.run(a)
 
+    def table(self, mask, n):
+        """bias (+ shift mask) summed and padded once per layer (tlxmi_attention_comb's table; :205-220 adds the two per forward)."""
+        mkey = None if mask is None else (mask.data_ptr(), mask._version, tuple(mask.shape))
+        return self._cached(("rpb+mask", mkey), lambda: E.attention_table(self.bias_table(), mask, n))
+
     def forward(self, x, mask=None):
         return self.run(x.to(E.precision()).contiguous(), mask)
 
@@ -182,6 +187,42 @@ class SwinTransformerBlock(nn.Module):
         self.mlp.run(h2.view(B, L, C), res=x)                                      # :335, in place
         return x
 
+    # ---- round 5: the block without its two LayerNorm-type passes.  The residual stream stays in IMAGE order all the way: the
+    # LayerNorms are folded around the Linear layers (row statistics out of the proj / fc2 epilogues, the normalisation in the qkv / fc1
+    # epilogues: engine.linear_stats / linear_ln), and roll + window_partition / window_reverse + roll back (:316-333) are the row
+    # arithmetic of the attention kernel (engine.attention_windows) instead of two passes over the activations.
+    def folded_ok(self, x):
+        return self.folded_ok_shape(x.shape[0] * x.shape[1], x.shape[2], x.dtype)
+
+    def folded_ok_shape(self, rows, C, dtype):
+        a, m, ws = self.attn, self.mlp, self.window_size
+        hd = C // self.num_heads
+        if not (E.option("lnfold") and E.option("attn_comb") and dtype == torch.float16 and hd in (32, 64, 96) and ws * ws <= 64
+                and isinstance(self.norm1, nn.LayerNorm) and isinstance(self.norm2, nn.LayerNorm) and hasattr(m.act, "ACT")
+                and m.act.ACT in (E.ACT_NONE, E.ACT_GELU) and C >= E.option_value("lnfold_min_c")):
+            return False
+        hid = m.fc1.out_features
+        return (E.linear_ln_supported(rows, C, 3 * C, dtype) and E.linear_ln_supported(rows, C, C, dtype, with_res=True)
+                and E.linear_ln_supported(rows, C, hid, dtype, act=m.act.ACT) and E.linear_ln_supported(rows, hid, C, dtype, with_res=True))
+
+    def run_folded(self, x, part, stats=True):
+        """x (B, L, C) fp16 updated IN PLACE; part: partial row statistics of x (engine.linear_stats of whoever wrote x); returns those of
+        the new x (None when stats is False)."""
+        H, W = self.input_resolution
+        B, L, C = x.shape
+        assert L == H * W, 'input feature has wrong size'
+        a, ws = self.attn, self.window_size
+        qkv = a.qkv.run_ln(x, self.norm1, E.ln_finalize(part, C, self.norm1.epsilon))                       # norm1 + qkv (:315, :194)
+        tab = a.table(self.attn_mask, ws * ws)
+        aw = E.attention_windows(qkv, a.num_heads, a.scale, tab, 0 if self.attn_mask is None else self.attn_mask.shape[0], H, W, ws,
+                                 self.shift_size)                                                            # :316-333 around :202-226
+        part = a.proj.run_stats(aw, res=x, out=x)[1]                                                         # proj + shortcut (:226, :334)
+        h = self.mlp.fc1.run_ln(x, self.norm2, E.ln_finalize(part, C, self.norm2.epsilon), act=self.mlp.act.ACT)   # norm2 + fc1 + GELU
+        if stats:
+            return self.mlp.fc2.run_stats(h, res=x, out=x)[1]                                                # fc2 + residual (:335)
+        self.mlp.fc2.run(h, res=x, out=x)
+        return None
+
     def forward(self, x):
         E.need_gpu(x, "input")
         return self.run(x.to(E.precision()).contiguous())
@@ -194,13 +235,17 @@ class PatchMerging(nn.Module):
         self.reduction = nn.Linear(in_features=4 * dim, out_features=2 * dim, b_init=nn.initializers.xavier_uniform())
         self.norm = layer_norm(4 * dim)
 
-    def run(self, x):
+    def run(self, x, stats=False):
+        """stats: also return the partial row statistics of the output (engine.linear_stats) when the reduction takes that path:
+        (y, part) instead of y."""
         H, W = self.input_resolution
         B, L, C = x.shape
         assert L == H * W, 'input feature has wrong size'
         assert H % 2 == 0 and W % 2 == 0, 'x size ({}*{}) are not even.'.format(H, W)
         if isinstance(self.norm, nn.LayerNorm):      # gather + concat + norm in one pass (:381-388)
             g = E.patch_merge_layernorm(x.view(B, H, W, C), self.norm.gamma.detach(), self.norm.beta.detach(), self.norm.epsilon)
+            if stats and E.linear_ln_supported(B * L // 4, 4 * C, self.reduction.out_features, g.dtype):
+                return self.reduction.run_stats(g)                                 # + the row statistics for the next stage's first norm1
             return self.reduction.run(g)                                           # :389
         g = E.patch_merge_gather(x.view(B, H, W, C)).view(B, H * W // 4, 4 * C)    # :381-387
         return self.reduction.run(self.norm(g))                                    # :388-389
@@ -222,15 +267,26 @@ class BasicLayer(nn.Module):
                                  attn_drop=attn_drop, layer_norm=layer_norm) for i in range(depth)])
         self.downsample = downsample(input_resolution, dim=dim, layer_norm=layer_norm) if downsample is not None else None
 
-    def run(self, x):
-        for blk in self.blocks:
-            x = blk.run(x)
+    def run(self, x, part=None, next_folded=False):
+        """part: partial row statistics of x when its producer emitted them (the previous stage's PatchMerging) -> the blocks run without
+        LayerNorm / window passes where they can (SwinTransformerBlock.run_folded).  next_folded: ask the PatchMerging for the statistics
+        of its output.  Returns (x, part of the output or None)."""
+        nb = len(self.blocks)
+        for i, blk in enumerate(self.blocks):
+            if part is not None and blk.folded_ok(x):
+                last = i == nb - 1 or not self.blocks[i + 1].folded_ok(x)
+                part = blk.run_folded(x, part, stats=not last)
+            else:
+                x = blk.run(x)
+                part = None
+        part = None
         if self.downsample is not None:
-            x = self.downsample.run(x)
-        return x
+            y = self.downsample.run(x, stats=next_folded)
+            x, part = y if isinstance(y, tuple) else (y, None)
+        return x, part
 
     def forward(self, x):
-        return self.run(x.to(E.precision()).contiguous())
+        return self.run(x.to(E.precision()).contiguous())[0]
 
 
 class PatchEmbed(nn.Module):
@@ -295,8 +351,12 @@ class SwinTransformer(nn.Module):
     def forward_features(self, x):
         self._require_eval()
         x = self.patch_embed(x)                        # :602
-        for layer in self.layers:                      # :606-607
-            x = layer.run(x)
+        part = None
+        for i, layer in enumerate(self.layers):        # :606-607
+            nxt = self.layers[i + 1] if i + 1 < len(self.layers) else None
+            # (the next stage's first block decides from the shape its input will have)
+            want = nxt is not None and nxt.blocks[0].folded_ok_shape(x.shape[0] * x.shape[1] // 4, x.shape[2] * 2, x.dtype)
+            x, part = layer.run(x, part, next_folded=want)
         x = self.norm(x)                               # :608
         return E.global_avgpool(x)                     # mean over tokens == avgpool(x^T) + flatten, :609-610
 
