@@ -329,3 +329,21 @@ def test_folded_layernorm_refuses_what_the_persistent_kernel_does_not_take(dev):
 def _load():
     from tlxcv_amd import _lib
     return _lib.load()
+
+
+@pytest.mark.parametrize("C", [256, 512, 768, 1024, 2048, 4096])
+def test_ln_finalize_every_width(dev, C):
+    """tlxmi_ln_finalize on its own: partial (sum, sum of squares) per 32-channel slot -> (rstd, -mean * rstd); the register-resident forms
+    (<= 16 / <= 32 slots) and the two-pass form for wider rows, rows with a mean far from zero, against torch on the same values."""
+    rng = np.random.default_rng(C)
+    rows = 1000 + 37
+    x = rnd(rng, (rows, C))
+    x[3] += 50.0
+    x[rows - 1] = x[rows - 1] * 0.1 - 5.0          # |mean| = 50 sigma.  (sum, sum of squares) in fp32 carry the variance to about
+    xs = x.view(rows, C // 32, 32)                 # 1e-7 * (1 + mean^2 / var) relative: 2.5e-4 here, the format's limit, not the kernel's
+    part = torch.stack([xs.sum(-1), (xs * xs).sum(-1)], -1).permute(1, 0, 2).contiguous().to(dev)
+    eps = 1e-5
+    rowab = E.ln_finalize(part, C, eps).cpu()
+    rstd = 1.0 / torch.sqrt(x.double().var(1, unbiased=False) + eps)
+    torch.testing.assert_close(rowab[:, 0].double(), rstd, atol=0, rtol=1e-3)
+    torch.testing.assert_close(rowab[:, 1].double(), -x.double().mean(1) * rstd, atol=1e-4, rtol=1e-3)

@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256, 2) void attn_dma_kernel(const AttnArgs a) {
             for (int j = 0; j < (NP / 8 + 3) / 4; ++j) {
                 const int p = wv + 4 * j;
                 const int key = 8 * p + krow;
-                const int off = (p < NP / 8 && key < N) ? base + (int)(key * tok_ld * 2) + which * heads * HD * 2 : OOB;
+                const int off = (p < NP / 8 && key < N && !TLXMI_DBG(a, 1)) ? base + (int)(key * tok_ld * 2) + which * heads * HD * 2 : OOB;      // (ablation bit 1, tuning flavour: no K / V traffic — zero rows)
                 if (p < NP / 8)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr_t)((which == 1 ? Ks : Vs) + p * 1024), 16, off, 0, 0, 0);
             }

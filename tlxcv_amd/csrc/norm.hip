@@ -300,29 +300,46 @@ extern "C" int tlxmi_layernorm(const void* x, const float* gamma, const float* b
 // M2 = sum_i (q_i - s_i * m_i) + 32 * sum_i (m_i - mean)^2 with m_i = s_i / 32 — so a row whose mean is far from zero loses no more
 // than each 32-channel group loses on its own.
 namespace tlxmi {
+// SL >= slots: every partial of the row in registers at once (ONE round of loads; the two-pass form re-read them: 5 - 6 us per launch
+// of dependent latencies, 4 % of Swin-B's kernel time); SL = 0: the generic two-pass form for wider rows.
+template <int SL>
 __global__ __launch_bounds__(64) void ln_finalize_kernel(const f32x2* __restrict__ part, int slots, int rows, float inv_c, float eps,
                                                          f32x2* __restrict__ rowab) {
     const int r = blockIdx.x * 64 + threadIdx.x;
     if (r >= rows) return;
-    // 16 independent loads in flight per thread (a dependent chain of `slots` loads made this launch 12 us for 24 slots)
-    float sum = 0.f;
-    for (int i0 = 0; i0 < slots; i0 += 16) {
-        float s16[16];
+    float mean, m2 = 0.f;
+    if constexpr (SL > 0) {
+        f32x2 p[SL];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) s16[i] = i0 + i < slots ? part[(size_t)(i0 + i) * rows + r][0] : 0.f;
+        for (int i = 0; i < SL; ++i) p[i] = i < slots ? part[(size_t)i * rows + r] : f32x2{0.f, 0.f};
+        float sum = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) sum += s16[i];
-    }
-    const float mean = sum * inv_c;
-    float m2 = 0.f;
-    for (int i0 = 0; i0 < slots; i0 += 16) {
-        f32x2 p16[16];
+        for (int i = 0; i < SL; ++i) sum += p[i][0];
+        mean = sum * inv_c;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) p16[i] = i0 + i < slots ? part[(size_t)(i0 + i) * rows + r] : f32x2{32.f * mean, 32.f * mean * mean};
+        for (int i = 0; i < SL; ++i) {
+            const float mi = p[i][0] * (1.f / 32.f), d = mi - mean;
+            if (i < slots) m2 += (p[i][1] - p[i][0] * mi) + 32.f * d * d;
+        }
+    } else {
+        float sum = 0.f;
+        for (int i0 = 0; i0 < slots; i0 += 16) {
+            float s16[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const float mi = p16[i][0] * (1.f / 32.f), d = mi - mean;
-            m2 += (p16[i][1] - p16[i][0] * mi) + 32.f * d * d;
+            for (int i = 0; i < 16; ++i) s16[i] = i0 + i < slots ? part[(size_t)(i0 + i) * rows + r][0] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sum += s16[i];
+        }
+        mean = sum * inv_c;
+        for (int i0 = 0; i0 < slots; i0 += 16) {
+            f32x2 p16[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) p16[i] = i0 + i < slots ? part[(size_t)(i0 + i) * rows + r] : f32x2{32.f * mean, 32.f * mean * mean};
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float mi = p16[i][0] * (1.f / 32.f), d = mi - mean;
+                m2 += (p16[i][1] - p16[i][0] * mi) + 32.f * d * d;
+            }
         }
     }
     const float rstd = 1.f / sqrtf(fmaxf(m2 * inv_c, 0.f) + eps);
@@ -335,8 +352,12 @@ extern "C" int tlxmi_ln_finalize(const float* partials, int slots, int64_t rows,
     TLXMI_REQUIRE(partials && rowab && slots > 0 && rows > 0 && rows < (1ll << 27) && C == 32 * slots && eps >= 0.f, TLXMI_ERR_BAD_ARG,
                   "ln_finalize: bad argument (C must be 32 * slots)");
     TLXMI_REQUIRE(((uintptr_t)partials & 7) == 0 && ((uintptr_t)rowab & 15) == 0, TLXMI_ERR_ALIGNMENT, "ln_finalize: partials 8-byte, rowab 16-byte aligned");
-    hipLaunchKernelGGL(ln_finalize_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, as_stream(stream),
-                       reinterpret_cast<const f32x2*>(partials), slots, (int)rows, 1.f / (float)C, eps, reinterpret_cast<f32x2*>(rowab));
+    const dim3 grid((unsigned)((rows + 63) / 64));
+    const f32x2* pp = reinterpret_cast<const f32x2*>(partials);
+    f32x2* ab = reinterpret_cast<f32x2*>(rowab);
+    if (slots <= 16) hipLaunchKernelGGL(ln_finalize_kernel<16>, grid, dim3(64), 0, as_stream(stream), pp, slots, (int)rows, 1.f / (float)C, eps, ab);
+    else if (slots <= 32) hipLaunchKernelGGL(ln_finalize_kernel<32>, grid, dim3(64), 0, as_stream(stream), pp, slots, (int)rows, 1.f / (float)C, eps, ab);
+    else hipLaunchKernelGGL(ln_finalize_kernel<0>, grid, dim3(64), 0, as_stream(stream), pp, slots, (int)rows, 1.f / (float)C, eps, ab);
     return check_launch("ln_finalize");
 }
 
