@@ -114,6 +114,10 @@ int tlxmi_patchify(const void* src, int src_dtype, void* dst, int dst_dtype, int
  * fp16.  D in {96, 128, 192, 256}; H, W multiples of 4; all buffers 16-byte aligned. */
 int tlxmi_patch_embed4(const void* x, int x_dtype, const void* w, const float* bias, const float* gamma,
                        const float* beta, void* y, int N, int H, int W, int D, float eps, void* stream);
+/* The same + SwinTransformer(ape=True)'s absolute position embedding (swin_transformer.py:561-565, 603-604): pos fp32 [H/4 * W/4][D]
+ * is added to every image's tokens after the LayerNorm. */
+int tlxmi_patch_embed4_pos(const void* x, int x_dtype, const void* w, const float* bias, const float* gamma, const float* beta,
+                           const float* pos, void* y, int N, int H, int W, int D, float eps, void* stream);
 /* dst: [N][C][H][W] contiguous; src: NHWC with pixel stride ld (>= C). */
 int tlxmi_nhwc_to_nchw(const void* src, int src_dtype, int ld, void* dst, int dst_dtype, int N, int C,
                        int H, int W, void* stream);
@@ -382,6 +386,10 @@ int tlxmi_layernorm_window_partition(const void* x, const float* gamma, const fl
 int tlxmi_window_reverse_layernorm(const void* win, const void* res, const float* gamma, const float* beta,
                                    void* sum, void* y, int dtype, int B, int H, int W, int C, int ws, int shift,
                                    float eps, void* stream);
+
+/* Row softmax over the last axis (tlx.ops.softmax / nn.Softmax of a reference forward run layer by layer: detr.py:1011-1043,
+ * vision_transformer.py:118): y[r][c] = exp(x[r][c] - max_r) / sum_c exp(...), fp32 arithmetic, dtype of x out; any C, strides in elements. */
+int tlxmi_softmax_rows(const void* x, void* y, int dtype, int64_t rows, int C, int64_t x_ld, int64_t y_ld, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * LayerNorm folded AROUND the Linear layers of a transformer block (fp16; vision_transformer.py:144-175: norm1 -> attn.qkv,

@@ -514,6 +514,8 @@ def swin(p, x, arch="swintransformer_base_patch4_window7_224"):
     c = SWIN_CFG[arch]
     x = conv(p, "patch_embed.proj", x, 4, 0)                                         # PatchEmbed.forward :498-504
     x = layernorm(p, "patch_embed.norm", x.flatten(2).permute(0, 2, 1), LN_EPS)
+    if "absolute_pos_embed" in p:                                                    # ape=True, :561-565, :603-604
+        x = x + _t(p, "absolute_pos_embed")
     res = c["img"] // 4
     for li, (depth, heads) in enumerate(zip(c["depths"], c["heads"])):
         H = W = res // 2 ** li

@@ -91,3 +91,34 @@ def test_bench_py_two_ranks_rehearsal_prints_one_line_with_gathered_logits(dev):
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak" and line["unit"] == "images/sec"
     assert line["config"]["global_batch"] == 512 and line["value"] > 0 and line["roofline"]["frac"] > 0
+
+
+def test_one_rank_on_the_real_rccl_backend_gathers_beside_a_replaying_graph(dev, tmp_path):
+    """RCCL executed once on the one GPU this box has.  A fresh child process initialises the "nccl" (= RCCL) backend at
+    world size 1 and drives dist.GatherPipe(force_collective=True) — librccl loaded, a communicator created, the asynchronous
+    all_gather_into_tensor on RCCL's stream next to hipGraph replays on the caller's — over six steps whose inputs alternate; every
+    gathered block must be that step's logits.  (No scaling is measured here: that is the driver's 8-GPU run.)"""
+    port = _free_port()
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("TLXMI_DIST_BACKEND", None)
+    p = subprocess.Popen([sys.executable, os.path.join(REPO, "tests", "dist_rccl1_worker.py"), str(tmp_path)], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    try:
+        o, _ = p.communicate(timeout=600)
+    except subprocess.TimeoutExpired:
+        p.kill()
+        raise
+    o = o.decode(errors="replace")
+    assert p.returncode == 0 and "RCCL_ONE_RANK_OK" in o, o[-3000:]
+    g = np.load(os.path.join(GOLDEN, "resnet50_b4.npz"))
+    ref = g["logits"]
+    r = np.load(os.path.join(str(tmp_path), "rccl1.npz"))
+    check_fp16_logits(r["logits_sharded"], ref, g["argmax"], "resnet50_b4")
+    ps = r["pipe_steps"]
+    assert ps.shape == (6, 4, 1000)
+    for i in range(6):
+        want, am = (ref, g["argmax"]) if i % 2 == 0 else (ref[::-1], g["argmax"][::-1])
+        check_fp16_logits(ps[i], want, am, "resnet50_b4")
+    assert np.array_equal(ps[0], ps[2]) and np.array_equal(ps[1], ps[3])          # replays are bit-reproducible through the gather
+    check_fp16_logits(r["gather_rows"], ref, g["argmax"], "resnet50_b4")

@@ -421,3 +421,33 @@ def test_swin_b_folded_stages_track_golden(dev, fp16_mode, batch):
         check_fp16_logits(ys[arm][rows], g["logits"], g["argmax"], "swin_b_b2")
     span = float(g["logits"].max() - g["logits"].min())
     assert np.abs(ys[True] - ys[False]).max() <= 0.006 * span
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+def test_swin_absolute_position_embedding(dev, prec):
+    """SwinTransformer(ape=True) (swin_transformer.py:561-565, 603-604: x = patch_embed(x) + absolute_pos_embed; no shipped config sets
+    it): fp32 through the stand-alone path (affine_act with the table as a per-element shift), fp16 through the one-pass patch embedding
+    that adds the table in its store (tlxmi_patch_embed4_pos) — both against the oracle restatement with the same weights."""
+    import tlxcv_amd
+    from oracle import functional as OF
+    from tlxcv_amd import models
+    tlxcv_amd.set_precision(prec)
+    try:
+        m = models.swintransformer_tiny_patch4_window7_224(ape=True)
+        params = seeded.fill(seeded.shapes_of(m), 17)
+        assert "absolute_pos_embed" in params and params["absolute_pos_embed"].shape == (1, 3136, 96)
+        params["absolute_pos_embed"] = (np.random.default_rng(2).standard_normal((1, 3136, 96)) * 0.5).astype(np.float32)   # visibly non-zero
+        m.load_dict(params)
+        m = m.to(dev).set_eval()
+        x = torch.from_numpy(seeded.image_batch(2, 8))
+        with torch.no_grad():
+            p = {k: torch.from_numpy(v) for k, v in params.items()}
+            ref = OF.swin(p, x, "swintransformer_tiny_patch4_window7_224").numpy()
+            p.pop("absolute_pos_embed")
+            ref_no = OF.swin(p, x, "swintransformer_tiny_patch4_window7_224").numpy()
+        assert np.abs(ref - ref_no).max() > 1e-2          # the table matters for this fixture
+        y = m(x.to(dev)).float().cpu().numpy()
+        span = float(ref.max() - ref.min())
+        assert np.abs(y - ref).max() <= (1e-4 if prec == "fp32" else 0.004 * span)
+    finally:
+        tlxcv_amd.set_precision("fp16")

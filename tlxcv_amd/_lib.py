@@ -62,6 +62,7 @@ PROTOTYPES = {
     "tlxmi_nchw_to_nhwc_s2d": [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "tlxmi_patchify": [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "tlxmi_patch_embed4": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
+    "tlxmi_patch_embed4_pos": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
     "tlxmi_nhwc_to_nchw": [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp],
     "tlxmi_pack_filter": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     "tlxmi_fold_bn": [_vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp],
@@ -91,6 +92,7 @@ PROTOTYPES = {
     "tlxmi_window_reverse_layernorm": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp],
     "tlxmi_linear_stats": [_i, _l, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _u, _vp],
     "tlxmi_ln_finalize": [_vp, _i, _l, _i, _f, _vp, _vp],
+    "tlxmi_softmax_rows": [_vp, _vp, _i, _l, _i, _l, _l, _vp],
     "tlxmi_linear_ln": [_i, _l, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _u, _vp],
     "tlxmi_attention": [C.POINTER(AttnDesc), _vp, _vp, _vp, _vp, _vp],
     "tlxmi_attention_comb": [C.POINTER(AttnDesc), _vp, _vp, _vp, _vp],

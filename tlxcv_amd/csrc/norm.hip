@@ -412,3 +412,54 @@ extern "C" int tlxmi_window_reverse_layernorm(const void* win, const void* res, 
     if (dt == TLXMI_F16) return launch_ln<half_t>(win, gamma, beta, y, rows, C, C, C, eps, as_stream(stream), nullptr, wm, res, sum);
     return launch_ln<float>(win, gamma, beta, y, rows, C, C, C, eps, as_stream(stream), nullptr, wm, res, sum);
 }
+
+// Row softmax over the last axis (tlx.ops.softmax / nn.Softmax of a reference forward run layer by layer, e.g. the attention of
+// detr.py:1011-1043 or vision_transformer.py:118): one wave per row, the row read twice (maximum, then exp and sum kept in registers for
+// rows of up to 64 * 8 elements, else a third read), fp32 arithmetic, the input's dtype out.  Any C >= 1, any row stride; a coverage
+// path (the fused attention kernels never materialise their scores).
+namespace tlxmi {
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const T* __restrict__ x, T* __restrict__ y, long rows, int C, long x_ld, long y_ld) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const T* xr = x + row * x_ld;
+    T* yr = y + row * y_ld;
+    float mx = -INFINITY;
+    for (int c = lane; c < C; c += 64) mx = fmaxf(mx, (float)xr[c]);
+    mx = wave_max(mx);
+    if (mx == -INFINITY) mx = 0.f;      // a row of -inf: torch gives NaN (0 / 0); keep that: exp(-inf - 0) = 0, sum 0, 0 / 0
+    float e[8], sum = 0.f;
+    const bool small = C <= 512;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = lane + 64 * i;
+        e[i] = (small && c < C) ? __expf((float)xr[c] - mx) : 0.f;
+        sum += e[i];
+    }
+    if (!small)
+        for (int c = lane; c < C; c += 64) sum += __expf((float)xr[c] - mx);
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    if (small) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = lane + 64 * i;
+            if (c < C) yr[c] = (T)(e[i] * inv);
+        }
+    } else {
+        for (int c = lane; c < C; c += 64) yr[c] = (T)(__expf((float)xr[c] - mx) * inv);
+    }
+}
+}  // namespace tlxmi
+
+extern "C" int tlxmi_softmax_rows(const void* x, void* y, int dt, int64_t rows, int C, int64_t x_ld, int64_t y_ld, void* stream) {
+    using namespace tlxmi;
+    TLXMI_REQUIRE(x && y && rows > 0 && C > 0 && x_ld >= C && y_ld >= C, TLXMI_ERR_BAD_ARG, "softmax_rows: bad argument");
+    TLXMI_REQUIRE(dt == TLXMI_F16 || dt == TLXMI_F32, TLXMI_ERR_BAD_ARG, "softmax_rows: bad dtype");
+    TLXMI_REQUIRE((rows + 3) / 4 < (1ll << 31), TLXMI_ERR_UNSUPPORTED, "softmax_rows: too many rows");
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    if (dt == TLXMI_F16) hipLaunchKernelGGL(softmax_rows_kernel<half_t>, grid, dim3(256), 0, as_stream(stream), (const half_t*)x, (half_t*)y, (long)rows, C, (long)x_ld, (long)y_ld);
+    else hipLaunchKernelGGL(softmax_rows_kernel<float>, grid, dim3(256), 0, as_stream(stream), (const float*)x, (float*)y, (long)rows, C, (long)x_ld, (long)y_ld);
+    return check_launch("softmax_rows");
+}

@@ -21,7 +21,7 @@ namespace tlxmi {
 template <typename TS, int NT, bool NORM>
 __global__ __launch_bounds__(256) void patch_embed4_kernel(const TS* __restrict__ x, const half_t* __restrict__ w, const float* __restrict__ bias,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta, half_t* __restrict__ y,
-                                                           int H, int W, long tokens, float eps) {
+                                                           int H, int W, long tokens, float eps, const float* __restrict__ pos) {
     constexpr int D = 16 * NT;
     const int lane = threadIdx.x & 63, px = lane & 15, g = lane >> 4;
     const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
@@ -124,9 +124,16 @@ __global__ __launch_bounds__(256) void patch_embed4_kernel(const TS* __restrict_
         }
         const long p = tile * 16 + px;
         if (p < tokens) {
+            // absolute position embedding (swin_transformer.py:561-565, 603-604: x + absolute_pos_embed after the norm): row p % (Ho * Wo) of pos
+            const float* prow = pos ? pos + (size_t)(p % ((long)Ho * Wo)) * D + 8 * g : nullptr;
 #pragma unroll
             for (int j = 0; j < NT / 2; ++j) {
                 half8v o;
+                f32x4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = p0;
+                if (prow) {
+                    p0 = *reinterpret_cast<const f32x4*>(prow + 32 * j);
+                    p1 = *reinterpret_cast<const f32x4*>(prow + 32 * j + 4);
+                }
 #pragma unroll
                 for (int r_ = 0; r_ < 4; ++r_) {
                     float a0 = acc[2 * j][r_], a1 = acc[2 * j + 1][r_];
@@ -134,8 +141,8 @@ __global__ __launch_bounds__(256) void patch_embed4_kernel(const TS* __restrict_
                         a0 = (a0 - mean) * rstd * gm[2 * j][r_] + bt[2 * j][r_];
                         a1 = (a1 - mean) * rstd * gm[2 * j + 1][r_] + bt[2 * j + 1][r_];
                     }
-                    o[r_] = (half_t)a0;
-                    o[4 + r_] = (half_t)a1;
+                    o[r_] = (half_t)(a0 + p0[r_]);
+                    o[4 + r_] = (half_t)(a1 + p1[r_]);
                 }
                 *reinterpret_cast<half8v*>(y + p * D + 32 * j + 8 * g) = o;
             }
@@ -164,9 +171,9 @@ using namespace tlxmi;
 // x: [N][3][H][W] fp32 or fp16 (16-byte aligned, W % 4 == 0); w: [D][64] fp16, k = 16 c + 4 ky + kx for k < 48, zero above (the
 // caller's re-indexing of the conv filter [D][3][4][4]); bias / gamma / beta: fp32 [D] or null (gamma == null: no LayerNorm);
 // y: [N * H/4 * W/4][D] fp16.  D in {96, 128, 192, 256}.
-extern "C" int tlxmi_patch_embed4(const void* x, int xdt, const void* w, const float* bias, const float* gamma, const float* beta,
-                                  void* y, int N, int H, int W, int D, float eps, void* stream) {
-    TLXMI_REQUIRE(x && w && y && aligned16(x) && aligned16(w) && aligned16(y) && aligned16(bias) && aligned16(gamma) && aligned16(beta),
+static int patch_embed4_impl(const void* x, int xdt, const void* w, const float* bias, const float* gamma, const float* beta, const float* pos,
+                             void* y, int N, int H, int W, int D, float eps, void* stream) {
+    TLXMI_REQUIRE(x && w && y && aligned16(x) && aligned16(w) && aligned16(y) && aligned16(bias) && aligned16(gamma) && aligned16(beta) && aligned16(pos),
                   TLXMI_ERR_BAD_ARG, "patch_embed4: null or misaligned buffer");
     TLXMI_REQUIRE(xdt == TLXMI_F32 || xdt == TLXMI_F16, TLXMI_ERR_BAD_ARG, "patch_embed4: bad dtype");
     TLXMI_REQUIRE(N > 0 && H > 0 && W > 0 && H % 4 == 0 && W % 4 == 0 && (gamma == nullptr) == (beta == nullptr), TLXMI_ERR_BAD_ARG,
@@ -182,9 +189,9 @@ extern "C" int tlxmi_patch_embed4(const void* x, int xdt, const void* w, const f
 #define PE_LAUNCH(TS, NT)                                                                                                                  \
     {                                                                                                                                      \
         if (gamma) hipLaunchKernelGGL((patch_embed4_kernel<TS, NT, true>), dim3((unsigned)grid), dim3(256), 0, st, (const TS*)x, (const half_t*)w, \
-                                      bias, gamma, beta, (half_t*)y, H, W, tokens, eps);                                                   \
+                                      bias, gamma, beta, (half_t*)y, H, W, tokens, eps, pos);                                              \
         else hipLaunchKernelGGL((patch_embed4_kernel<TS, NT, false>), dim3((unsigned)grid), dim3(256), 0, st, (const TS*)x, (const half_t*)w,      \
-                                bias, gamma, beta, (half_t*)y, H, W, tokens, eps);                                                         \
+                                bias, gamma, beta, (half_t*)y, H, W, tokens, eps, pos);                                                    \
     }
 #define PE_DT(NT)                                \
     {                                            \
@@ -198,4 +205,17 @@ extern "C" int tlxmi_patch_embed4(const void* x, int xdt, const void* w, const f
 #undef PE_DT
 #undef PE_LAUNCH
     return check_launch("patch_embed4");
+}
+
+extern "C" int tlxmi_patch_embed4(const void* x, int xdt, const void* w, const float* bias, const float* gamma, const float* beta,
+                                  void* y, int N, int H, int W, int D, float eps, void* stream) {
+    return patch_embed4_impl(x, xdt, w, bias, gamma, beta, nullptr, y, N, H, W, D, eps, stream);
+}
+
+// + the absolute position embedding of SwinTransformer(ape=True) (swin_transformer.py:561-565, 603-604): pos fp32 [H/4 * W/4][D], added
+// to every image's tokens after the LayerNorm, before the one rounding to fp16.
+extern "C" int tlxmi_patch_embed4_pos(const void* x, int xdt, const void* w, const float* bias, const float* gamma, const float* beta,
+                                      const float* pos, void* y, int N, int H, int W, int D, float eps, void* stream) {
+    TLXMI_REQUIRE(pos, TLXMI_ERR_BAD_ARG, "patch_embed4_pos: null position table");
+    return patch_embed4_impl(x, xdt, w, bias, gamma, beta, pos, y, N, H, W, D, eps, stream);
 }

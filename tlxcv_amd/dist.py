@@ -19,7 +19,7 @@ def init(backend=None):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("TLXMI_DIST_INIT_SINGLE") == "1") and not dist.is_initialized():      # (single: the one-rank RCCL rehearsal)
         if backend is None:
             backend = os.environ.get("TLXMI_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if torch.cuda.is_available():
@@ -87,8 +87,12 @@ class GatherPipe:
     for the PREVIOUS step's gather and returns that result (None on the first call).  flush() returns the last one.
     With the gloo rehearsal backend (device tensors staged through the host) every gather is synchronous."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, force_collective=False):
+        """force_collective: take the collective branch also at world size 1 (an initialised process group is required) — a one-rank
+        RCCL communicator still loads librccl, creates the communicator and runs the asynchronous all_gather_into_tensor on RCCL's
+        stream beside the caller's hipGraph replays: tests/test_dist_gpu.py runs the real backend that way on a one-GPU box."""
         self.group = group
+        self.force = bool(force_collective)
         self.stage = [None, None]
         self.n = 0
         self.pending = None        # (out, work)
@@ -103,7 +107,7 @@ class GatherPipe:
         return out
 
     def put(self, local_logits):
-        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+        if not dist.is_initialized() or (dist.get_world_size(self.group) == 1 and not self.force):
             # single rank: still a staged copy — the caller's next replay rewrites `local_logits` before this result is read
             k = self.n & 1
             self.n += 1

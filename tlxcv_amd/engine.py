@@ -306,15 +306,29 @@ def patch_embed4_filter(w_oihw):
     return out
 
 
-def patch_embed4(x, w64, bias, gamma, beta, eps):
-    """(N,3,H,W) fp32 / fp16 -> (N, H/4 * W/4, D) fp16 = LayerNorm(conv4x4/4(x) + bias) (no LayerNorm when gamma is None), one pass."""
+def patch_embed4(x, w64, bias, gamma, beta, eps, pos=None):
+    """(N,3,H,W) fp32 / fp16 -> (N, H/4 * W/4, D) fp16 = LayerNorm(conv4x4/4(x) + bias) (no LayerNorm when gamma is None) [+ pos, the
+    (H/4 * W/4, D) absolute position embedding of SwinTransformer(ape=True)], one pass."""
     need_gpu(x, "input")
+    if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] % 4 or x.shape[3] % 4:
+        raise RuntimeError(f"patch_embed4: a (N, 3, H, W) image with H, W multiples of 4 is expected, got {tuple(x.shape)} (the kernel reads 3 colour planes)")
+    if w64.dim() != 2 or w64.shape[1] != 64 or w64.dtype != torch.float16:
+        raise RuntimeError("patch_embed4: the filter must be the (D, 64) fp16 image of patch_embed4_filter()")
+    if (gamma is None) != (beta is None):
+        raise RuntimeError("patch_embed4: gamma and beta go together (both None: no LayerNorm)")
     if x.dtype not in (torch.float16, torch.float32):
         x = x.float()
     x = x.contiguous()
     N, Cc, H, W = x.shape
     D = w64.shape[0]
     y = torch.empty((N, (H // 4) * (W // 4), D), dtype=torch.float16, device=x.device)
+    if pos is not None:
+        pos = _f32(pos).reshape(-1, D).contiguous()
+        if pos.shape[0] != (H // 4) * (W // 4):
+            raise RuntimeError(f"patch_embed4: position table of {pos.shape[0]} rows for {(H // 4) * (W // 4)} tokens")
+        _lib.call("tlxmi_patch_embed4_pos", _p(x), dt_code(x.dtype), _p(w64), _p(_f32(bias)), _p(_f32(gamma)), _p(_f32(beta)), _p(pos), _p(y), N, H, W, D,
+                  C.c_float(eps), _stream())
+        return y
     _lib.call("tlxmi_patch_embed4", _p(x), dt_code(x.dtype), _p(w64), _p(_f32(bias)), _p(_f32(gamma)), _p(_f32(beta)), _p(y), N, H, W, D,
               C.c_float(eps), _stream())
     return y
@@ -1030,6 +1044,57 @@ def broadcast_rows_into(vec_, out, rows, out_ld):
     Cc = vec_.numel()
     _lib.call("tlxmi_copy_channels", _p(vec_), _p(out), dt_code(out.dtype), rows, Cc, 0, out_ld, _stream())
     return out
+
+
+def softmax(x, axis=-1):
+    """tlx.ops.softmax / nn.Softmax on the device (tlxmi_softmax_rows): fp16 / fp32, any axis (another axis than the last is moved there
+    and back: two layout copies)."""
+    need_gpu(x, "input")
+    if x.dtype not in (torch.float16, torch.float32):
+        x = x.to(_precision)
+    ax = axis % x.dim()
+    if ax != x.dim() - 1:
+        return softmax(x.movedim(ax, -1).contiguous(), -1).movedim(-1, ax)
+    if not x.is_contiguous():
+        x = x.contiguous()
+    Cc = x.shape[-1]
+    y = torch.empty_like(x)
+    if x.numel():
+        _lib.call("tlxmi_softmax_rows", _p(x), _p(y), dt_code(x.dtype), x.numel() // Cc, Cc, Cc, Cc, _stream())
+    return y
+
+
+def matmul(a, b, transpose_a=False, transpose_b=False):
+    """tlx.matmul on libtlxmi (detr.py:1013 `tlx.matmul(q, k, transpose_b=True)`, vision_transformer.py:117-120): every (M, K) x (K, N)
+    product of the broadcast batch is one tlxmi_conv2d launch (a Linear with the second operand packed as its filter) — a coverage path
+    for reference-style layer-by-layer forwards (the engine's own models run fused attention kernels); fp16 or fp32, fp32 accumulation."""
+    need_gpu(a, "matmul operand")
+    need_gpu(b, "matmul operand")
+    dt = a.dtype if a.dtype in (torch.float16, torch.float32) else _precision
+    a, b = a.to(dt), b.to(dt)
+    if a.dim() < 2 or b.dim() < 2:
+        raise RuntimeError("matmul: operands of at least two dimensions are expected")
+    if transpose_a:
+        a = a.transpose(-1, -2)
+    w = b if transpose_b else b.transpose(-1, -2)          # (..., N, K): the second operand as a Linear's [out][in] weight
+    M, K, N = a.shape[-2], a.shape[-1], w.shape[-2]
+    if w.shape[-1] != K:
+        raise RuntimeError(f"matmul: inner dimensions {K} and {w.shape[-1]} differ")
+    batch = torch.broadcast_shapes(a.shape[:-2], w.shape[:-2])
+    a = a.expand(*batch, M, K).reshape(-1, M, K)
+    w = w.expand(*batch, N, K).reshape(-1, N, K)
+    v = vec(dt)
+    Kp = (K + v - 1) // v * v
+    if Kp != K:                                            # rows must be whole 16-byte chunks
+        a = torch.nn.functional.pad(a, (0, Kp - K))
+        w = torch.nn.functional.pad(w, (0, Kp - K))
+    a = a.contiguous()
+    wf = w.float().contiguous()
+    out = torch.empty((a.shape[0], M, N), dtype=dt, device=a.device)
+    for i in range(a.shape[0]):
+        pk = PackedFilter(wf[i], dt)
+        conv2d(a[i].view(M, 1, 1, Kp), pk, out=out[i].view(M, 1, 1, N), out_ld=N)
+    return out.view(*batch, M, N)
 
 
 def attention(qkv, heads, scale, bias=None, mask=None):

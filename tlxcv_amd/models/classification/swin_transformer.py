@@ -301,23 +301,28 @@ class PatchEmbed(nn.Module):
                                    out_channels=embed_dim, padding=0, data_format='channels_first')
         self.norm = layer_norm(embed_dim) if layer_norm is not None else None
 
-    def forward(self, x):
+    def forward(self, x, pos=None):
+        """pos: fp32 (num_patches, D) absolute position embedding added to the tokens after the norm (SwinTransformer(ape=True), :603-604)."""
         conv, D = self.proj, self.embed_dim
         if (E.option("patch_embed4") and E.precision() == torch.float16 and tuple(self.patch_size) == (4, 4) and self.in_chans == 3
-                and D in (96, 128, 192, 256) and x.dim() == 4 and x.shape[2] % 4 == 0 and x.shape[3] % 4 == 0 and x.dtype in (torch.float16, torch.float32)
+                and D in (96, 128, 192, 256) and x.dim() == 4 and x.shape[1] == 3 and x.shape[2] % 4 == 0 and x.shape[3] % 4 == 0 and x.dtype in (torch.float16, torch.float32)
                 and not x.permute(0, 2, 3, 1).is_contiguous() and (self.norm is None or isinstance(self.norm, nn.LayerNorm))):
             # conv + flatten + transpose + norm (:498-504) in one pass over the image: the layer is HBM traffic only
             w64 = conv._cached("pe4", lambda: E.patch_embed4_filter(conv.filters))
             bias = conv._cached("bias", lambda: E._f32(conv.biases)) if conv.biases is not None else None
             if self.norm is None:
-                return E.patch_embed4(x, w64, bias, None, None, 0.0)
-            return E.patch_embed4(x, w64, bias, self.norm.gamma.detach(), self.norm.beta.detach(), self.norm.epsilon)
+                return E.patch_embed4(x, w64, bias, None, None, 0.0, pos)
+            return E.patch_embed4(x, w64, bias, self.norm.gamma.detach(), self.norm.beta.detach(), self.norm.epsilon, pos)
         if self.patch_size[0] % 4 == 0 and not x.permute(0, 2, 3, 1).is_contiguous():
             y = self.proj.run_stem(x, 4)                                           # 4x4/4 conv == 1x1 conv on 48 folded channels
         else:
             y = self.proj.run_nhwc(as_nhwc(x, 'channels_first'))                   # (B, H/4, W/4, D): :500-501
         y = y.view(y.shape[0], -1, y.shape[-1])
-        return self.norm(y) if self.norm is not None else y
+        y = self.norm(y) if self.norm is not None else y
+        if pos is not None:      # x + absolute_pos_embed, one table for every image: a per-element shift over the flattened image
+            B, L, _ = y.shape
+            y = E.affine_act(y.contiguous().view(B, L * D), shift=pos.reshape(-1)).view(B, L, D)
+        return y
 
 
 class SwinTransformer(nn.Module):
@@ -334,8 +339,9 @@ class SwinTransformer(nn.Module):
         self.patch_embed = PatchEmbed(img_size=img_size, patch_size=patch_size, in_chans=in_chans, embed_dim=embed_dim,
                                       layer_norm=layer_norm if self.patch_norm else None)
         pr = self.patches_resolution = self.patch_embed.patches_resolution
-        if self.ape:
-            raise NotImplementedError("absolute position embedding (ape=True) is not used by any reference config")
+        if self.ape:      # swin_transformer.py:561-565 (no shipped config sets it)
+            self.absolute_pos_embed = nn.Parameter(data=trunc_normal_(shape=(1, self.patch_embed.num_patches, embed_dim)))
+            self.register_parameter(name="absolute_pos_embed", param=self.absolute_pos_embed)
         self.pos_drop = nn.Dropout(p=drop_rate)
         self.layers = nn.ModuleList()
         for i in range(self.num_layers):
@@ -350,7 +356,10 @@ class SwinTransformer(nn.Module):
 
     def forward_features(self, x):
         self._require_eval()
-        x = self.patch_embed(x)                        # :602
+        pos = None
+        if self.ape:                                   # :603-604, folded into the patch embedding's store
+            pos = self._cached("ape", lambda: E._f32(self.absolute_pos_embed.detach()[0]).contiguous())
+        x = self.patch_embed(x, pos)                   # :602
         part = None
         for i, layer in enumerate(self.layers):        # :606-607
             nxt = self.layers[i + 1] if i + 1 < len(self.layers) else None

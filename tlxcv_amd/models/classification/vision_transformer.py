@@ -5,7 +5,9 @@ Same factories / constructor arguments / parameter tree as the reference
 change of arithmetic):
   * PatchEmbed conv + flatten + transpose + concat cls + add pos_embed (:206-220, :321-323) is ONE Linear over all B * (1 + P)
     token rows: patch rows in the flattened filter's order with a zero row in each image's cls slot (tlxmi_patchify), the conv
-    filter as the weight, the per-row residual [cls + pos[0] - bias | pos[1:]] (round 4; patch sizes that are multiples of 8).
+    filter as the weight, the per-image residual rows [cls + pos[0] | pos[1:] + bias] broadcast into the token matrix first and added
+    in place (round 4; round 5: one (1 + P, D) table per model instead of a (B, 1 + P, D) tensor per batch size; patch sizes that
+    are multiples of 8).
     Otherwise (and with set_option("patch_linear", False)): the conv on a space-to-depth image writes straight into rows 1..P of
     the token matrix with `+ pos_embed[1:]` in its epilogue, and row 0 is the constant cls_token + pos_embed[0].
   * Attention (:112-123) = qkv GEMM(+bias) -> one fused softmax(q k^T * scale) v kernel on the
@@ -218,9 +220,6 @@ class VisionTransformer(nn.Module):
         pe.check(x)
         dt = E.precision()
         B, P, D = x.shape[0], pe.num_patches, self.embed_dim
-        pos = self._cached("pos", lambda: self.pos_embed.detach()[0, 1:].to(dt).contiguous())            # (P, D)
-        row0 = self._cached("row0", lambda: (self.cls_token.detach()[0, 0] + self.pos_embed.detach()[0, 0])
-                            .to(dt).contiguous())                                                         # (D,)
         tok = torch.empty((B, P + 1, D), dtype=dt, device=x.device)
         ps, conv = pe.patch_size[0], pe.proj
         if (E.option("patch_linear") and self.data_format == "channels_first" and pe.patch_size[0] == pe.patch_size[1] and ps % 8 == 0 and B * (P + 1) < (1 << 20)
@@ -228,30 +227,36 @@ class VisionTransformer(nn.Module):
                 and tuple(conv.stride) == tuple(pe.patch_size) and tuple(conv.padding) == (0, 0) and not conv.same):
             # The patch-embedding conv as ONE Linear over all B * (1 + P) token rows (vision_transformer.py:197-204, 321-323): patch
             # rows in the flattened filter's order with a zero row in the cls slot (tlxmi_patchify), the filter as the Linear weight,
-            # and a per-row residual [cls + pos[0] - bias | pos[1:]] — the zero row yields bias + (cls + pos[0] - bias).  It runs on the
+            # and the rows [cls + pos[0] | pos[1:] + bias] as an in-place residual — the zero row yields cls + pos[0].  It runs on the
             # persistent GEMM like proj (same shape) instead of the generic implicit GEMM: ViT-B/16 batch 256 forward 11.01 -> 10.93 ms.
             pk = conv._cached(("patch_linear", dt), lambda: E.PackedFilter(conv.filters.detach().reshape(D, -1).contiguous(), dt))
-            bias = conv._cached("bias", lambda: E._f32(conv.biases)) if conv.biases is not None else None
 
-            def rows_res():
+            def rows_table():
+                # one image's residual rows [cls + pos[0] | pos[1:] + bias], summed in fp32 and rounded ONCE (the conv bias rides here, not
+                # in the GEMM epilogue: a zero patch row + this row is exactly cls + pos[0], whatever the bias is)
                 first = self.cls_token.detach()[0, 0].float() + self.pos_embed.detach()[0, 0].float()
+                rest = self.pos_embed.detach()[0, 1:].float()
                 if conv.biases is not None:
-                    first = first - conv.biases.detach().float()
-                one = torch.cat((first[None], self.pos_embed.detach()[0, 1:].float()), 0).to(dt)      # (1 + P, D)
-                return one[None].expand(B, P + 1, D).contiguous()
-            # one (B * (1 + P), D) tensor per batch size seen, kept for the life of the model: a captured hipGraph holds its address
-            res = self._cached(("patch_res", B, dt), rows_res, deps=(conv,))
+                    rest = rest + conv.biases.detach().float()[None]
+                return torch.cat((first[None], rest), 0).to(dt).contiguous().view(-1)             # ((1 + P) * D,)
+            # (1 + P, D) per model, whatever the batch: the table is broadcast into the token matrix (one 2-byte-per-element write) and
+            # the GEMM adds it as its in-place residual.  (Round 4 cached the expanded (B, 1 + P, D) tensor per batch size seen.)
+            table = self._cached(("patch_rows", dt), rows_table, deps=(conv,))
+            E.broadcast_rows_into(table, tok, B, (P + 1) * D)
             if len(self.blocks) and all(blk.folded_ok(tok) for blk in self.blocks) and E.linear_ln_supported(B * (P + 1), pk.Cin, D, dt, with_res=True):
                 # LayerNorm statistics ride in the epilogues of the GEMMs that write the token matrix (round 5): no LayerNorm launch
-                part = E.linear_stats(E.patchify(x, ps, 1, dt), pk, bias, res=res, out=tok)[1]
+                part = E.linear_stats(E.patchify(x, ps, 1, dt), pk, None, res=tok, out=tok)[1]
                 for i, blk in enumerate(self.blocks):
                     part = blk.run_folded(tok, part, last=i == len(self.blocks) - 1)
                 return E.layernorm_rows(tok, B, D, (P + 1) * D, self.norm.gamma.detach(), self.norm.beta.detach(), self.norm.epsilon)
-            E.linear(E.patchify(x, ps, 1, dt), pk, bias, res=res, out=tok)
+            E.linear(E.patchify(x, ps, 1, dt), pk, None, res=tok, out=tok)
             for blk in self.blocks:
                 blk.run_inplace(tok)
             return E.layernorm_rows(tok, B, D, (P + 1) * D, self.norm.gamma.detach(), self.norm.beta.detach(), self.norm.epsilon)
         # rows 1..P: conv + bias + pos_embed[1:]   (vision_transformer.py:206-220, 321-323)
+        pos = self._cached("pos", lambda: self.pos_embed.detach()[0, 1:].to(dt).contiguous())            # (P, D)
+        row0 = self._cached("row0", lambda: (self.cls_token.detach()[0, 0] + self.pos_embed.detach()[0, 0])
+                            .to(dt).contiguous())                                                         # (D,)
         kw = dict(res=pos, out=tok[:, 1:], out_ld=D, y_nstride=(P + 1) * D, res_bcast=True, res_ld=D)
         fold = 4 if pe.patch_size[0] % 4 == 0 else (2 if pe.patch_size[0] % 2 == 0 else 0)
         if self.data_format == "channels_first" and fold and not x.permute(0, 2, 3, 1).is_contiguous():

@@ -71,7 +71,7 @@ def fill(shapes, seed):
             a = rng.standard_normal(shape, dtype=np.float32) * np.float32(0.05)
         elif leaf == "moving_var":
             a = rng.uniform(0.8, 1.2, shape).astype(np.float32)
-        elif leaf in ("pos_embed", "cls_token", "relative_position_bias_table"):
+        elif leaf in ("pos_embed", "cls_token", "relative_position_bias_table", "absolute_pos_embed"):
             a = np.clip(rng.standard_normal(shape, dtype=np.float32), -2, 2) * np.float32(0.02)
         elif leaf.endswith("_weight") and len(shape) == 2:      # attention projections stored (out, in): detr.py:975-995
             a = rng.standard_normal(shape, dtype=np.float32) * np.float32(np.sqrt(1.0 / shape[1]))

@@ -81,11 +81,8 @@ def index_select(x, index, axis=0):
 
 
 def matmul(a, b, transpose_a=False, transpose_b=False):
-    if transpose_a:
-        a = a.transpose(-1, -2)
-    if transpose_b:
-        b = b.transpose(-1, -2)
-    return torch.matmul(a, b)
+    """tlx.matmul (detr.py:1013): on the device every product runs on libtlxmi (engine.matmul), never a BLAS library."""
+    return _E.matmul(a, b, transpose_a, transpose_b)
 
 
 def add(value, bias):

@@ -408,8 +408,7 @@ class Softmax(Module):
         self.axis = axis
 
     def forward(self, x):
-        E.need_gpu(x)
-        return torch.softmax(x, dim=self.axis)
+        return E.softmax(x, self.axis)
 
 
 class Dropout(Module):
