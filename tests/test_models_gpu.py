@@ -380,7 +380,12 @@ def test_swin_blocks_without_layernorm_or_window_passes(dev, fp16_mode, shift):
         for blk, p in zip(blks, ps):
             ref = OF.swin_block({"b." + k: torch.from_numpy(v) for k, v in p.items()}, "b", ref, H, W, heads, 7, blk.shift_size)
     xd = x0.to(dev)
-    assert blks[0].folded_ok(xd) and blks[1].folded_ok(xd)
+    keep = E.option_value("lnfold_min_rows_one_stream")
+    E.set_option("lnfold_min_rows_one_stream", 0)      # (a one-stream forward folds from 12 k rows; the path itself is under test here)
+    try:
+        assert blks[0].folded_ok(xd) and blks[1].folded_ok(xd)
+    finally:
+        E.set_option("lnfold_min_rows_one_stream", keep)
     # statistics of the input from a producer: an identity-free way is a Linear with stats; here the stand-alone pass + a dummy producer
     # would hide bugs, so the input goes through PatchMerging-like statistics by hand: sums over 32-channel slots
     xf = xd.float().view(B * H * W, C // 32, 32)
@@ -410,12 +415,15 @@ def test_swin_b_folded_stages_track_golden(dev, fp16_mode, batch):
     x[rows] = gold
     x = torch.from_numpy(x).to(dev)
     ys = {}
+    keep = E.option_value("lnfold_min_rows_one_stream")
+    E.set_option("lnfold_min_rows_one_stream", 0)
     try:
         for arm in (True, False):
             E.set_option("lnfold", arm)
             ys[arm] = m(x).float().cpu().numpy()
     finally:
         E.set_option("lnfold", True)
+        E.set_option("lnfold_min_rows_one_stream", keep)
     from util import check_fp16_logits
     for arm in (True, False):
         check_fp16_logits(ys[arm][rows], g["logits"], g["argmax"], "swin_b_b2")

@@ -113,6 +113,8 @@ def test_layernorm_folded_into_the_gemms_tracks_golden(dev, fp16_mode, batch):
     x[rows] = gold
     x = torch.from_numpy(x).to(dev)
     ys, launches = {}, {}
+    keep = E.option_value("lnfold_min_rows_one_stream")
+    E.set_option("lnfold_min_rows_one_stream", 0)      # (the product folds a one-stream forward from 12 k rows only: here the path itself is under test)
     try:
         for arm in (True, False):
             E.set_option("lnfold", arm)
@@ -121,6 +123,7 @@ def test_layernorm_folded_into_the_gemms_tracks_golden(dev, fp16_mode, batch):
             launches[arm] = _count_ln(m) - n0
     finally:
         E.set_option("lnfold", True)
+        E.set_option("lnfold_min_rows_one_stream", keep)
     assert launches[True] == 0 and launches[False] >= 24 * (2 if batch >= 64 else 1)      # the folded arm ran no LayerNorm module
     for arm in (True, False):
         check_fp16_logits(ys[arm][rows], g["logits"], g["argmax"], "vit_b16_b2")

@@ -34,6 +34,7 @@ _options = {"splitk": True,       # classifier heads: K slices side by side (tlx
                                   # the normalisation in theirs (tlxmi_linear_ln); off = LayerNorm launches + plain Linear layers (the parity
                                   # tests' other arm)
             "lnfold_min_rows": 2048,  # (a number) folded Linear layers need at least this many rows (below, the tiled kernels of the dispatcher win)
+            "lnfold_min_rows_one_stream": 12000,  # (a number) ... and this many outside a two-stream forward
             "lnfold_min_c": 256,  # (a number) Swin: fold the LayerNorms of the stages with at least this many channels (tools/ A/B per stage)
             "tail_splitk": False} # Linear layers: the rows of a short last round of 256 x 256 tiles on K slices (_linear_tail): built,
                                   # parity-green, measured a LOSS on the ViT-B/16 forward (10.63 -> 11.61 ms for every K >= 768,
@@ -782,7 +783,11 @@ def _linear_splits(rows, K, pk, x):
 def linear_ln_supported(rows, K, Cout, dtype, act=ACT_NONE, with_res=False):
     """Whether a Linear of this shape takes the folded-LayerNorm path (tlxmi_linear_stats with_res / tlxmi_linear_ln): fp16 on the
     persistent 256 x 256 GEMM kernel, rows enough to fill it (below ~2 k rows the tiled kernels of the dispatcher win)."""
-    if not _options["lnfold"] or dtype != torch.float16 or rows < _options["lnfold_min_rows"]:
+    # tools/batch_table.py (round 5): inside a two-stream forward the other half's launches fill what a persistent GEMM with few tiles
+    # leaves idle, so the fold pays from ~2 k rows (ViT-B/16 batch 64 = 2 x 32 images: +9 %); a forward on ONE stream at that size is
+    # faster on the dispatcher's smaller tiles + LayerNorm launches (ViT-B/16 batch 32: -6 %, Swin-B batch 32: -7 %, batch 64: equal)
+    min_rows = _options["lnfold_min_rows"] if in_halves() else max(_options["lnfold_min_rows"], _options["lnfold_min_rows_one_stream"])
+    if not _options["lnfold"] or dtype != torch.float16 or rows < min_rows:
         return False
     return bool(_lib.load().tlxmi_linear_ln_supported(F16, int(rows), int(K), int(Cout), int(act), 1 if with_res else 0))
 

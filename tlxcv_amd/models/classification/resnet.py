@@ -119,7 +119,9 @@ class BottleneckBlock(nn.Module):
         # ones, 0.74 without any; from 16 images the 56 x 56 / 28 x 28 seams win (batch 32: 1.09 vs 1.14 ms), the 14 x 14 ones
         # (1 MB of filters per 128 pixels) only from ~96 images, or inside a two-stream forward (batch 128 = 2 x 64: 2.12 vs 2.16).
         n_img = out.shape[0]
-        if n_img < 12 or (c3.in_channels >= 256 and n_img < 96 and not E.in_halves()):
+        # (round 5, tools/batch_table.py: at 512 images = 2 x 256 per launch the 14 x 14 seams LOSE 2.3 % to two persistent GEMM launches —
+        #  their 1 MB of filters per 128 pixels is re-streamed 196 times per CU; at 2 x 128 they win 1.7 %: fused up to 192 images a launch)
+        if n_img < 12 or (c3.in_channels >= 256 and ((n_img < 96 and not E.in_halves()) or n_img > 192)):
             return None
         pk3 = c3._cached("pk", lambda: E.PackedFilter(c3.filters, dt))
         pk1 = c1._cached("pk", lambda: E.PackedFilter(c1.filters, dt))

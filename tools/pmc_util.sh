@@ -27,6 +27,9 @@ import os
 sys.path.insert(0, os.getcwd())
 import bench
 lines = [f"{wl}: per-kernel averages over the launches of one bench.py run (rocprofv3 --pmc, one counter per pass); csrc_sha {bench.csrc_sha()}",
+         "NOTE: the forward runs as two half batches on two streams; under rocprofv3 --pmc the streams are SERIALISED and each half-batch launch of the",
+         "      conv / linear family is planned for 128 of the 256 CUs (TLXMI_PLAN_SHARED_HALF: ResNet-50, ViT-B/16) — a chip-wide percentage such as MfmaUtil",
+         "      is therefore about HALF of what the two concurrent halves reach together (layer tables: profiles/*/…_layer_times.txt).",
          f"{'launches':>8s} {'MfmaUtil %':>11s} {'LdsBankConflict %':>18s}  kernel"]
 for k, a in sorted(agg.items(), key=lambda kv: -kv[1].get("n_MfmaUtil", 0) * kv[1].get("MfmaUtil", 0.0)):
     n = a.get("n_MfmaUtil", 0)
