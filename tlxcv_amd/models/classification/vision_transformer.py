@@ -273,7 +273,9 @@ class VisionTransformer(nn.Module):
 
     # two half batches on two streams (round 3, hipGraph replay of ViT-B/16 on one box): batch 256 11.05 -> 10.76 ms with
     # the tiles planned for half the CUs, batch 128 6.14 -> 5.56 ms and batch 64 3.45 -> 3.35 ms with the device's own plan
-    @E.two_streams(64, plan=lambda n: "half" if n >= 256 else None)
+    # round 5 (tools/plan_modes.py, with the LayerNorms folded into the GEMMs): batch 256 one stream 10.18 ms, halves planned for the device 9.85, for
+    # half the CUs 10.14 (round 3 had it the other way round: the stand-alone LayerNorm launches filled the gaps the half plan left); batch 128: 5.69 / 5.17 / 5.77
+    @E.two_streams(64, plan="full")
     def forward(self, x):
         x = self.forward_features(x)
         if isinstance(self.head, nn.Linear):
