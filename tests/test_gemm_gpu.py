@@ -347,3 +347,36 @@ def test_ln_finalize_every_width(dev, C):
     rstd = 1.0 / torch.sqrt(x.double().var(1, unbiased=False) + eps)
     torch.testing.assert_close(rowab[:, 0].double(), rstd, atol=0, rtol=1e-3)
     torch.testing.assert_close(rowab[:, 1].double(), -x.double().mean(1) * rstd, atol=1e-4, rtol=1e-3)
+
+
+@pytest.mark.parametrize("shape", [(2304, 768, 2304), (2304, 768, 256), (27648, 768, 2304), (2304, 768, 3072), (12544 + 100, 512, 1536)],
+                         ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("act", [E.ACT_NONE, E.ACT_GELU], ids=["none", "gelu"])
+def test_linear_ln_row_and_channel_tables_exact(dev, shape, act):
+    """The regression test of the round-5 fault in gemm_stream's ROWAFF epilogue: with a = 0, b = 1 the consumer's output is
+    act(c1[n] + c2[n]) whatever x is — small integers, exact in fp16 — so ANY wrong read of the row table (a, b) or of the channel
+    tables (c1, c2) shows as a wrong integer.  (The first form read (a, b) of a sub-tile by one ds_read_b64 right in front of its
+    use inside the MFMA segment: sub-tile 1 of the lower half tile came back with b = 0 in lanes 48 - 63 for single elements, on
+    every launch, and only there — 36 of 2304 columns in 32 of every 256 rows; the shipped form fetches the four pairs of a half
+    tile in the load segment by one asm block.)  One and several tiles per workgroup, the half-height tail, both activations."""
+    M, K, N = shape
+    rng = np.random.default_rng(M + N)
+    x = rnd(rng, (M, K)).half().to(dev)
+    w = rnd(rng, (N, K), (1.0 / K) ** 0.5)
+    prep = E.LinearLN(w.to(dev), None, torch.ones(K, device=dev), torch.zeros(K, device=dev), torch.float16)
+    prep.c1 = (torch.arange(N, device=dev) % 500 + 1).float()
+    prep.c2 = torch.full((N,), -7.0, device=dev)
+    rowab = torch.stack([torch.zeros(M, device=dev), torch.ones(M, device=dev)], 1).contiguous()
+    want = prep.c1 - 7.0
+    if act == E.ACT_GELU:
+        want = torch.nn.functional.gelu(want)
+    for plan in (None, "half"):
+        with E.shared_plan(plan):
+            z = E.linear_ln(x, prep, rowab, act).float()
+        bad = torch.nonzero((z - want[None]).abs() > (0 if act == E.ACT_NONE else 2e-3 * (1 + want.abs().max())))
+        assert bad.shape[0] == 0, f"plan {plan}: {bad.shape[0]} wrong elements, first {bad[:6].tolist()}, rows mod 256 {sorted(set((bad[:, 0] % 256).tolist()))[:16]}"
+    # and the row side: a = row pattern, b = 0, weights = identity-free check through x = const: out[m][n] = a[m] * (sum_k x W') + c2
+    rowab2 = torch.stack([(torch.arange(M, device=dev) % 13).float(), torch.zeros(M, device=dev)], 1).contiguous()
+    z0 = E.linear_ln(x, prep, torch.stack([torch.ones(M, device=dev), torch.zeros(M, device=dev)], 1).contiguous(), E.ACT_NONE).float()
+    z2 = E.linear_ln(x, prep, rowab2, E.ACT_NONE).float()
+    torch.testing.assert_close(z2 + 7.0, (z0 + 7.0) * rowab2[:, :1], atol=8e-2, rtol=5e-3)      # (both sides rounded to fp16 at |z| up to ~40)

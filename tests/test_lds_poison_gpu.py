@@ -213,3 +213,64 @@ def test_convolutions_seams_and_attention_op_by_op_with_poisoned_lds(dev, fp16_m
             if not _same(y, ref):
                 failures.append(f"{name} [{pname}]: " + _diff_report(y.float(), ref.float()))
     assert not failures, "\n".join(failures)
+
+
+def test_folded_layernorm_and_window_attention_op_by_op_with_poisoned_lds(dev, fp16_mode, probe):
+    """Round 5's kernels one by one at the shapes the ViT-B/16 / Swin-B forwards run them (half batches, both CU plans): tlxmi_linear_stats
+    (gemm_stream STATS with and without a residual; gemm_pp LNF for the 8-K-tile residual producer of Swin-B stage 3), tlxmi_ln_finalize,
+    tlxmi_linear_ln (gemm_stream ROWAFF, plain and GELU: its row table and the (a, b) prefetch live in LDS), tlxmi_attention_windows.
+    Every LDS byte holds the pattern before every launch; outputs and statistics must not move by a bit."""
+    from tlxcv_amd import engine as E
+    g = torch.Generator().manual_seed(11)
+    cases = []
+
+    def fold(tag, M, K, D, N2, act, plan):
+        x = torch.randn((M, K), generator=g).half().to(dev)
+        w = (torch.randn((D, K), generator=g) * K ** -0.5).to(dev)
+        b = (torch.randn(D, generator=g) * 0.1).to(dev)
+        r = torch.randn((M, D), generator=g).half().to(dev)
+        pk = E.PackedFilter(w, torch.float16)
+        prep = E.LinearLN((torch.randn((N2, D), generator=g) * D ** -0.5).to(dev), (torch.randn(N2, generator=g) * 0.1).to(dev),
+                          (torch.rand(D, generator=g) + 0.5).to(dev), (torch.randn(D, generator=g) * 0.2).to(dev), torch.float16)
+
+        def producer(res):
+            with E.shared_plan(plan):
+                y, part = E.linear_stats(x, pk, b, res=res)
+            return torch.cat([y.float().reshape(-1), part.reshape(-1)])
+        with E.shared_plan(plan):
+            y0, part0 = E.linear_stats(x, pk, b, res=r)
+        rowab0 = E.ln_finalize(part0, D, 1e-5)
+        cases.append((f"{tag} producer + res M={M} K={K} N={D} plan={plan}", lambda: producer(r)))
+        cases.append((f"{tag} producer M={M} K={K} N={D} plan={plan}", lambda: producer(None)))
+        cases.append((f"{tag} finalize {D // 32} slots", lambda: E.ln_finalize(part0, D, 1e-5)))
+
+        def consumer():
+            with E.shared_plan(plan):
+                return E.linear_ln(y0, prep, rowab0, act)
+        cases.append((f"{tag} consumer M={M} K={D} N={N2} act={act} plan={plan}", consumer))
+    fold("vit proj -> qkv", 25216, 768, 768, 2304, E.ACT_NONE, "full")
+    fold("vit fc2 -> fc1", 25216, 3072, 768, 3072, E.ACT_GELU, "half")
+    fold("swin-3 proj -> fc1 (8 K tiles: gemm_pp LNF)", 12544, 512, 512, 2048, E.ACT_GELU, "full")
+    fold("swin-3 fc2 -> qkv", 12544, 2048, 512, 1536, E.ACT_NONE, "full")
+    fold("swin-4 fc2 -> qkv", 3136, 4096, 1024, 3072, E.ACT_NONE, "full")
+
+    for (B, H, W, heads, shift) in ((64, 14, 14, 16, 3), (64, 28, 28, 8, 0), (64, 7, 7, 32, 0)):
+        C = heads * 32
+        qkv = torch.randn((B, H * W, 3 * C), generator=g).half().to(dev)
+        bias = (torch.randn((heads, 49, 49), generator=g) * 0.5).to(dev)
+        from oracle import functional as OF
+        mask = OF.swin_attn_mask(H, W, 7, shift).to(dev) if shift else None
+        tab = E.attention_table(bias, mask, 49)
+        cases.append((f"window attention on image rows {H}x{W} heads {heads} shift {shift}",
+                      lambda qkv=qkv, tab=tab, mask=mask, H=H, W=W, heads=heads, shift=shift: E.attention_windows(qkv, heads, 32 ** -0.5, tab, 0 if mask is None else mask.shape[0], H, W, 7, shift)))
+    failures = []
+    for name, run in cases:
+        ref = run().clone()
+        torch.cuda.synchronize()
+        for pname, pat in PATTERNS:
+            with poisoned(probe, pat):
+                y = run().clone()
+            torch.cuda.synchronize()
+            if not _same(y, ref):
+                failures.append(f"{name} [{pname}]: " + _diff_report(y.float(), ref.float()))
+    assert not failures, "\n".join(failures)
