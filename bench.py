@@ -41,7 +41,7 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 HBM_ACHIEVABLE_GBS = 6290.0      # same guide: 6.29 TB/s measured float4 copy (79 % of spec)
 MFMA_F16_PEAK_TF = 2500.0        # dense fp16 MFMA, spec
 MEASURED_GEMM_F16_TF = 1333.0    # hipBLASLt (torch.matmul) 16384 x 4096 x 4096 on a box of this pool (profiles/r01/roofline_denominators.txt)
-PROFILE_ROUND = "r04"
+PROFILE_ROUND = "r05"
 
 # SURVEY.md §8d / BASELINE.md §2: algorithmic work per image with every elementwise op fused into its producer
 WORK = {
