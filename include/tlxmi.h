@@ -391,6 +391,14 @@ int tlxmi_window_reverse_layernorm(const void* win, const void* res, const float
  * vision_transformer.py:118): y[r][c] = exp(x[r][c] - max_r) / sum_c exp(...), fp32 arithmetic, dtype of x out; any C, strides in elements. */
 int tlxmi_softmax_rows(const void* x, void* y, int dtype, int64_t rows, int C, int64_t x_ld, int64_t y_ld, void* stream);
 
+/* A transformer MLP as one launch (swin_transformer.py:62-82, :335): out = fc2(gelu(fc1(x) + b1)) + b2 + res; the hidden activations
+ * (rows x hidden) never leave the CU.  fp16; x [rows][x_ld] (K channels), res / out [rows][ld] (N channels); w1 / w2 packed by
+ * tlxmi_pack_filter (1 x 1) as [hidden][K] and [N][hidden].  Compiled for K = N = 128, hidden a multiple of 64 up to 2048 (Swin-B
+ * stage 1); tlxmi_mlp_seam_supported answers 1 when a shape is taken. */
+int tlxmi_mlp_seam_supported(int dtype, int K, int hidden, int N);
+int tlxmi_mlp_seam(int dtype, int64_t rows, int K, int hidden, int N, const void* x, int x_ld, const void* w1_packed, const float* bias1,
+                   const void* w2_packed, const float* bias2, const void* res, int res_ld, void* out, int out_ld, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * LayerNorm folded AROUND the Linear layers of a transformer block (fp16; vision_transformer.py:144-175: norm1 -> attn.qkv,
  * norm2 -> mlp.fc1; swin_transformer.py:310-337).  The Linear that PRODUCES the residual stream (proj, fc2, the patch embedding)

@@ -120,3 +120,36 @@ def test_seam_with_the_projection_shortcut_inside(dev, fp16_mode, N, H, W):
 def test_unsupported_triples_are_reported_not_run(dev):
     assert not E.bottleneck_seam_supported(96, 384, 96, torch.float16)
     assert not E.bottleneck_seam_supported(64, 256, 64, torch.float32)
+
+
+@pytest.mark.parametrize("rows,hidden", [(4096 + 37, 512), (200704, 512), (8192, 256), (5000, 1024)], ids=lambda v: str(v))
+def test_mlp_as_one_launch(dev, rows, hidden):
+    """tlxmi_mlp_seam (round 5; swin_transformer.py:62-82 Mlp + the residual of :335): out = fc2(gelu(fc1(x) + b1)) + b2 + res with the
+    hidden activations kept on the CU (the seam kernel's MLP form, 128 -> hidden -> 128).  Against torch fp32 (exact-erf GELU) on the
+    fp16-rounded operands, against the two-launch path (fc1 + GELU, fc2 + residual) on the same inputs, in place (out = res), a ragged
+    last workgroup, Swin-B stage 1's row count at half batch 64."""
+    import numpy as np
+    from tlxcv_amd import engine as E
+    from util import rnd, q16
+    rng = np.random.default_rng(rows % 1000 + hidden)
+    K = N = 128
+    x = q16(rnd(rng, (rows, K)))
+    res = q16(rnd(rng, (rows, N)))
+    w1 = q16(rnd(rng, (hidden, K), (1.0 / K) ** 0.5))
+    b1 = rnd(rng, (hidden,), 0.3)
+    w2 = q16(rnd(rng, (N, hidden), (1.0 / hidden) ** 0.5))
+    b2 = rnd(rng, (N,), 0.2)
+    assert E.mlp_seam_supported(rows, K, hidden, N, torch.float16)
+    pk1, pk2 = E.PackedFilter(w1.to(dev), torch.float16), E.PackedFilter(w2.to(dev), torch.float16)
+    xd, rd = x.half().to(dev), res.half().to(dev)
+    got = E.mlp_seam(xd, pk1, b1.to(dev), pk2, b2.to(dev), rd)
+    sel = torch.cat([torch.arange(0, 600), torch.arange(rows - 600, rows)])
+    h = torch.nn.functional.gelu(x[sel] @ w1.t() + b1)
+    want = q16(h) @ w2.t() + b2 + res[sel]              # the hidden activations are rounded to fp16 between the two products, as in two launches
+    torch.testing.assert_close(got[sel.to(dev)].float().cpu(), want, atol=6e-3, rtol=6e-3)
+    two = E.linear(E.linear(xd, pk1, b1.to(dev), act=E.ACT_GELU), pk2, b2.to(dev), res=rd)
+    torch.testing.assert_close(got.float(), two.float(), atol=6e-3, rtol=6e-3)
+    inplace = rd.clone()
+    out = E.mlp_seam(xd, pk1, b1.to(dev), pk2, b2.to(dev), inplace, out=inplace)
+    assert out.data_ptr() == inplace.data_ptr() and torch.equal(out, got)
+    assert torch.equal(E.mlp_seam(xd, pk1, b1.to(dev), pk2, b2.to(dev), rd), got)

@@ -90,6 +90,7 @@ PROTOTYPES = {
     "tlxmi_layernorm": [_vp, _vp, _vp, _vp, _i, _l, _i, _i, _i, _f, _vp],
     "tlxmi_layernorm_window_partition": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp],
     "tlxmi_window_reverse_layernorm": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp],
+    "tlxmi_mlp_seam": [_i, _l, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp],
     "tlxmi_linear_stats": [_i, _l, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _u, _vp],
     "tlxmi_ln_finalize": [_vp, _i, _l, _i, _f, _vp, _vp],
     "tlxmi_softmax_rows": [_vp, _vp, _i, _l, _i, _l, _l, _vp],
@@ -120,6 +121,7 @@ _SPECIAL = {
     "tlxmi_multiclass_nms_workspace_bytes": ([_i, _i], C.c_size_t),
     "tlxmi_bottleneck_seam_supported": ([_i, _i, _i, _i], C.c_int),
     "tlxmi_linear_ln_supported": ([_i, _l, _i, _i, _i, _i], C.c_int),
+    "tlxmi_mlp_seam_supported": ([_i, _i, _i, _i], C.c_int),
 }
 ALL_SYMBOLS = sorted(list(PROTOTYPES) + list(_SPECIAL))
 

@@ -20,5 +20,6 @@ struct SeamArgs {
 
 bool block_seam_shape_ok(int K1, int N1, int N2);
 int launch_block_seam(const SeamArgs& a, int K1, int N2, hipStream_t st);
+int launch_mlp_seam(const SeamArgs& a, int K1, int N2, hipStream_t st);      // the MLP form: fc1 + GELU + fc2 + residual
 
 }  // namespace tlxmi

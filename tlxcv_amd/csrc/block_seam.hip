@@ -81,6 +81,20 @@ static __device__ __forceinline__ u32x2 bs_bn_skip_relu4(f32x4 acc, f32x4 sc, f3
     const half2v p0 = half2v{(half_t)t0[0], (half_t)t0[1]}, p1 = half2v{(half_t)t1[0], (half_t)t1[1]};
     return u32x2{bs_pkrelu(__builtin_bit_cast(unsigned, p0)), bs_pkrelu(__builtin_bit_cast(unsigned, p1))};
 }
+// MLP form (below): gelu(acc * scale + shift) of 4 channels -> 4 packed halves (the fp16-mode GELU of the GEMM epilogues, common.h)
+static __device__ __forceinline__ u32x2 bs_bn_gelu4(f32x4 acc, f32x4 sc, f32x4 sh) {
+    const f32x2v g0 = gelu_fast2(f32x2v{__builtin_fmaf(acc[0], sc[0], sh[0]), __builtin_fmaf(acc[1], sc[1], sh[1])});
+    const f32x2v g1 = gelu_fast2(f32x2v{__builtin_fmaf(acc[2], sc[2], sh[2]), __builtin_fmaf(acc[3], sc[3], sh[3])});
+    const half2v p0 = half2v{(half_t)g0[0], (half_t)g0[1]}, p1 = half2v{(half_t)g1[0], (half_t)g1[1]};
+    return u32x2{__builtin_bit_cast(unsigned, p0), __builtin_bit_cast(unsigned, p1)};
+}
+// ... and acc * scale + shift + res, no activation
+static __device__ __forceinline__ u32x2 bs_bn_res4(f32x4 acc, f32x4 sc, f32x4 sh, half4v res) {
+    const float t0 = __builtin_fmaf(acc[0], sc[0], sh[0]) + (float)res[0], t1 = __builtin_fmaf(acc[1], sc[1], sh[1]) + (float)res[1];
+    const float t2 = __builtin_fmaf(acc[2], sc[2], sh[2]) + (float)res[2], t3 = __builtin_fmaf(acc[3], sc[3], sh[3]) + (float)res[3];
+    const half2v p0 = half2v{(half_t)t0, (half_t)t1}, p1 = half2v{(half_t)t2, (half_t)t3};
+    return u32x2{__builtin_bit_cast(unsigned, p0), __builtin_bit_cast(unsigned, p1)};
+}
 static __device__ __forceinline__ u32x2 bs_bn_relu4(f32x4 acc, f32x4 sc, f32x4 sh) {
     const f32x2 t0 = f32x2{__builtin_fmaf(acc[0], sc[0], sh[0]), __builtin_fmaf(acc[1], sc[1], sh[1])};
     const f32x2 t1 = f32x2{__builtin_fmaf(acc[2], sc[2], sh[2]), __builtin_fmaf(acc[3], sc[3], sh[3])};
@@ -93,8 +107,14 @@ static __device__ __forceinline__ u32x2 bs_bn_relu4(f32x4 acc, f32x4 sc, f32x4 s
 // shortcut map is neither written nor read.
 // WPS: waves per SIMD the register budget is cut for (0: the compiler's choice — with 4-wave workgroups it spreads into the
 // AGPRs and a CU then holds ONE workgroup however little LDS it takes)
-template <int K1, int N2, int PW, int NW, bool PROJ = false, int WPS = 0>
+// MLP (round 5): the same two chained products as a transformer MLP whose hidden activations never leave the CU —
+//     out = fc2(gelu(fc1(x))) + res          (swin_transformer.py:62-82 Mlp, :335 `x + mlp(norm2(x))`; stage 1 of Swin-B: 128 -> 512 -> 128)
+// x = the K1-channel rows (a.x), W3 / shift3 = fc1's filter / bias, W1 / shift1 = fc2's; epilogue 1 is bias + GELU with NO store (y is
+// never written) and no skip, epilogue 2 is bias + the residual rows a.res [M][N2] with no activation.  Per row 3 * 2 * K1 bytes cross
+// HBM instead of (2 K1 + 4 N1) * 2: the hidden map (205 MB per block at half batch 64) is neither written nor read.
+template <int K1, int N2, int PW, int NW, bool PROJ = false, int WPS = 0, bool MLP = false>
 __global__ __launch_bounds__(64 * NW, WPS ? WPS : 1) void seam_kernel(const SeamArgs a) {
+    static_assert(!(PROJ && MLP), "one form at a time");
     constexpr int NT = 64 * NW;          // threads
     constexpr int IPT = 512 / NT;        // 16-byte chunks of a panel each thread stages
     constexpr int KS = K1 / 32;          // k-steps of GEMM1
@@ -166,7 +186,7 @@ __global__ __launch_bounds__(64 * NW, WPS ? WPS : 1) void seam_kernel(const Seam
                 xpf[ks][pw] = bs_load16(rsrd, pok[pw] ? (pix[pw] * a.res_ld + 32 * ks + 8 * g) * 2 : OOB);
     }
     auto skip_load = [&](int c, u32x4 (&sk)[PW][2]) {
-        if constexpr (PROJ) return;
+        if constexpr (PROJ || MLP) return;
 #pragma unroll
         for (int pw = 0; pw < PW; ++pw)
 #pragma unroll
@@ -286,6 +306,11 @@ __global__ __launch_bounds__(64 * NW, WPS ? WPS : 1) void seam_kernel(const Seam
                     } else {
                         rv = __builtin_bit_cast(half8v, sk[pw][h]);
                     }
+                    if constexpr (MLP) {      // bias + GELU; the hidden activations stay in registers
+                        const u32x2 o0 = bs_bn_gelu4(acc1[2 * h][pw], s0, h0), o1 = bs_bn_gelu4(acc1[2 * h + 1][pw], s1, h1);
+                        yf[pw][h] = u32x4{o0[0], o0[1], o1[0], o1[1]};
+                        continue;
+                    }
                     const u32x2 o0 = bs_bn_skip_relu4(acc1[2 * h][pw], s0, h0, half4v{rv[0], rv[1], rv[2], rv[3]});
                     const u32x2 o1 = bs_bn_skip_relu4(acc1[2 * h + 1][pw], s1, h1, half4v{rv[4], rv[5], rv[6], rv[7]});
                     const u32x4 o = u32x4{o0[0], o0[1], o1[0], o1[1]};
@@ -328,7 +353,15 @@ __global__ __launch_bounds__(64 * NW, WPS ? WPS : 1) void seam_kernel(const Seam
             const f32x4 h0 = *reinterpret_cast<const f32x4*>(sh + 8 * h), h1 = *reinterpret_cast<const f32x4*>(sh + 8 * h + 4);
 #pragma unroll
             for (int pw = 0; pw < PW; ++pw) {
-                const u32x2 o0 = bs_bn_relu4(acc2[4 * q + 2 * h][pw], s0, h0), o1 = bs_bn_relu4(acc2[4 * q + 2 * h + 1][pw], s1, h1);
+                u32x2 o0, o1;
+                if constexpr (MLP) {      // + the residual rows, no activation
+                    const half8v rv = __builtin_bit_cast(half8v, bs_load16(rsrd, pok[pw] ? (pix[pw] * a.res_ld + 64 * q + 16 * g + 8 * h) * 2 : OOB));
+                    o0 = bs_bn_res4(acc2[4 * q + 2 * h][pw], s0, h0, half4v{rv[0], rv[1], rv[2], rv[3]});
+                    o1 = bs_bn_res4(acc2[4 * q + 2 * h + 1][pw], s1, h1, half4v{rv[4], rv[5], rv[6], rv[7]});
+                } else {
+                    o0 = bs_bn_relu4(acc2[4 * q + 2 * h][pw], s0, h0);
+                    o1 = bs_bn_relu4(acc2[4 * q + 2 * h + 1][pw], s1, h1);
+                }
                 const u32x4 o = u32x4{o0[0], o0[1], o1[0], o1[1]};
                 if (TLXMI_DBG(a, 4)) continue;
                 if (TLXMI_DBG_NT(a.z_nt)) bs_store16_nt(zsrd, o, pok[pw] ? (pix[pw] * a.z_ld + 64 * q + 16 * g + 8 * h) * 2 : OOB);
@@ -546,11 +579,11 @@ template <int K1, int N2, int NW> static int launch_seam_pair_t(const SeamArgs& 
     return TLXMI_OK;
 }
 
-template <int K1, int N2, int PW, int NW, bool PROJ = false, int WPS = 0> static int launch_seam_t(const SeamArgs& a, hipStream_t st) {
+template <int K1, int N2, int PW, int NW, bool PROJ = false, int WPS = 0, bool MLP = false> static int launch_seam_t(const SeamArgs& a, hipStream_t st) {
     constexpr int NP = K1 / 64 + N2 / 64 + (PROJ ? K1 / 64 : 0);
     const size_t lds = (size_t)2 * NP * 64 * 128 + (size_t)(2 * a.N1 + 2 * N2 + (PROJ ? 2 * a.N1 : 0)) * sizeof(float);
     if (lds > 160 * 1024) return fail(TLXMI_ERR_UNSUPPORTED, "block_seam: %zu bytes of LDS", lds);
-    const void* fn = reinterpret_cast<const void*>(&seam_kernel<K1, N2, PW, NW, PROJ, WPS>);
+    const void* fn = reinterpret_cast<const void*>(&seam_kernel<K1, N2, PW, NW, PROJ, WPS, MLP>);
     if (lds > 64 * 1024)
         if (int rc = raise_lds_limit(fn, 160 * 1024, "block_seam")) return rc;
     const long grid = ((long)a.M + NW * 16 * PW - 1) / (NW * 16 * PW);
@@ -577,6 +610,15 @@ bool block_seam_shape_ok(int K1, int N1, int N2) {
     // answer yes to a launch that is then refused (256 -> 2048 -> 256 needs 165888 bytes; found by tests/test_seam_gpu.py)
     const size_t lds = (size_t)2 * (K1 / 64 + N2 / 64) * 64 * 128 + (size_t)(2 * N1 + 2 * N2) * sizeof(float) + (K1 == 256 ? (size_t)8 * 2 * 1024 : 0);
     return lds <= 160 * 1024;
+}
+
+// the MLP form (a.y == nullptr): 128 -> N1 -> 128 (Swin-B stage 1)
+int launch_mlp_seam(const SeamArgs& a0, int K1, int N2, hipStream_t st) {
+    SeamArgs b = a0;
+    b.z_nt = b.y_nt = 0;
+    b.debug = 0;
+    if (K1 == 128 && N2 == 128) return launch_seam_t<128, 128, 2, 8, false, 0, true>(b, st);
+    return fail(TLXMI_ERR_UNSUPPORTED, "mlp_seam: no instantiation for %d -> N1 -> %d channels", K1, N2);
 }
 
 int launch_block_seam(const SeamArgs& a0, int K1, int N2, hipStream_t st) {
@@ -670,4 +712,37 @@ extern "C" int tlxmi_bottleneck_seam_proj(const tlxmi_seam_desc* d, const void* 
                                           const float* shift1, void* t1, void* stream) {
     TLXMI_REQUIRE(wd_packed, TLXMI_ERR_BAD_ARG, "bottleneck_seam_proj: null shortcut filter");
     return seam_impl(d, t2, w3_packed, scale3, shift3, x, y, w1_packed, scale1, shift1, t1, stream, wd_packed, scale_d, shift_d);
+}
+
+// A transformer MLP as ONE launch (round 5): out = fc2(gelu(fc1(x) + b1)) + b2 + res, the hidden activations never leave the CU
+// (swin_transformer.py:62-82, :335; the seam kernel above in its MLP form).  fp16; x [rows][x_ld] with K channels, res / out [rows][ld]
+// with N = K output channels; hidden = the middle width (a multiple of 64).  Compiled for K = N = 128 (stage 1 of Swin-B);
+// tlxmi_mlp_seam_supported asks first.
+extern "C" int tlxmi_mlp_seam_supported(int dtype, int K, int hidden, int N) {
+    return (dtype == TLXMI_F16 && K == 128 && N == 128 && hidden % 64 == 0 && hidden >= 64 && hidden <= 2048 && block_seam_shape_ok(K, hidden, N)) ? 1 : 0;
+}
+
+extern "C" int tlxmi_mlp_seam(int dtype, int64_t rows, int K, int hidden, int N, const void* x, int x_ld, const void* w1_packed, const float* bias1,
+                              const void* w2_packed, const float* bias2, const void* res, int res_ld, void* out, int out_ld, void* stream) {
+    TLXMI_REQUIRE(x && w1_packed && w2_packed && res && out, TLXMI_ERR_BAD_ARG, "mlp_seam: null argument");
+    if (!tlxmi_mlp_seam_supported(dtype, K, hidden, N)) return fail(TLXMI_ERR_UNSUPPORTED, "mlp_seam: no kernel for %d -> %d -> %d", K, hidden, N);
+    TLXMI_REQUIRE(rows > 0 && x_ld >= K && res_ld >= N && out_ld >= N, TLXMI_ERR_BAD_ARG, "mlp_seam: bad extent");
+    TLXMI_REQUIRE(x_ld % 8 == 0 && res_ld % 8 == 0 && out_ld % 8 == 0 && aligned16(x) && aligned16(res) && aligned16(out) && aligned16(w1_packed) && aligned16(w2_packed),
+                  TLXMI_ERR_ALIGNMENT, "mlp_seam: rows must be whole 16-byte chunks");
+    const long long big = (1ll << 31);
+    TLXMI_REQUIRE(rows * x_ld * 2 < big && rows * res_ld * 2 < big && rows * out_ld * 2 < big, TLXMI_ERR_UNSUPPORTED, "mlp_seam: a tensor exceeds 2 GiB");
+    SeamArgs a;
+    a.x = (const char*)x; a.w3 = (const char*)w1_packed; a.res = (const char*)res; a.w1 = (const char*)w2_packed;
+    a.y = nullptr; a.z = (char*)out;
+    a.scale3 = nullptr; a.shift3 = bias1; a.scale1 = nullptr; a.shift1 = bias2;
+    a.M = (int)rows; a.N1 = hidden;
+    a.x_ld = x_ld; a.res_ld = res_ld; a.y_ld = 0; a.z_ld = out_ld;
+    a.x_bytes = (unsigned)(rows * x_ld * 2); a.res_bytes = (unsigned)(rows * res_ld * 2); a.y_bytes = 0; a.z_bytes = (unsigned)(rows * out_ld * 2);
+    a.wd = nullptr; a.scale_d = a.shift_d = nullptr; a.wd_bytes = 0;
+    a.w3_bytes = (unsigned)(((size_t)(hidden + 127) / 128 * 128) * (size_t)K * 2);
+    a.w1_bytes = (unsigned)(((size_t)(N + 127) / 128 * 128) * (size_t)hidden * 2);
+    a.y_nt = a.z_nt = 0; a.debug = 0;
+    const int rc = launch_mlp_seam(a, K, N, as_stream(stream));
+    if (rc != TLXMI_OK) return rc;
+    return check_launch("mlp_seam");
 }

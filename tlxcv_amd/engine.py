@@ -29,6 +29,7 @@ _options = {"splitk": True,       # classifier heads: K slices side by side (tlx
             "patch_linear": True, # ViT patch embedding as one Linear over all token rows (tlxmi_patchify + the persistent GEMM); off = the
                                   # space-to-depth implicit GEMM writing rows 1.. of each image (the A/B and the parity tests' other arm)
             "patch_embed4": True, # Swin patch embedding (conv 4 x 4 / 4 + LayerNorm) as one pass over the NCHW image (tlxmi_patch_embed4, fp16)
+            "mlp_seam": True,     # Swin stage 1 (128 -> 512 -> 128): fc1 + GELU + fc2 + residual as one launch (tlxmi_mlp_seam), the hidden map stays on chip
             "lnfold": True,       # LayerNorm folded AROUND the Linear layers of a transformer block (fp16, round 5): proj / fc2 / the patch embedding
                                   # emit the row statistics of the residual stream from their epilogues (tlxmi_linear_stats), qkv / fc1 apply
                                   # the normalisation in theirs (tlxmi_linear_ln); off = LayerNorm launches + plain Linear layers (the parity
@@ -778,6 +779,31 @@ def _linear_splits(rows, K, pk, x):
     if best and rows * pk.Cout * es * best >= (1 << 31):
         return 0
     return best
+
+
+def mlp_seam_supported(rows, K, hidden, N, dtype):
+    return bool(_options["mlp_seam"] and dtype == torch.float16 and rows >= 4096 and _lib.load().tlxmi_mlp_seam_supported(F16, int(K), int(hidden), int(N)))
+
+
+def mlp_seam(x, pk1, b1, pk2, b2, res, out=None):
+    """out = fc2(gelu(fc1(x) + b1)) + b2 + res in ONE launch (tlxmi_mlp_seam): x (..., K) fp16, pk1 / pk2 the packed fc1 / fc2 filters, res
+    (..., N) the residual rows; out may be res (in place: a row is read before it is written by the lane that owns it)."""
+    need_gpu(x, "input")
+    shp = x.shape
+    x = x if x.is_contiguous() else x.contiguous()
+    K = shp[-1]
+    rows = x.numel() // K
+    N = pk2.Cout
+    if not res.is_contiguous():
+        raise RuntimeError("mlp_seam: the residual must be dense")
+    y = out if out is not None else torch.empty((*shp[:-1], N), dtype=x.dtype, device=x.device)
+    if _probe is not None:
+        e0, e1 = _probe_pair()
+    _lib.call("tlxmi_mlp_seam", dt_code(x.dtype), rows, K, pk1.Cout, N, _p(x), K, _p(pk1.buf), _p(b1), _p(pk2.buf), _p(b2), _p(res), N, _p(y), N, _stream())
+    if _probe is not None:
+        e1.record()
+        _probe.append((e0, e1, (rows * (K + 2 * N) + 2 * pk1.Cout * K) * 2, 2 * rows * pk1.Cout * (K + N), (rows, 1, 1, K, N, pk1.Cout, "mlp seam", True)))
+    return y
 
 
 def linear_ln_supported(rows, K, Cout, dtype, act=ACT_NONE, with_res=False):

@@ -76,6 +76,15 @@ class Mlp(nn.Module):
         self.drop = nn.Dropout(drop)
 
     def run(self, x, res=None):
+        dt = E.precision()
+        if (res is not None and getattr(self.act, "ACT", None) == E.ACT_GELU and x.dtype == dt
+                and E.mlp_seam_supported(x.numel() // x.shape[-1], self.fc1.in_features, self.fc1.out_features, self.fc2.out_features, dt)):
+            # fc1 + GELU + fc2 + residual as one launch: the (rows, 4 C) hidden map stays on the CU (round 5; stage 1 of Swin-B)
+            pk1 = self.fc1._cached("pk", lambda: E.PackedFilter(self.fc1.weights.detach().t().contiguous(), dt))
+            pk2 = self.fc2._cached("pk", lambda: E.PackedFilter(self.fc2.weights.detach().t().contiguous(), dt))
+            b1 = self.fc1._cached("bias", lambda: E._f32(self.fc1.biases)) if self.fc1.biases is not None else None
+            b2 = self.fc2._cached("bias", lambda: E._f32(self.fc2.biases)) if self.fc2.biases is not None else None
+            return E.mlp_seam(x, pk1, b1, pk2, b2, res, out=res)
         return self.fc2.run(self.fc1.run(x, act=self.act.ACT), res=res, out=res)
 
     def forward(self, x):
