@@ -193,6 +193,12 @@ int tlxmi_yolo_box(const void* x, int dtype, int N, int A, int C, int H, int W, 
 size_t tlxmi_multiclass_nms_workspace_bytes(int N, int M);
 int tlxmi_multiclass_nms(const float* boxes, const float* scores, int N, int M, int C, float score_threshold, float nms_threshold,
                          int keep_top_k, void* workspace, float* detections, int32_t* counts, void* stream);
+/* The same with the kept boxes' indices (the index-returning NMS the for_mot branch of YOLOv3.forward asks of its post-process,
+ * yolov3.py:70-78; Paddle's multiclass_nms(return_index=True), utils/ops.py:189-229): keep_index [N][keep_top_k] = position
+ * of each detection row's box among the M boxes of its image, -1 beyond counts[n]. */
+int tlxmi_multiclass_nms_index(const float* boxes, const float* scores, int N, int M, int C, float score_threshold,
+                               float nms_threshold, int keep_top_k, void* workspace, float* detections, int32_t* counts,
+                               int32_t* keep_index, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Image pre-processing on the device (the host pipeline of demo/image_classification/predict.py:22-29,

@@ -70,14 +70,17 @@ def _nms(boxes, scores, thr):
     return order[torch.tensor(keep, dtype=torch.int64)]
 
 
-def multiclass_nms(bboxes, scores, score_threshold=0.7, nms_threshold=0.45, keep_top_k=100):
+def multiclass_nms(bboxes, scores, score_threshold=0.7, nms_threshold=0.45, keep_top_k=100, return_index=False):
     """tlx_multiclass_nms, utils/ops.py:255-329 (class-aware branch): per image rows (class, score, x1, y1, x2, y2), None when
-    nothing passes the threshold.  torchvision.ops.batched_nms = greedy NMS on boxes shifted by class * (max coordinate + 1)."""
+    nothing passes the threshold.  torchvision.ops.batched_nms = greedy NMS on boxes shifted by class * (max coordinate + 1).
+    return_index: (rows, index of each row's box in the image's box list) per image — what the for_mot branch of YOLOv3.forward
+    unpacks as nms_keep_idx (yolov3.py:70-78; Paddle's multiclass_nms(return_index=True), utils/ops.py:189-229)."""
     out = []
     for xyxy, score in zip(bboxes, scores):
         conf, pred = score.max(1)                                                           # :287-288 (first maximal class)
         m = conf >= score_threshold
         det = torch.cat([xyxy, conf[:, None], pred[:, None].float()], 1)[m]                 # :292-296
+        src = torch.nonzero(m)[:, 0]
         if det.shape[0] == 0:
             out.append(None)
             continue
@@ -88,7 +91,8 @@ def multiclass_nms(bboxes, scores, score_threshold=0.7, nms_threshold=0.45, keep
         if keep_top_k > 0 and len(order) > keep_top_k:
             order = order[:keep_top_k]
         det = det[order]
-        out.append(torch.cat([det[:, 5:6], det[:, 4:5], det[:, :4]], 1))                    # :320-322
+        rows = torch.cat([det[:, 5:6], det[:, 4:5], det[:, :4]], 1)                         # :320-322
+        out.append((rows, src[keep][order]) if return_index else rows)
     return out
 
 

@@ -47,6 +47,34 @@ def test_multiclass_nms_edge_cases(dev):
     assert int(cnt[0]) == 2 and det[0, :2, 0].tolist() == [0.0, 1.0] and det[0, :2, 1].tolist() == pytest.approx([0.9, 0.7])
 
 
+def test_multiclass_nms_returns_the_kept_boxes_indices(dev):
+    """The index-returning form (yolov3.py:70-78 `nms_keep_idx`): same detections as the plain call, each row's index points at its
+    box, -1 past the count; the golden candidates of the reference's own function, a ragged random case with ties, and the
+    one-thread-per-row (keep_top_k > 1024) form of the kernel."""
+    g = np.load(os.path.join(GOLDEN, "yolov3_post_b1.npz"))
+    cases = [(torch.from_numpy(g[f"{t}_boxes"]), torch.from_numpy(g[f"{t}_scores"]), float(g[f"{t}_thr"]), 100) for t in ("yolo", "dense")]
+    rng = np.random.default_rng(11)
+    b = torch.from_numpy(rng.uniform(0, 60, (3, 301, 4)).astype(np.float32))
+    b[..., 2:] += b[..., :2]
+    s = torch.from_numpy((rng.integers(0, 50, (3, 301, 4)) / 50.0).astype(np.float32))      # many equal scores
+    cases += [(b, s, 0.3, 20), (b, s, 0.5, 1500), (b[:, :37], s[:, :37], 2.0, 10)]
+    for bx, sc, thr, k in cases:
+        det0, cnt0 = E.multiclass_nms(bx.to(dev), sc.to(dev), thr, 0.5, k)
+        det, cnt, idx = E.multiclass_nms(bx.to(dev), sc.to(dev), thr, 0.5, k, return_index=True)
+        assert torch.equal(det, det0) and torch.equal(cnt, cnt0) and idx.shape == (bx.shape[0], k) and idx.dtype == torch.int32
+        want = OD.multiclass_nms(bx, sc, thr, 0.5, k, return_index=True)
+        for n, w in enumerate(want):
+            c = int(cnt[n])
+            assert c == (0 if w is None else w[0].shape[0])
+            assert (idx[n, c:] == -1).all()
+            if c:
+                assert torch.equal(bx[n][idx[n, :c].cpu().long()], det[n, :c, 2:].cpu())          # the row's box IS that box
+                assert torch.equal(sc[n][idx[n, :c].cpu().long()].max(1).values, det[n, :c, 1].cpu())
+                assert np.array_equal(det[n, :c].cpu().numpy(), w[0].numpy())
+                # ties in score may be kept in either order by a stable / unstable sort only if rows are identical: compare as sets per score
+                assert sorted(idx[n, :c].tolist()) == sorted(w[1].tolist())
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["fp32", "fp16"])
 def test_yolo_box_decode(dev, dtype):
     rng = np.random.default_rng(3)
@@ -83,6 +111,12 @@ def test_yolov3_forward_ends_in_detections(dev, fp32_mode):
     assert out["labels"].tolist() == want[:, 0].int().tolist()
     np.testing.assert_allclose(out["scores"], want[:, 1].numpy(), rtol=1e-4, atol=1e-5)
     assert np.abs(out["boxes"] - want[:, 2:].numpy().astype(int)).max() <= 1          # integer pixel boxes (cvt_results)
+    # for_mot (:64-78): the same detections, the neck's embedding maps, and which candidate box each row came from
+    m.for_mot = True
+    mot = m({"images": x.to(dev)})
+    assert torch.equal(mot["detections"], out["detections"]) and len(mot["emb_feats"]) == 3
+    keep = mot["nms_keep_idx"]
+    assert keep.shape == (1, 100) and (keep[0, n:] == -1).all() and int(keep[0, :n].min()) >= 0 and keep[0, :n].unique().numel() == n
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["fp32", "fp16"])

@@ -75,6 +75,7 @@ PROTOTYPES = {
     "tlxmi_yolo_iou_aware": [_vp, _vp, _i, _l, _i, _i, _f, _vp],
     "tlxmi_yolo_box": [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _f, _i, _i, _f, _vp, _vp, _i, _i, _vp],
     "tlxmi_multiclass_nms": [_vp, _vp, _i, _i, _i, _f, _f, _i, _vp, _vp, _vp, _vp],
+    "tlxmi_multiclass_nms_index": [_vp, _vp, _i, _i, _i, _f, _f, _i, _vp, _vp, _vp, _vp, _vp],
     "tlxmi_linear_splitk": [_i, _l, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _u, _vp, _i, _vp],
     "tlxmi_group_conv2d": [C.POINTER(ConvDesc), _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "tlxmi_pack_group_filter": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],

@@ -150,8 +150,8 @@ __global__ void nms_keys16_kernel(const float* __restrict__ scores, unsigned lon
 
 template <bool LDSKEYS>
 __global__ __launch_bounds__(1024) void nms_image_kernel(const float* __restrict__ boxes, unsigned long long* __restrict__ keys,
-                                                         const int* __restrict__ cls, float* __restrict__ det, int* __restrict__ count, int M,
-                                                         int MP, float nms_thr, int keep_top_k) {
+                                                         const int* __restrict__ cls, float* __restrict__ det, int* __restrict__ count,
+                                                         int* __restrict__ kidx, int M, int MP, float nms_thr, int keep_top_k) {
     extern __shared__ __attribute__((aligned(16))) char nms_smem[];
     // LDSKEYS (MP <= 16384): the image's keys are sorted in LDS, [MP] keys then [MP] suppression flags — the 105 compare-exchange
     // passes of 16 384 keys cost a global round trip each when sorted in place (YOLOv3, 32 images: 662 us, most of it the sort)
@@ -245,6 +245,7 @@ __global__ __launch_bounds__(1024) void nms_image_kernel(const float* __restrict
             const float* bi = boxes + ((long)n * M + mi) * 4;
             float* o = dp + kept * 6;
             o[0] = (float)cls[(long)n * M + mi]; o[1] = __uint_as_float((unsigned)(ki >> 32)); o[2] = bi[0]; o[3] = bi[1]; o[4] = bi[2]; o[5] = bi[3];
+            if (kidx) kidx[(long)n * keep_top_k + kept] = mi;
         }
         ++kept;
         for (int j = i + 1 + t; j < K; j += 1024) {
@@ -274,10 +275,13 @@ __global__ __launch_bounds__(1024) void nms_image_kernel(const float* __restrict
             const float* bi = boxes + ((long)n * M + mi) * 4;
             float* o = dp + t * 6;
             o[0] = (float)cls[(long)n * M + mi]; o[1] = __uint_as_float((unsigned)(ki >> 32)); o[2] = bi[0]; o[3] = bi[1]; o[4] = bi[2]; o[5] = bi[3];
+            if (kidx) kidx[(long)n * keep_top_k + t] = mi;
         }
     }
     if (t == 0) count[n] = kept;
     for (int i = kept * 6 + t; i < keep_top_k * 6; i += 1024) dp[i] = 0.f;
+    if (kidx)
+        for (int i = kept + t; i < keep_top_k; i += 1024) kidx[(long)n * keep_top_k + i] = -1;
 }
 
 }  // namespace tlxmi
@@ -323,8 +327,8 @@ extern "C" size_t tlxmi_multiclass_nms_workspace_bytes(int N, int M) {
     return (size_t)N * nms_pow2(M) * 8 + (size_t)N * M * 4;
 }
 
-extern "C" int tlxmi_multiclass_nms(const float* boxes, const float* scores, int N, int M, int C, float score_threshold, float nms_threshold,
-                                    int keep_top_k, void* workspace, float* detections, int32_t* counts, void* stream) {
+static int multiclass_nms_impl(const float* boxes, const float* scores, int N, int M, int C, float score_threshold, float nms_threshold,
+                               int keep_top_k, void* workspace, float* detections, int32_t* counts, int32_t* keep_index, void* stream) {
     TLXMI_REQUIRE(boxes && scores && workspace && detections && counts, TLXMI_ERR_BAD_ARG, "multiclass_nms: null argument");
     TLXMI_REQUIRE(N > 0 && M > 0 && C > 0 && keep_top_k > 0, TLXMI_ERR_BAD_ARG, "multiclass_nms: bad extent");
     const int MP = nms_pow2(M);
@@ -345,12 +349,24 @@ extern "C" int tlxmi_multiclass_nms(const float* boxes, const float* scores, int
         const size_t lds = (size_t)MP * 9;
         if (lds > 48 * 1024)       // (the kernel also has 8 KB of static LDS: the dynamic limit cannot be the whole 160 KB)
             if (int rc = raise_lds_limit(reinterpret_cast<const void*>(&nms_image_kernel<true>), 148 * 1024, "multiclass_nms")) return rc;
-        hipLaunchKernelGGL(nms_image_kernel<true>, dim3(N), dim3(1024), lds, st, boxes, keys, cls, detections, counts, M, MP, nms_threshold, keep_top_k);
+        hipLaunchKernelGGL(nms_image_kernel<true>, dim3(N), dim3(1024), lds, st, boxes, keys, cls, detections, counts, keep_index, M, MP, nms_threshold, keep_top_k);
     } else {
         const size_t lds = (size_t)MP;
         if (lds > 48 * 1024)
             if (int rc = raise_lds_limit(reinterpret_cast<const void*>(&nms_image_kernel<false>), 96 * 1024, "multiclass_nms")) return rc;
-        hipLaunchKernelGGL(nms_image_kernel<false>, dim3(N), dim3(1024), lds, st, boxes, keys, cls, detections, counts, M, MP, nms_threshold, keep_top_k);
+        hipLaunchKernelGGL(nms_image_kernel<false>, dim3(N), dim3(1024), lds, st, boxes, keys, cls, detections, counts, keep_index, M, MP, nms_threshold, keep_top_k);
     }
     return check_launch("multiclass_nms");
+}
+
+extern "C" int tlxmi_multiclass_nms(const float* boxes, const float* scores, int N, int M, int C, float score_threshold, float nms_threshold,
+                                    int keep_top_k, void* workspace, float* detections, int32_t* counts, void* stream) {
+    return multiclass_nms_impl(boxes, scores, N, M, C, score_threshold, nms_threshold, keep_top_k, workspace, detections, counts, nullptr, stream);
+}
+
+extern "C" int tlxmi_multiclass_nms_index(const float* boxes, const float* scores, int N, int M, int C, float score_threshold,
+                                          float nms_threshold, int keep_top_k, void* workspace, float* detections, int32_t* counts,
+                                          int32_t* keep_index, void* stream) {
+    TLXMI_REQUIRE(keep_index, TLXMI_ERR_BAD_ARG, "multiclass_nms_index: null keep_index");
+    return multiclass_nms_impl(boxes, scores, N, M, C, score_threshold, nms_threshold, keep_top_k, workspace, detections, counts, keep_index, stream);
 }

@@ -1211,15 +1211,21 @@ def yolo_iou_aware(head_nhwc, num_anchors, num_classes, factor):
     return y
 
 
-def multiclass_nms(boxes, scores, score_threshold=0.05, nms_threshold=0.5, keep_top_k=100):
+def multiclass_nms(boxes, scores, score_threshold=0.05, nms_threshold=0.5, keep_top_k=100, return_index=False):
     """tlx_multiclass_nms (detection/utils/ops.py:255-329) on the device: boxes (N,M,4), scores (N,M,C) fp32 ->
-    (detections (N, keep_top_k, 6) rows (class, score, x1, y1, x2, y2), counts (N,) int32)."""
+    (detections (N, keep_top_k, 6) rows (class, score, x1, y1, x2, y2), counts (N,) int32); return_index (yolov3.py:70-78, the
+    for_mot post-process): also keep_index (N, keep_top_k) int32, each row's box among the M of its image, -1 past the count."""
     need_gpu(boxes, "boxes")
     boxes, scores = boxes.float().contiguous(), scores.float().contiguous()
     N, M, Cc = scores.shape
     ws = torch.empty(_lib.load().tlxmi_multiclass_nms_workspace_bytes(N, M), dtype=torch.uint8, device=boxes.device)
     det = torch.empty((N, keep_top_k, 6), dtype=torch.float32, device=boxes.device)
     cnt = torch.empty((N,), dtype=torch.int32, device=boxes.device)
+    if return_index:
+        idx = torch.empty((N, keep_top_k), dtype=torch.int32, device=boxes.device)
+        _lib.call("tlxmi_multiclass_nms_index", _p(boxes), _p(scores), N, M, Cc, C.c_float(score_threshold), C.c_float(nms_threshold),
+                  int(keep_top_k), _p(ws), _p(det), _p(cnt), _p(idx), _stream())
+        return det, cnt, idx
     _lib.call("tlxmi_multiclass_nms", _p(boxes), _p(scores), N, M, Cc, C.c_float(score_threshold), C.c_float(nms_threshold), int(keep_top_k),
               _p(ws), _p(det), _p(cnt), _stream())
     return det, cnt

@@ -12,6 +12,12 @@ bias (+ shift mask) -> softmax -> @v -> proj -> window_reverse -> roll back -> r
     (heads, 49, 49) bias table and the (nW, 49, 49) shift mask in registers;
   * qkv / proj / fc1(+GELU) / fc2(+residual) are the implicit-GEMM kernel with fused epilogues;
   * PatchMerging's strided 2x2 gather + concat + LayerNorm is one pass (tlxmi_patch_merge_layernorm), then the GEMM.
+Round 5, fp16 at >= `lnfold_min_rows` token rows per launch and channel widths >= `lnfold_min_c` (stages 2 - 4 of
+Swin-B at bench size): the residual stream stays in IMAGE order and neither LayerNorm-type pass runs — the producing GEMM (proj,
+fc2, the PatchMerging reduction) leaves per-row (sum, sum of squares) partials, qkv / fc1 run on the raw stream with gamma folded
+into the weight and the per-row affine in the epilogue, and roll + window_partition / window_reverse + roll back are row
+arithmetic inside the attention kernel (tlxmi_attention_windows).  Stage 1 (128 channels: statistics of a row fit no tile
+economy, the passes stay) runs its Mlp as one launch with the hidden map on chip (tlxmi_mlp_seam).
 Quirks kept on purpose: the -100.0 (not -inf) mask, and the PatchMerging reduction bias (:369-370).
 """
 

@@ -13,8 +13,11 @@ change of arithmetic):
   * Attention (:112-123) = qkv GEMM(+bias) -> one fused softmax(q k^T * scale) v kernel on the
     packed qkv matrix -> proj GEMM with bias and the residual add of Block.forward (:173) fused.
   * Mlp (:81-87) = fc1 GEMM with bias+exact-erf GELU epilogue -> fc2 GEMM with bias + residual (:174).
-  * norm1 / norm2 (:172-174) are LayerNorm launches of their own in front of the qkv / fc1 GEMMs (folding them into the GEMMs
-    was built in rounds 2 - 3, measured equal or slower in every form and removed in round 4: DESIGN 5.2).
+  * norm1 / norm2 (:172-174) are no launches and no passes over the token matrix at fp16 bench sizes (round 5): the
+    GEMM that writes the residual stream (patch Linear, proj, fc2) leaves per-row (sum, sum of squares) partials from its fp32
+    epilogue values, a 3 us launch turns them into (rstd, -mean * rstd) per row, and qkv / fc1 run on the RAW stream with gamma
+    folded into the weight and  y = a * acc + b * c1[n] + c2[n]  in the epilogue.  Below `lnfold_min_rows` token rows per launch,
+    in fp32, and with set_option("lnfold", 0): LayerNorm launches of their own in front of the qkv / fc1 GEMMs.
   * final LayerNorm only on the cls rows (x[:, 0] commutes with a per-row norm, :327-328).
 """
 import numpy as np

@@ -163,8 +163,8 @@ class MultiClassNMS:
     def __init__(self, score_threshold=0.05, nms_top_k=-1, keep_top_k=100, nms_threshold=0.5, **kwds):
         self.score_threshold, self.nms_top_k, self.keep_top_k, self.nms_threshold = score_threshold, nms_top_k, keep_top_k, nms_threshold
 
-    def __call__(self, bboxes, score):
-        return E.multiclass_nms(bboxes, score, self.score_threshold, self.nms_threshold, self.keep_top_k)
+    def __call__(self, bboxes, score, return_index=False):
+        return E.multiclass_nms(bboxes, score, self.score_threshold, self.nms_threshold, self.keep_top_k, return_index=return_index)
 
 
 def cvt_results(det, cnt):
@@ -196,8 +196,10 @@ class YOLOv3(nn.Module):
         conv = lambda ts: [from_nhwc(t, self.data_format) for t in ts]
         out = {"images": inputs["images"], "body_feats": conv(body), "neck_feats": conv(neck), "yolo_head_outs": conv(head)}
         if self.for_mot:
-            # :64-65: the embedding maps of a tracker (JDE); the reference's for_mot post-process additionally returns the NMS
-            # keep indices (boxes_idx / nms_keep_idx, :70-78) through an index-returning NMS that is not part of this engine
+            # :64-65: the embedding maps of a tracker (JDE).  The for_mot branch (:70-78) unpacks FOUR values from a post-process
+            # the reference does not ship (its BBoxPostProcess returns two, utils/post_process.py:53); what a tracker needs from
+            # it — which candidate box each detection row came from, to pick that box's embedding — is "nms_keep_idx" below
+            # (tlxmi_multiclass_nms_index).
             out["emb_feats"] = conv(emb)
         # :67-103: decode + NMS -> labels / scores / boxes / bbox_num
         img = inputs["images"]
@@ -206,7 +208,11 @@ class YOLOv3(nn.Module):
         scale_factor = inputs.get("scale_factor", torch.ones_like(torch.as_tensor(im_shape, dtype=torch.float32)))
         bboxes, scores = self.decode(head, self.yolo_head.mask_anchors, torch.as_tensor(im_shape, dtype=torch.float32).cpu(),
                                      torch.as_tensor(scale_factor, dtype=torch.float32).cpu())
-        det, cnt = self.nms(bboxes, scores)
+        if self.for_mot:
+            det, cnt, keep = self.nms(bboxes, scores, return_index=True)
+            out["nms_keep_idx"] = keep                          # (N, keep_top_k) int32: row of `bboxes[n]`, -1 past bbox_num[n]
+        else:
+            det, cnt = self.nms(bboxes, scores)
         out.update(cvt_results(det, cnt))
         out["detections"], out["detection_counts"] = det, cnt
         return out
