@@ -33,7 +33,8 @@
 extern "C" {
 #endif
 
-/* 101 (round 5): + tlxmi_linear_stats / tlxmi_ln_finalize / tlxmi_linear_ln / tlxmi_linear_ln_supported.  100 (round 4) had removed
+/* 101 (round 5): + tlxmi_linear_stats / tlxmi_ln_finalize / tlxmi_linear_ln / tlxmi_linear_ln_supported, tlxmi_attention_windows,
+ * tlxmi_mlp_seam(_supported), tlxmi_softmax_rows, tlxmi_patch_embed4_pos, tlxmi_multiclass_nms_index.  100 (round 4) had removed
  * tlxmi_row_stats / tlxmi_linear_ln(11 args) / tlxmi_layernorm_linear of the round-3 header without a version step: a caller built
  * against that header must check tlxmi_version() >= 101 and use the signatures below. */
 #define TLXMI_VERSION 101

@@ -28,6 +28,10 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"libtlxmi.so does not export {n}"
     # and the ctypes table covers exactly the header
     assert sorted(_lib.ALL_SYMBOLS) == names
+    # ... and the library exports nothing under the prefix that the header does not declare (a removed entry point stays removed)
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
+    exported = sorted(l.split()[-1] for l in out.splitlines() if l.split()[-1].startswith("tlxmi_") and l.split()[-2] in "TW")
+    assert exported == names
 
 
 def test_version_and_error_string():

@@ -332,12 +332,14 @@ def test_argmax_ties_nan_and_tail(dev):
 @pytest.mark.parametrize("shape", [(3, 3, 30, 46), (1, 3, 224, 224), (2, 3, 6, 2), (2, 4, 8, 8)],
                          ids=lambda s: "x".join(map(str, s)))
 @pytest.mark.parametrize("offset", [0, 1], ids=["aligned", "odd_element_offset"])
-def test_rgb_space_to_depth_fold(dev, shape, offset):
-    """tlxmi_nchw_to_nhwc_s2d with b = 2 (the RGB stems: 8-byte loads when the image is 3-channel fp32 and 8-byte
-    aligned, the generic kernel otherwise): channel (ph*2 + pw)*C + c of output pixel (h2, w2) = x[n, c, 2*h2+ph, 2*w2+pw]."""
+@pytest.mark.parametrize("src", [torch.float32, torch.float16], ids=["from_fp32", "from_fp16"])
+def test_rgb_space_to_depth_fold(dev, shape, offset, src):
+    """tlxmi_nchw_to_nhwc_s2d with b = 2 (the RGB stems: one load per pair of horizontal neighbours when the image is 3-channel and
+    pair-aligned — 8 bytes of an fp32 image, 4 of an fp16 one — the generic kernel otherwise): channel (ph*2 + pw)*C + c of output
+    pixel (h2, w2) = x[n, c, 2*h2+ph, 2*w2+pw]."""
     N, Cc, H, W = shape
     g = torch.Generator().manual_seed(41)
-    flat = torch.randn(N * Cc * H * W + 1, generator=g)
+    flat = torch.randn(N * Cc * H * W + 1, generator=g).to(src)
     x = flat[offset: offset + N * Cc * H * W].view(N, Cc, H, W)
     want = x.view(N, Cc, H // 2, 2, W // 2, 2).permute(0, 2, 4, 3, 5, 1).reshape(N, H // 2, W // 2, 4 * Cc)
     xd = flat.to(dev)[offset: offset + N * Cc * H * W].view(N, Cc, H, W)

@@ -136,26 +136,40 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_s2d_rows_kernel(const TS* __
 // horizontal neighbours, six loads per output pixel instead of twelve, consecutive lanes read consecutive 8 bytes.
 // A thread makes PPT output pixels 256 apart in the flattened (image, row, column) order — all 12 / 24 loads in flight before the
 // first conversion, every lane busy, 8 KB of contiguous output per workgroup and pass (round 4: one 112-pixel row per 128-thread
-// workgroup ran 2.4 TB/s on 128 images; this form: tools/stem_micro.py).
-template <typename TD, int PPT>
-__global__ __launch_bounds__(256) void nchw3_to_nhwc_s2d2_kernel(const float* __restrict__ src, TD* __restrict__ dst, int H, int W,
+// workgroup ran 2.4 TB/s on 128 images; this form: tools/stem_micro.py).  Round 5: an fp16 image (BASELINE's input dtype, what
+// bench.py feeds) takes the same kernel with 4-byte loads and PPT = 4 (it ran the generic row kernel: 44 us against 32 for fp32).
+template <typename TS> struct Pair2;
+template <> struct Pair2<float> {
+    using T = float2;
+    static __device__ __forceinline__ float lo(T v) { return v.x; }
+    static __device__ __forceinline__ float hi(T v) { return v.y; }
+};
+template <> struct Pair2<half_t> {
+    using T = unsigned;
+    static __device__ __forceinline__ float lo(T v) { return (float)__builtin_bit_cast(half_t, (unsigned short)(v & 0xFFFFu)); }
+    static __device__ __forceinline__ float hi(T v) { return (float)__builtin_bit_cast(half_t, (unsigned short)(v >> 16)); }
+};
+
+template <typename TS, typename TD, int PPT>
+__global__ __launch_bounds__(256) void nchw3_to_nhwc_s2d2_kernel(const TS* __restrict__ src, TD* __restrict__ dst, int H, int W,
                                                                int Cpad, long pixels) {
+    using P2 = typename Pair2<TS>::T;
     constexpr int V = Chunk<TD>::N;
     const int H2 = H >> 1, W2 = W >> 1;
     const long HW = (long)H * W;
     const unsigned per_img = (unsigned)(H2 * W2);
     const long p0 = ((long)blockIdx.x * PPT) * 256 + threadIdx.x;
-    float2 t[PPT][3][2];
+    P2 t[PPT][3][2];
 #pragma unroll
     for (int q = 0; q < PPT; ++q) {
         const long p = p0 + 256 * q;
         const unsigned pu = p < pixels ? (unsigned)p : 0u;      // (pixels < 2^31: entry point)
         const unsigned n = pu / per_img, r = pu - n * per_img, h2 = r / (unsigned)W2, w2 = r - h2 * (unsigned)W2;
-        const float* sp = src + (long)n * 3 * HW + (long)(2 * h2) * W + 2 * w2;
+        const TS* sp = src + (long)n * 3 * HW + (long)(2 * h2) * W + 2 * w2;
 #pragma unroll
         for (int c = 0; c < 3; ++c)
 #pragma unroll
-            for (int ph = 0; ph < 2; ++ph) t[q][c][ph] = *reinterpret_cast<const float2*>(sp + c * HW + (long)ph * W);
+            for (int ph = 0; ph < 2; ++ph) t[q][c][ph] = *reinterpret_cast<const P2*>(sp + c * HW + (long)ph * W);
     }
 #pragma unroll
     for (int q = 0; q < PPT; ++q) {
@@ -168,8 +182,8 @@ __global__ __launch_bounds__(256) void nchw3_to_nhwc_s2d2_kernel(const float* __
         for (int c = 0; c < 3; ++c)
 #pragma unroll
             for (int ph = 0; ph < 2; ++ph) {
-                v16[(ph * 2 + 0) * 3 + c] = t[q][c][ph].x;
-                v16[(ph * 2 + 1) * 3 + c] = t[q][c][ph].y;
+                v16[(ph * 2 + 0) * 3 + c] = Pair2<TS>::lo(t[q][c][ph]);
+                v16[(ph * 2 + 1) * 3 + c] = Pair2<TS>::hi(t[q][c][ph]);
             }
         TD* dp = dst + p * Cpad;
 #pragma unroll
@@ -787,8 +801,15 @@ extern "C" int tlxmi_nchw_to_nhwc_s2d(const void* src, int sdt, void* dst, int d
         constexpr int PPT = 2;
         const long pixels = (long)N * (H / 2) * (W / 2);
         const dim3 g2((unsigned)((pixels + 256 * PPT - 1) / (256 * PPT))), b2(256);
-        if (ddt == TLXMI_F16) hipLaunchKernelGGL((nchw3_to_nhwc_s2d2_kernel<half_t, PPT>), g2, b2, 0, st, (const float*)src, (half_t*)dst, H, W, Cpad, pixels);
-        else hipLaunchKernelGGL((nchw3_to_nhwc_s2d2_kernel<float, PPT>), g2, b2, 0, st, (const float*)src, (float*)dst, H, W, Cpad, pixels);
+        if (ddt == TLXMI_F16) hipLaunchKernelGGL((nchw3_to_nhwc_s2d2_kernel<float, half_t, PPT>), g2, b2, 0, st, (const float*)src, (half_t*)dst, H, W, Cpad, pixels);
+        else hipLaunchKernelGGL((nchw3_to_nhwc_s2d2_kernel<float, float, PPT>), g2, b2, 0, st, (const float*)src, (float*)dst, H, W, Cpad, pixels);
+        return check_launch("nchw_to_nhwc_s2d");
+    }
+    if (sdt == TLXMI_F16 && ddt == TLXMI_F16 && b == 2 && C == 3 && Cpad == 16 && W % 2 == 0 && ((uintptr_t)src % 4) == 0 && (long)N * (H / 2) * (W / 2) < (1l << 31)) {
+        constexpr int PPT = 4;
+        const long pixels = (long)N * (H / 2) * (W / 2);
+        const dim3 g2((unsigned)((pixels + 256 * PPT - 1) / (256 * PPT))), b2(256);
+        hipLaunchKernelGGL((nchw3_to_nhwc_s2d2_kernel<half_t, half_t, PPT>), g2, b2, 0, st, (const half_t*)src, (half_t*)dst, H, W, Cpad, pixels);
         return check_launch("nchw_to_nhwc_s2d");
     }
     {
