@@ -103,6 +103,67 @@ def test_round4_entry_points_reject_bad_arguments_without_a_gpu():
     assert lib.tlxmi_patch_merge_layernorm(p, p, p, q, 9, 1, 4, 4, 16, f, None) == -1
 
 
+def test_round5_entry_points_reject_bad_arguments_without_a_gpu():
+    """The folded-LayerNorm trio, the Mlp seam, softmax_rows and the index NMS validate before any HIP call: null and misaligned
+    buffers, fp32, shapes outside the kernels, a partial-sum / row-table layout that does not match — each with its own code."""
+    from tlxcv_amd import _lib
+    lib = _lib.load()
+    buf = (ctypes.c_char * 8192)()
+    base = ctypes.addressof(buf)
+    base += (-base) % 16
+    p, q, r, t = (ctypes.c_void_p(base + 1024 * i) for i in range(4))
+    odd8, odd4 = ctypes.c_void_p(base + 8), ctypes.c_void_p(base + 4)
+    F16, F32, NONE, RELU, GELU = 0, 1, 0, 1, 6
+    err = lambda: lib.tlxmi_last_error()
+    # linear_stats(dtype, rows, K, Cout, x_ld, y_ld, x, w, bias, res, res_ld, y, partials, flags, stream)
+    assert lib.tlxmi_linear_stats(F16, 4096, 768, 768, 768, 768, None, q, None, None, 0, r, t, 0, None) == -1 and b"null" in err()
+    assert lib.tlxmi_linear_stats(F32, 4096, 768, 768, 768, 768, p, q, None, None, 0, r, t, 0, None) == -2 and b"fp16 only" in err()
+    assert lib.tlxmi_linear_stats(F16, 4096, 768, 768, 760, 768, p, q, None, None, 0, r, t, 0, None) == -1 and b"extent" in err()
+    assert lib.tlxmi_linear_stats(F16, 4096, 768, 100, 768, 104, p, q, None, None, 0, r, t, 0, None) == -2 and b"outside" in err()
+    assert lib.tlxmi_linear_stats(F16, 4096, 768, 768, 768, 768, p, q, None, None, 0, r, None, 0, None) == -1 and b"partials" in err()
+    assert lib.tlxmi_linear_stats(F16, 4096, 768, 768, 768, 768, p, q, None, None, 0, r, odd4, 0, None) == -1 and b"partials" in err()
+    assert lib.tlxmi_linear_stats(F16, 4096, 768, 768, 768, 768, p, q, None, t, 760, r, t, 0, None) == -1 and b"residual" in err()
+    assert lib.tlxmi_linear_stats(F16, 4096, 768, 768, 768, 768, p, odd8, None, None, 0, r, t, 0, None) == -3
+    # ln_finalize(partials, slots, rows, C, eps, rowab, stream)
+    assert lib.tlxmi_ln_finalize(p, 24, 4096, 760, 1e-5, q, None) == -1 and b"32 * slots" in err()
+    assert lib.tlxmi_ln_finalize(p, 24, 0, 768, 1e-5, q, None) == -1
+    assert lib.tlxmi_ln_finalize(None, 24, 4096, 768, 1e-5, q, None) == -1
+    assert lib.tlxmi_ln_finalize(p, 24, 4096, 768, 1e-5, odd8, None) == -3 and b"aligned" in err()
+    # linear_ln(dtype, rows, K, Cout, x_ld, y_ld, x, w, c1, c2, rowab, act, y, flags, stream)
+    assert lib.tlxmi_linear_ln(F16, 4096, 768, 2304, 768, 2304, p, q, r, r, None, NONE, t, 0, None) == -1 and b"rowab" in err()
+    assert lib.tlxmi_linear_ln(F16, 4096, 768, 2304, 768, 2304, p, q, r, r, odd8, NONE, t, 0, None) == -1 and b"rowab" in err()
+    assert lib.tlxmi_linear_ln(F16, 4096, 768, 2304, 768, 2304, p, q, r, r, r, RELU, t, 0, None) == -2 and b"activation" in err()
+    assert lib.tlxmi_linear_ln(F32, 4096, 768, 2304, 768, 2304, p, q, r, r, r, GELU, t, 0, None) == -2
+    assert lib.tlxmi_linear_ln_supported(F16, 50432, 768, 2304, GELU, 0) == 1 and lib.tlxmi_linear_ln_supported(F32, 50432, 768, 2304, NONE, 0) == 0
+    assert lib.tlxmi_linear_ln_supported(F16, 50432, 768, 2304, RELU, 0) == 0 and lib.tlxmi_linear_ln_supported(F16, 50432, 768, 100, NONE, 0) == 0
+    # mlp_seam(dtype, rows, K, hidden, N, x, x_ld, w1, b1, w2, b2, res, res_ld, out, out_ld, stream)
+    assert lib.tlxmi_mlp_seam_supported(F16, 128, 512, 128) == 1 and lib.tlxmi_mlp_seam_supported(F16, 256, 1024, 256) == 0
+    assert lib.tlxmi_mlp_seam_supported(F32, 128, 512, 128) == 0 and lib.tlxmi_mlp_seam_supported(F16, 128, 500, 128) == 0
+    assert lib.tlxmi_mlp_seam(F16, 6272, 128, 512, 128, None, 128, q, None, r, None, t, 128, t, 128, None) == -1 and b"null" in err()
+    assert lib.tlxmi_mlp_seam(F16, 6272, 256, 1024, 256, p, 256, q, None, r, None, t, 256, t, 256, None) == -2 and b"no kernel" in err()
+    assert lib.tlxmi_mlp_seam(F16, 6272, 128, 512, 128, p, 120, q, None, r, None, t, 128, t, 128, None) == -1 and b"extent" in err()
+    assert lib.tlxmi_mlp_seam(F16, 6272, 128, 512, 128, p, 128, q, None, r, None, odd8, 128, t, 128, None) == -3
+    # softmax_rows(x, y, dt, rows, C, x_ld, y_ld, stream)
+    assert lib.tlxmi_softmax_rows(None, q, F16, 8, 10, 10, 10, None) == -1
+    assert lib.tlxmi_softmax_rows(p, q, 5, 8, 10, 10, 10, None) == -1 and b"dtype" in err()
+    assert lib.tlxmi_softmax_rows(p, q, F16, 8, 10, 8, 10, None) == -1
+    # attention_windows(desc, qkv, comb, out, H, W, ws, shift, stream)
+    d = _lib.AttnDesc(dtype=F16, B=2 * 64, Ntok=49, heads=4, hd=32, scale=0.17, nW=64)
+    assert lib.tlxmi_attention_windows(ctypes.byref(d), p, None, r, 56, 56, 7, 3, None) == -1 and b"null" in err()
+    assert lib.tlxmi_attention_windows(ctypes.byref(d), p, q, r, 56, 55, 7, 3, None) == -1 and b"windows of 7" in err()
+    assert lib.tlxmi_attention_windows(ctypes.byref(d), p, q, r, 56, 56, 7, 7, None) == -1                  # shift < ws
+    d.nW = 16
+    assert lib.tlxmi_attention_windows(ctypes.byref(d), p, q, r, 56, 56, 7, 3, None) == -1 and b"nW = 16" in err()
+    d.nW, d.hd = 64, 48
+    assert lib.tlxmi_attention_windows(ctypes.byref(d), p, q, r, 56, 56, 7, 3, None) == -2
+    # patch_embed4_pos(x, xdt, w, bias, gamma, beta, pos, y, N, H, W, D, eps, stream)
+    assert lib.tlxmi_patch_embed4_pos(p, F16, q, None, None, None, None, r, 1, 32, 32, 128, 1e-5, None) == -1 and b"position" in err()
+    # multiclass_nms_index(boxes, scores, N, M, C, thr, nms_thr, keep_top_k, workspace, detections, counts, keep_index, stream)
+    assert lib.tlxmi_multiclass_nms_index(p, q, 1, 100, 3, 0.1, 0.5, 10, r, t, t, None, None) == -1 and b"keep_index" in err()
+    assert lib.tlxmi_multiclass_nms_index(p, q, 1, 100, 3, 0.1, 0.5, 0, r, t, t, t, None) == -1
+    assert lib.tlxmi_multiclass_nms_index(p, q, 1, 70000, 3, 0.1, 0.5, 10, r, t, t, t, None) == -2
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from tlxcv_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)
