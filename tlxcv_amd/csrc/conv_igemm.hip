@@ -1214,6 +1214,22 @@ static int fill_ln_gemm(Gemm256Args& g, const char* who, int dtype, int64_t rows
 static int ln_plan_cus(unsigned flags) {
     return (flags & TLXMI_PLAN_SHARED_HALF) ? (num_cus() / 2 > 0 ? num_cus() / 2 : 1) : num_cus();
 }
+// Whether a folded GEMM the persistent kernel could take goes to the one-tile kernel's half-height tiles instead: fewer 256 x 256 tiles
+// than half the CUs (Swin-B stage 3 fc2: 49 x 2; stage 4 proj / fc2: 13 x 4; ViT-B/16 at batch 64: 25 x 3).  Measured on the graph replay:
+// Swin-B batch 128 -0.4 %, ViT-B/16 batch 64 -3.5 % (every tile of the persistent kernel half-height instead, TLXMI_HALFTAIL=2: +3.5 %).
+// TLXMI_LN_SMALL_PP (tuning flavour): 0 = off.
+static bool ln_small_on_pp(const Gemm256Args& g) {
+    const long t256 = (long)((g.M + 255) / 256) * ((g.Cout + 255) / 256);
+    return tune_int("TLXMI_LN_SMALL_PP", 1) != 0 && 2 * t256 <= num_cus() && g.M > 128;
+}
+// The one-tile-per-workgroup form of a folded GEMM: 256 x 256 tiles, or 128 x 256 when the full tiles would leave half the CUs
+// without one (then twice as many half-height tiles still fit one round).  TLXMI_LN_PP128 (tuning flavour): 0 never, 1 always.
+static int launch_ln_pp(int dtype, const Gemm256Args& g, hipStream_t st) {
+    const long t256 = (long)((g.M + 255) / 256) * ((g.Cout + 255) / 256);
+    const long knob = tune_int("TLXMI_LN_PP128", -1);
+    const bool half_height = knob >= 0 ? knob != 0 : (2 * t256 <= num_cus() && g.M > 128);
+    return half_height ? launch_gemm_pp128(dtype, g, st) : launch_gemm_pp(dtype, g, st);
+}
 }  // namespace tlxmi
 
 extern "C" int tlxmi_linear_ln_supported(int dtype, int64_t rows, int K, int Cout, int act, int with_res) {
@@ -1241,8 +1257,8 @@ extern "C" int tlxmi_linear_stats(int dtype, int64_t rows, int K, int Cout, int 
     g.stats_out = partials;
     g.flags = flags & (TLXMI_PLAN_SHARED_HALF | TLXMI_PLAN_SHARED_FULL);
     // the persistent kernel where it applies; a residual with a short K (its residual steps need 11 K tiles: Swin-B stage 3 proj,
-    // K = 512) on the one-tile-per-workgroup form of the same K loop
-    if (int rc = gemm_stream_ok(dtype, g) ? launch_gemm_stream(dtype, g, as_stream(stream), ln_plan_cus(flags)) : launch_gemm_pp(dtype, g, as_stream(stream))) return rc;
+    // K = 512) and launches of few tiles (ln_small_on_pp) on the one-tile-per-workgroup form of the same K loop
+    if (int rc = (gemm_stream_ok(dtype, g) && !ln_small_on_pp(g)) ? launch_gemm_stream(dtype, g, as_stream(stream), ln_plan_cus(flags)) : launch_ln_pp(dtype, g, as_stream(stream))) return rc;
     return check_launch("linear_stats");
 }
 
@@ -1259,8 +1275,8 @@ extern "C" int tlxmi_linear_ln(int dtype, int64_t rows, int K, int Cout, int x_l
     g.act = act;
     g.flags = flags & (TLXMI_PLAN_SHARED_HALF | TLXMI_PLAN_SHARED_FULL);
     // TLXMI_LN_GELU_PP (tuning flavour): 1 = GELU layers on the one-tile-per-workgroup kernel (its epilogue is not squeezed between MFMAs)
-    const bool on_pp = !gemm_stream_ok(dtype, g) || (act == TLXMI_ACT_GELU && tune_int("TLXMI_LN_GELU_PP", 0));
-    if (int rc = on_pp ? launch_gemm_pp(dtype, g, as_stream(stream)) : launch_gemm_stream(dtype, g, as_stream(stream), ln_plan_cus(flags))) return rc;
+    const bool on_pp = !gemm_stream_ok(dtype, g) || ln_small_on_pp(g) || (act == TLXMI_ACT_GELU && tune_int("TLXMI_LN_GELU_PP", 0));
+    if (int rc = on_pp ? launch_ln_pp(dtype, g, as_stream(stream)) : launch_gemm_stream(dtype, g, as_stream(stream), ln_plan_cus(flags))) return rc;
     return check_launch("linear_ln");
 }
 

@@ -522,6 +522,10 @@ int launch_gemm_pp128(int dtype, const Gemm256Args& a, hipStream_t st) {
         if (dtype == TLXMI_F16) return launch_pp_t<half_t, 1, 2, true>(a, st);
         return launch_pp_t<float, 1, 2, true>(a, st);
     }
+    if (a.rowstats || a.stats_out) {      // LayerNorm fold on half-height tiles (few row tiles: Swin-B stage 3 proj, 49 x 2 tiles of 256 x 256)
+        if (dtype != TLXMI_F16 || (a.Cout & 31) || a.kslices > 1) return fail(TLXMI_ERR_UNSUPPORTED, "gemm_pp: the LayerNorm fold is fp16, Cout %% 32 == 0");
+        return launch_pp_t<half_t, 1, 2, false, true>(a, st);
+    }
     if (dtype == TLXMI_F16) return launch_pp_t<half_t, 1, 2, false>(a, st);
     return launch_pp_t<float, 1, 2, false>(a, st);
 }
