@@ -117,11 +117,13 @@ class BottleneckBlock(nn.Module):
         # Where the fused launch pays (tools/small_batch.py, graph replay, one box): a seam runs its 64-channel steps one after
         # the other, so with few pixels it is a chain of latencies — batch 1 0.91 ms with all seams, 0.78 without the 14 x 14
         # ones, 0.74 without any; from 16 images the 56 x 56 / 28 x 28 seams win (batch 32: 1.09 vs 1.14 ms), the 14 x 14 ones
-        # (1 MB of filters per 128 pixels) only from ~96 images, or inside a two-stream forward (batch 128 = 2 x 64: 2.12 vs 2.16).
+        # (1 MB of filters per 128 pixels) only from ~96 images a launch.
         n_img = out.shape[0]
         # (round 5, tools/batch_table.py: at 512 images = 2 x 256 per launch the 14 x 14 seams LOSE 2.3 % to two persistent GEMM launches —
         #  their 1 MB of filters per 128 pixels is re-streamed 196 times per CU; at 2 x 128 they win 1.7 %: fused up to 192 images a launch)
-        if n_img < 12 or (c3.in_channels >= 256 and ((n_img < 96 and not E.in_halves()) or n_img > 192)):
+        #  end of round 5, same table: inside a two-stream forward of 96 / 128 images (48 / 64 a launch) they lose 1.1 / 1.9 % as well — 96 ... 192 images
+        #  a launch whatever the stream arrangement)
+        if n_img < 12 or (c3.in_channels >= 256 and (n_img < 96 or n_img > 192)):
             return None
         pk3 = c3._cached("pk", lambda: E.PackedFilter(c3.filters, dt))
         pk1 = c1._cached("pk", lambda: E.PackedFilter(c1.filters, dt))
@@ -204,7 +206,9 @@ class ResNet(nn.Module):
                                 batch_norm=batch_norm, data_format=data_format))
         return nn.Sequential(layers)
 
-    @E.two_streams(128, plan="half")
+    # tools/two_stream_threshold.py (round 5, ResNet-50; one stream / halves planned for half the CUs): batch 64 1.445 / 1.431 ms,
+    # 80 1.531 / 1.516, 96 1.906 / 1.772, 128 2.153 / 2.037, 256 3.670 / 3.353
+    @E.two_streams(96, plan="half")
     def forward(self, x):
         if (self.data_format == 'channels_first' and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
                 and not x.permute(0, 2, 3, 1).is_contiguous()):

@@ -384,7 +384,9 @@ class SwinTransformer(nn.Module):
         x = self.norm(x)                               # :608
         return E.global_avgpool(x)                     # mean over tokens == avgpool(x^T) + flatten, :609-610
 
-    @E.two_streams(128, plan="full")
+    # tools/two_stream_threshold.py (round 5, profiles/r05/two_stream_threshold.txt; one stream / halves with no plan flag / planned for the
+    # device): batch 16 2.41 / 2.36 / 3.12 ms, 32 3.06 / 2.89 / 3.04, 64 4.18 / 3.87 / 3.99, 96 5.48 / 5.27 / 5.32, 128 6.80 / 6.53 / 6.56
+    @E.two_streams(32, plan=None)
     def forward(self, x):
         x = self.forward_features(x)
         return self.head.run(x) if isinstance(self.head, nn.Linear) else x

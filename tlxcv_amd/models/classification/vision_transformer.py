@@ -278,7 +278,10 @@ class VisionTransformer(nn.Module):
     # the tiles planned for half the CUs, batch 128 6.14 -> 5.56 ms and batch 64 3.45 -> 3.35 ms with the device's own plan
     # round 5 (tools/plan_modes.py, with the LayerNorms folded into the GEMMs): batch 256 one stream 10.18 ms, halves planned for the device 9.85, for
     # half the CUs 10.14 (round 3 had it the other way round: the stand-alone LayerNorm launches filled the gaps the half plan left); batch 128: 5.69 / 5.17 / 5.77
-    @E.two_streams(64, plan="full")
+    # end of round 5 (tools/two_stream_threshold.py, profiles/r05/two_stream_threshold.txt; one stream / halves with no plan flag / planned
+    # for the device): batch 16 1.35 / 1.37 / 1.83 ms, 32 2.07 / 1.90 / 1.92, 64 2.90 / 2.88 / 2.86, 128 5.36 / 4.97 / 5.00, 256 9.75 / 9.70 / 9.69
+    # -> halves from 32 images, each launch planned as if alone
+    @E.two_streams(32, plan=None)
     def forward(self, x):
         x = self.forward_features(x)
         if isinstance(self.head, nn.Linear):

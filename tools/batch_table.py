@@ -1,7 +1,7 @@
-"""Throughput against batch: ResNet-50 / ViT-B/16 / Swin-B at batch 1, 8, 32, 64, 128, 256, 512 on the hipGraph replay, with the
+"""Throughput against batch: ResNet-50 / ViT-B/16 / Swin-B at batch 1, 8, 32, 64, 96, 128, 256, 512 on the hipGraph replay, with the
 dispatch switch points of each batch marked AND measured: every host-side switch that changes at some batch is toggled on the same graph
-replay — two_streams (forwards of >= 128 / 64 / 128 images), the bottleneck seams (>= 12 images per launch; the 14 x 14 ones >= 96 or inside a
-two-stream forward), split-K (classifier head <= 512 rows, 7 x 7 convs with few tiles), the folded LayerNorm (>= 2048 token rows per launch).
+replay — two_streams (forwards of >= 96 / 32 / 32 images), the bottleneck seams (>= 12 images per launch; the 14 x 14 ones from 96 to 192 images
+per launch), split-K (classifier head <= 512 rows, 7 x 7 convs with few tiles), the folded LayerNorm (>= 2048 token rows per launch).
 Output -> profiles/<round>/batch_table.txt.   usage: batch_table.py [models] [batches]"""
 import os
 import sys
@@ -22,7 +22,7 @@ ARMS = {"resnet50": {"one stream": ("two_streams", 0), "no seams": ("seams", 0),
         "vit_b16": {"one stream": ("two_streams", 0), "LayerNorm launches": ("lnfold", 0)},
         "swin_b": {"one stream": ("two_streams", 0), "LayerNorm / window passes": ("lnfold", 0)}}
 wls = sys.argv[1].split(",") if len(sys.argv) > 1 else list(CT)
-batches = [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else "1,8,32,64,128,256,512".split(","))]
+batches = [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else "1,8,32,64,96,128,256,512".split(","))]
 for wl in wls:
     m = getattr(models, CT[wl])()
     m.load_dict(seeded.fill(seeded.shapes_of(m), 1))
