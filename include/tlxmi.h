@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-/* 101 (round 5): + tlxmi_linear_stats / tlxmi_ln_finalize / tlxmi_linear_ln / tlxmi_linear_ln_supported, tlxmi_attention_windows,
+/* 101 (round 5): + tlxmi_linear_stats / tlxmi_linear_ln / tlxmi_linear_ln_supported, tlxmi_attention_windows,
  * tlxmi_mlp_seam(_supported), tlxmi_softmax_rows, tlxmi_patch_embed4_pos, tlxmi_multiclass_nms_index.  100 (round 4) had removed
  * tlxmi_row_stats / tlxmi_linear_ln(11 args) / tlxmi_layernorm_linear of the round-3 header without a version step: a caller built
  * against that header must check tlxmi_version() >= 101 and use the signatures below. */
@@ -411,23 +411,24 @@ int tlxmi_mlp_seam(int dtype, int64_t rows, int K, int hidden, int N, const void
  * norm2 -> mlp.fc1; swin_transformer.py:310-337).  The Linear that PRODUCES the residual stream (proj, fc2, the patch embedding)
  * also emits the row statistics of its output, the Linear that CONSUMES a LayerNorm applies it in its epilogue; the normalised
  * activations are never written or read:
- *   tlxmi_linear_stats   y[m][n] = sum_k x[m][k] W[n][k] + bias[n] (+ res[m][n]);  partials[n / 32][m] = (sum, sum of squares) of
- *                        y[m][32 s .. 32 s + 31] — `partials` holds (Cout / 32) * rows * 2 floats
- *   tlxmi_ln_finalize    rowab[m] = (rstd, -mean * rstd) from the `slots` = C / 32 partial sums of row m (biased variance, eps)
- *   tlxmi_linear_ln      y[m][n] = act(rowab[m][0] * sum_k x[m][k] Wg[n][k] + rowab[m][1] * c1[n] + c2[n]) on the RAW rows x, with
- *                        Wg = W * gamma packed by tlxmi_pack_filter (1 x 1), c1[n] = sum_k Wg[n][k] (of the fp16 values as packed),
- *                        c2[n] = bias[n] + sum_k W[n][k] * beta[k];  act: TLXMI_ACT_NONE or TLXMI_ACT_GELU
- * All three run on the 256 x 256 GEMM kernels (the persistent one; a residual with K < 704 on its one-tile-per-workgroup form): fp16,
- * Cout % 32 == 0, Cout >= 256, K >= 128;
+ *   tlxmi_linear_stats   y[m][n] = sum_k x[m][k] W[n][k] + bias[n] (+ res[m][n]);  partials[p][m] = (sum, sum of squares) of
+ *                        y[m][256 p .. 256 p + 255] (the fp32 values before rounding) — ceil(Cout / 256) * rows * 2 floats, 16-byte aligned
+ *   tlxmi_linear_ln      per row m: mean = sum_p partials[p][m][0] / K, var = sum_p partials[p][m][1] / K - mean^2 (biased, as
+ *                        nn.LayerNorm), rstd = 1 / sqrt(var + eps);  y[m][n] = act(rstd * sum_k x[m][k] Wg[n][k] - mean * rstd * c1[n]
+ *                        + c2[n]) on the RAW rows x, with Wg = W * gamma packed by tlxmi_pack_filter (1 x 1), c1[n] = sum_k Wg[n][k]
+ *                        (of the fp16 values as packed), c2[n] = bias[n] + sum_k W[n][k] * beta[k];  act: TLXMI_ACT_NONE or
+ *                        TLXMI_ACT_GELU;  `partials`: the ceil(K / 256) <= 4 planes a tlxmi_linear_stats launch with Cout = K left for
+ *                        these rows — no launch in between
+ * Both run on the 256 x 256 GEMM kernels (the persistent one; a residual with K < 704 and launches of few tiles on its
+ * one-tile-per-workgroup form): fp16, Cout % 32 == 0, Cout >= 256, K >= 128, K <= 1024 for the consumer;
  * tlxmi_linear_ln_supported(dtype, rows, K, Cout, act, with_res) answers 1 when the shape is taken, otherwise the calls return
  * TLXMI_ERR_UNSUPPORTED and the caller keeps tlxmi_layernorm + tlxmi_conv2d.  `flags`: TLXMI_PLAN_SHARED_* or 0.
  * ---------------------------------------------------------------------------------------- */
 int tlxmi_linear_ln_supported(int dtype, int64_t rows, int K, int Cout, int act, int with_res);
 int tlxmi_linear_stats(int dtype, int64_t rows, int K, int Cout, int x_ld, int y_ld, const void* x, const void* w_packed,
                        const float* bias, const void* res, int res_ld, void* y, float* partials, unsigned flags, void* stream);
-int tlxmi_ln_finalize(const float* partials, int slots, int64_t rows, int C, float eps, float* rowab, void* stream);
 int tlxmi_linear_ln(int dtype, int64_t rows, int K, int Cout, int x_ld, int y_ld, const void* x, const void* w_packed,
-                    const float* c1, const float* c2, const float* rowab, int act, void* y, unsigned flags, void* stream);
+                    const float* c1, const float* c2, const float* partials, float eps, int act, void* y, unsigned flags, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused multi-head self attention on a packed qkv matrix (the output of the qkv Linear):

@@ -124,16 +124,14 @@ def test_round5_entry_points_reject_bad_arguments_without_a_gpu():
     assert lib.tlxmi_linear_stats(F16, 4096, 768, 768, 768, 768, p, q, None, None, 0, r, odd4, 0, None) == -1 and b"partials" in err()
     assert lib.tlxmi_linear_stats(F16, 4096, 768, 768, 768, 768, p, q, None, t, 760, r, t, 0, None) == -1 and b"residual" in err()
     assert lib.tlxmi_linear_stats(F16, 4096, 768, 768, 768, 768, p, odd8, None, None, 0, r, t, 0, None) == -3
-    # ln_finalize(partials, slots, rows, C, eps, rowab, stream)
-    assert lib.tlxmi_ln_finalize(p, 24, 4096, 760, 1e-5, q, None) == -1 and b"32 * slots" in err()
-    assert lib.tlxmi_ln_finalize(p, 24, 0, 768, 1e-5, q, None) == -1
-    assert lib.tlxmi_ln_finalize(None, 24, 4096, 768, 1e-5, q, None) == -1
-    assert lib.tlxmi_ln_finalize(p, 24, 4096, 768, 1e-5, odd8, None) == -3 and b"aligned" in err()
-    # linear_ln(dtype, rows, K, Cout, x_ld, y_ld, x, w, c1, c2, rowab, act, y, flags, stream)
-    assert lib.tlxmi_linear_ln(F16, 4096, 768, 2304, 768, 2304, p, q, r, r, None, NONE, t, 0, None) == -1 and b"rowab" in err()
-    assert lib.tlxmi_linear_ln(F16, 4096, 768, 2304, 768, 2304, p, q, r, r, odd8, NONE, t, 0, None) == -1 and b"rowab" in err()
-    assert lib.tlxmi_linear_ln(F16, 4096, 768, 2304, 768, 2304, p, q, r, r, r, RELU, t, 0, None) == -2 and b"activation" in err()
-    assert lib.tlxmi_linear_ln(F32, 4096, 768, 2304, 768, 2304, p, q, r, r, r, GELU, t, 0, None) == -2
+    # linear_ln(dtype, rows, K, Cout, x_ld, y_ld, x, w, c1, c2, partials, eps, act, y, flags, stream)
+    assert lib.tlxmi_linear_ln(F16, 4096, 768, 2304, 768, 2304, p, q, r, r, None, 1e-5, NONE, t, 0, None) == -1 and b"partials" in err()
+    assert lib.tlxmi_linear_ln(F16, 4096, 768, 2304, 768, 2304, p, q, r, r, odd8, 1e-5, NONE, t, 0, None) == -1 and b"partials" in err()
+    assert lib.tlxmi_linear_ln(F16, 4096, 768, 2304, 768, 2304, p, q, r, r, r, -1.0, NONE, t, 0, None) == -1 and b"eps" in err()
+    assert lib.tlxmi_linear_ln(F16, 4096, 768, 2304, 768, 2304, p, q, r, r, r, 1e-5, RELU, t, 0, None) == -2 and b"activation" in err()
+    assert lib.tlxmi_linear_ln(F32, 4096, 768, 2304, 768, 2304, p, q, r, r, r, 1e-5, GELU, t, 0, None) == -2
+    assert lib.tlxmi_linear_ln(F16, 4096, 1536, 4608, 1536, 4608, p, q, r, r, r, 1e-5, NONE, t, 0, None) == -2 and b"planes" in err()
+    assert lib.tlxmi_linear_ln_supported(F16, 50432, 1536, 4608, NONE, 0) == 0 and lib.tlxmi_linear_ln_supported(F16, 50432, 3072, 768, NONE, 1) == 1
     assert lib.tlxmi_linear_ln_supported(F16, 50432, 768, 2304, GELU, 0) == 1 and lib.tlxmi_linear_ln_supported(F32, 50432, 768, 2304, NONE, 0) == 0
     assert lib.tlxmi_linear_ln_supported(F16, 50432, 768, 2304, RELU, 0) == 0 and lib.tlxmi_linear_ln_supported(F16, 50432, 768, 100, NONE, 0) == 0
     # mlp_seam(dtype, rows, K, hidden, N, x, x_ld, w1, b1, w2, b2, res, res_ld, out, out_ld, stream)

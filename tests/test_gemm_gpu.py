@@ -243,7 +243,7 @@ def test_linear_splitk(dev, dtype, shape, act, res):
         torch.testing.assert_close(got.float().cpu(), plain.float().cpu(), atol=1e-3, rtol=1e-3)
 
 
-# ---- LayerNorm folded AROUND the Linear layers (round 5: tlxmi_linear_stats -> tlxmi_ln_finalize -> tlxmi_linear_ln; reference
+# ---- LayerNorm folded AROUND the Linear layers (round 5: tlxmi_linear_stats -> tlxmi_linear_ln, no launch in between; reference
 # vision_transformer.py:172-175: x = x + attn(norm1(x)); x = x + mlp(norm2(x))).  The producer's outputs must equal the plain Linear's
 # bit for bit, its row statistics the LayerNorm's, and the consumer the oracle's Linear(LayerNorm(x)) — on ragged row counts, several
 # tiles per workgroup, the half-height tail tiles, a planned half device, rows far from zero mean, gamma / beta / bias present.
@@ -275,9 +275,8 @@ def test_layernorm_folded_around_linears(dev, case, plan):
         plain = E.linear(xd, pk, b.to(dev), res=rd)
         y, part = E.linear_stats(xd, pk, b.to(dev), res=rd)
         y2, part2 = E.linear_stats(xd, pk, b.to(dev), res=rd)
-        rowab = E.ln_finalize(part, D, eps)
         prep = E.LinearLN(w2.to(dev), b2.to(dev), gamma.to(dev), beta.to(dev), torch.float16)
-        outs = {act: E.linear_ln(y, prep, rowab, act) for act in (E.ACT_NONE, E.ACT_GELU)}
+        outs = {act: E.linear_ln(y, prep, part, eps, act) for act in (E.ACT_NONE, E.ACT_GELU)}
         # without a residual (the patch-embedding producer of a model whose position table is folded elsewhere)
         y0, part0 = E.linear_stats(xd, pk, b.to(dev))
     torch.cuda.synchronize()
@@ -286,20 +285,16 @@ def test_layernorm_folded_around_linears(dev, case, plan):
     torch.testing.assert_close(y.float(), plain.float(), atol=4e-3, rtol=4e-3)
     torch.testing.assert_close(y.float().cpu(), y_ref, **tol(torch.float16))
     torch.testing.assert_close(y0.float().cpu(), x @ w.t() + b, **tol(torch.float16))
-    # partial sums: (sum, sum of squares) of the fp32 values before the store's rounding, per 32-channel slot
-    slots = y_ref.view(M, D // 32, 32)
-    want_s, want_q = slots.sum(-1).t().contiguous(), (slots * slots).sum(-1).t().contiguous()
+    # row statistics: (sum, sum of squares) of the fp32 values before the store's rounding, per 256-channel tile column
+    assert part.shape == (D // 256, M, 2) and part0.shape == part.shape
+    planes = y_ref.view(M, D // 256, 256)
+    want_s, want_q = planes.sum(-1).t().contiguous(), (planes * planes).sum(-1).t().contiguous()
     sc = float(y_ref.abs().max())
-    torch.testing.assert_close(part[..., 0].cpu(), want_s, atol=2e-3 * sc, rtol=2e-3)
-    torch.testing.assert_close(part[..., 1].cpu(), want_q, atol=2e-3 * sc * sc, rtol=4e-3)
-    s0 = (x @ w.t() + b).view(M, D // 32, 32)
-    torch.testing.assert_close(part0[..., 0].cpu(), s0.sum(-1).t().contiguous(), atol=2e-3 * sc, rtol=2e-3)
-    # row affine of the LayerNorm
+    torch.testing.assert_close(part[..., 0].cpu(), want_s, atol=4e-3 * sc, rtol=2e-3)
+    torch.testing.assert_close(part[..., 1].cpu(), want_q, atol=4e-3 * sc * sc, rtol=4e-3)
+    s0 = (x @ w.t() + b).view(M, D // 256, 256)
+    torch.testing.assert_close(part0[..., 0].cpu(), s0.sum(-1).t().contiguous(), atol=4e-3 * sc, rtol=2e-3)
     yf = y.float().cpu()
-    mean, var = yf.mean(1), yf.var(1, unbiased=False)
-    rstd = 1.0 / torch.sqrt(var + eps)
-    torch.testing.assert_close(rowab[:, 0].cpu(), rstd, atol=0, rtol=2e-3)
-    torch.testing.assert_close(rowab[:, 1].cpu(), -mean * rstd, atol=3e-3, rtol=2e-3)
     # consumer: Linear(LayerNorm(y)) of the oracle on the stored fp16 rows
     ln = OF.layernorm({"n.gamma": gamma, "n.beta": beta}, "n", yf, eps)
     for act, got in outs.items():
@@ -331,52 +326,73 @@ def _load():
     return _lib.load()
 
 
-@pytest.mark.parametrize("C", [256, 512, 768, 1024, 2048, 4096])
-def test_ln_finalize_every_width(dev, C):
-    """tlxmi_ln_finalize on its own: partial (sum, sum of squares) per 32-channel slot -> (rstd, -mean * rstd); the register-resident forms
-    (<= 16 / <= 32 slots) and the two-pass form for wider rows, rows with a mean far from zero, against torch on the same values."""
+@pytest.mark.parametrize("C", [256, 512, 768, 1024])
+def test_linear_ln_row_statistics_envelope(dev, C):
+    """The consumer's own mean / rstd (from 1 .. 4 planes of (sum, sum of squares)): rows whose mean is 50 sigma away from zero, rows of
+    tiny and of large variance, a ragged row count — against Linear(LayerNorm(x)) of the oracle in float64 on the same fp16 rows.
+    (sum, sum of squares) in fp32 carry the variance to about 1e-7 * (1 + mean^2 / var) relative: 2.5e-4 here — the format's limit.)"""
     rng = np.random.default_rng(C)
-    rows = 1000 + 37
+    rows, N = 2304 + 37, 512
     x = rnd(rng, (rows, C))
     x[3] += 50.0
-    x[rows - 1] = x[rows - 1] * 0.1 - 5.0          # |mean| = 50 sigma.  (sum, sum of squares) in fp32 carry the variance to about
-    xs = x.view(rows, C // 32, 32)                 # 1e-7 * (1 + mean^2 / var) relative: 2.5e-4 here, the format's limit, not the kernel's
-    part = torch.stack([xs.sum(-1), (xs * xs).sum(-1)], -1).permute(1, 0, 2).contiguous().to(dev)
+    x[rows - 1] = x[rows - 1] * 0.1 - 5.0
+    x[7] *= 1e-2
+    x[11] *= 30.0
+    x = q16(x)
+    planes = x.double().view(rows, C // 256, 256)
+    part = torch.stack([planes.sum(-1), (planes * planes).sum(-1)], -1).permute(1, 0, 2).contiguous().float().to(dev)
+    w = rnd(rng, (N, C), (1.0 / C) ** 0.5)
+    b = rnd(rng, (N,), 0.2)
+    gamma = torch.from_numpy(rng.uniform(0.5, 1.5, C).astype(np.float32))
+    beta = rnd(rng, (C,), 0.3)
     eps = 1e-5
-    rowab = E.ln_finalize(part, C, eps).cpu()
-    rstd = 1.0 / torch.sqrt(x.double().var(1, unbiased=False) + eps)
-    torch.testing.assert_close(rowab[:, 0].double(), rstd, atol=0, rtol=1e-3)
-    torch.testing.assert_close(rowab[:, 1].double(), -x.double().mean(1) * rstd, atol=1e-4, rtol=1e-3)
+    prep = E.LinearLN(w.to(dev), b.to(dev), gamma.to(dev), beta.to(dev), torch.float16)
+    got = E.linear_ln(x.half().to(dev), prep, part, eps).float().cpu()
+    xd = x.double()
+    ln = (xd - xd.mean(1, keepdim=True)) / torch.sqrt(xd.var(1, unbiased=False, keepdim=True) + eps) * gamma.double() + beta.double()
+    want = (ln @ w.double().t() + b.double()).float()
+    torch.testing.assert_close(got, want, atol=8e-3, rtol=8e-3)
+    with pytest.raises(RuntimeError, match="statistics of shape"):
+        E.linear_ln(x.half().to(dev), prep, part[:, :-1].contiguous(), eps)
 
 
 @pytest.mark.parametrize("shape", [(2304, 768, 2304), (2304, 768, 256), (27648, 768, 2304), (2304, 768, 3072), (12544 + 100, 512, 1536)],
                          ids=lambda s: "x".join(map(str, s)))
 @pytest.mark.parametrize("act", [E.ACT_NONE, E.ACT_GELU], ids=["none", "gelu"])
 def test_linear_ln_row_and_channel_tables_exact(dev, shape, act):
-    """The regression test of the round-5 fault in gemm_stream's ROWAFF epilogue: with a = 0, b = 1 the consumer's output is
-    act(c1[n] + c2[n]) whatever x is — small integers, exact in fp16 — so ANY wrong read of the row table (a, b) or of the channel
-    tables (c1, c2) shows as a wrong integer.  (The first form read (a, b) of a sub-tile by one ds_read_b64 right in front of its
-    use inside the MFMA segment: sub-tile 1 of the lower half tile came back with b = 0 in lanes 48 - 63 for single elements, on
-    every launch, and only there — 36 of 2304 columns in 32 of every 256 rows; the shipped form fetches the four pairs of a half
-    tile in the load segment by one asm block.)  One and several tiles per workgroup, the half-height tail, both activations."""
+    """The regression test of the round-5 fault in gemm_stream's ROWAFF epilogue: with x = 0 and row statistics that make (a, b) = (1, 1)
+    exactly (mean -1, variance 1, eps 0, spread over the planes) the consumer's output is act(c1[n] + c2[n]) — small integers, exact
+    in fp16 — so ANY wrong read of a row's (a, b), of a plane, or of the channel tables (c1, c2) shows as a wrong integer.  (The
+    first form read (a, b) of a sub-tile by one ds_read_b64 right in front of its use inside the MFMA segment: sub-tile 1 of the lower
+    half tile came back with b = 0 in lanes 48 - 63 for single elements, on every launch, and only there — 36 of 2304 columns in 32
+    of every 256 rows; the shipped form fetches the four pairs of a half tile in the load segment by one asm block.)  One and several
+    tiles per workgroup, the half-height tail, both activations."""
     M, K, N = shape
+    T = K // 256
     rng = np.random.default_rng(M + N)
-    x = rnd(rng, (M, K)).half().to(dev)
     w = rnd(rng, (N, K), (1.0 / K) ** 0.5)
     prep = E.LinearLN(w.to(dev), None, torch.ones(K, device=dev), torch.zeros(K, device=dev), torch.float16)
     prep.c1 = (torch.arange(N, device=dev) % 500 + 1).float()
     prep.c2 = torch.full((N,), -7.0, device=dev)
-    rowab = torch.stack([torch.zeros(M, device=dev), torch.ones(M, device=dev)], 1).contiguous()
+    zeros = torch.zeros((M, K), dtype=torch.float16, device=dev)
+    part = torch.empty((T, M, 2), device=dev)
+    part[..., 0] = -K / T                      # mean -1
+    part[..., 1] = 2.0 * K / T                 # E[x^2] = 2 -> variance 1 -> rstd 1, b = -mean * rstd = 1
     want = prep.c1 - 7.0
     if act == E.ACT_GELU:
         want = torch.nn.functional.gelu(want)
     for plan in (None, "half"):
         with E.shared_plan(plan):
-            z = E.linear_ln(x, prep, rowab, act).float()
+            z = E.linear_ln(zeros, prep, part, 0.0, act).float()
         bad = torch.nonzero((z - want[None]).abs() > (0 if act == E.ACT_NONE else 2e-3 * (1 + want.abs().max())))
         assert bad.shape[0] == 0, f"plan {plan}: {bad.shape[0]} wrong elements, first {bad[:6].tolist()}, rows mod 256 {sorted(set((bad[:, 0] % 256).tolist()))[:16]}"
-    # and the row side: a = row pattern, b = 0, weights = identity-free check through x = const: out[m][n] = a[m] * (sum_k x W') + c2
-    rowab2 = torch.stack([(torch.arange(M, device=dev) % 13).float(), torch.zeros(M, device=dev)], 1).contiguous()
-    z0 = E.linear_ln(x, prep, torch.stack([torch.ones(M, device=dev), torch.zeros(M, device=dev)], 1).contiguous(), E.ACT_NONE).float()
-    z2 = E.linear_ln(x, prep, rowab2, E.ACT_NONE).float()
-    torch.testing.assert_close(z2 + 7.0, (z0 + 7.0) * rowab2[:, :1], atol=8e-2, rtol=5e-3)      # (both sides rounded to fp16 at |z| up to ~40)
+    # and the row side: mean 0, rstd = a row pattern r[m] (variance 1 / r^2, only the LAST plane non-zero): out[m][n] = r[m] * (x W'^T)[m][n] + c2
+    x = rnd(rng, (M, K)).half().to(dev)
+    r = (torch.arange(M, device=dev) % 13 + 1).float()
+    one = torch.zeros((T, M, 2), device=dev)
+    one[T - 1, :, 1] = K
+    pat = torch.zeros((T, M, 2), device=dev)
+    pat[T - 1, :, 1] = K / (r * r)
+    z0 = E.linear_ln(x, prep, one, 0.0, E.ACT_NONE).float()
+    z2 = E.linear_ln(x, prep, pat, 0.0, E.ACT_NONE).float()
+    torch.testing.assert_close(z2 + 7.0, (z0 + 7.0) * r[:, None], atol=8e-2, rtol=5e-3)      # (both sides rounded to fp16 at |z| up to ~40)

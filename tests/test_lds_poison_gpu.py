@@ -217,8 +217,9 @@ def test_convolutions_seams_and_attention_op_by_op_with_poisoned_lds(dev, fp16_m
 
 def test_folded_layernorm_and_window_attention_op_by_op_with_poisoned_lds(dev, fp16_mode, probe):
     """Round 5's kernels one by one at the shapes the ViT-B/16 / Swin-B forwards run them (half batches, both CU plans): tlxmi_linear_stats
-    (gemm_stream STATS with and without a residual; gemm_pp LNF for the 8-K-tile residual producer of Swin-B stage 3), tlxmi_ln_finalize,
-    tlxmi_linear_ln (gemm_stream ROWAFF, plain and GELU: its row table and the (a, b) prefetch live in LDS), tlxmi_attention_windows.
+    (gemm_stream STATS with and without a residual: its statistics cross the waves through an LDS scratch; gemm_pp LNF for the 8-K-tile
+    residual producer of Swin-B stage 3 and the launches of few tiles), tlxmi_linear_ln (gemm_stream ROWAFF, plain and GELU: the
+    statistics planes, their conversion to (a, b) and the prefetch all live in LDS), tlxmi_attention_windows.
     Every LDS byte holds the pattern before every launch; outputs and statistics must not move by a bit."""
     from tlxcv_amd import engine as E
     g = torch.Generator().manual_seed(11)
@@ -239,14 +240,12 @@ def test_folded_layernorm_and_window_attention_op_by_op_with_poisoned_lds(dev, f
             return torch.cat([y.float().reshape(-1), part.reshape(-1)])
         with E.shared_plan(plan):
             y0, part0 = E.linear_stats(x, pk, b, res=r)
-        rowab0 = E.ln_finalize(part0, D, 1e-5)
         cases.append((f"{tag} producer + res M={M} K={K} N={D} plan={plan}", lambda: producer(r)))
         cases.append((f"{tag} producer M={M} K={K} N={D} plan={plan}", lambda: producer(None)))
-        cases.append((f"{tag} finalize {D // 32} slots", lambda: E.ln_finalize(part0, D, 1e-5)))
 
         def consumer():
             with E.shared_plan(plan):
-                return E.linear_ln(y0, prep, rowab0, act)
+                return E.linear_ln(y0, prep, part0, 1e-5, act)
         cases.append((f"{tag} consumer M={M} K={D} N={N2} act={act} plan={plan}", consumer))
     fold("vit proj -> qkv", 25216, 768, 768, 2304, E.ACT_NONE, "full")
     fold("vit fc2 -> fc1", 25216, 3072, 768, 3072, E.ACT_GELU, "half")

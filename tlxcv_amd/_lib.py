@@ -93,9 +93,8 @@ PROTOTYPES = {
     "tlxmi_window_reverse_layernorm": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp],
     "tlxmi_mlp_seam": [_i, _l, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp],
     "tlxmi_linear_stats": [_i, _l, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _u, _vp],
-    "tlxmi_ln_finalize": [_vp, _i, _l, _i, _f, _vp, _vp],
     "tlxmi_softmax_rows": [_vp, _vp, _i, _l, _i, _l, _l, _vp],
-    "tlxmi_linear_ln": [_i, _l, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _u, _vp],
+    "tlxmi_linear_ln": [_i, _l, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _u, _vp],
     "tlxmi_attention": [C.POINTER(AttnDesc), _vp, _vp, _vp, _vp, _vp],
     "tlxmi_attention_comb": [C.POINTER(AttnDesc), _vp, _vp, _vp, _vp],
     "tlxmi_attention_windows": [C.POINTER(AttnDesc), _vp, _vp, _vp, _i, _i, _i, _i, _vp],

@@ -1180,11 +1180,11 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, int splits,
 // ------------------------------------------------------------------------------------------
 // LayerNorm folded AROUND the Linear layers of a transformer block (vision_transformer.py:144-175 norm1 -> attn.qkv, norm2 -> mlp.fc1;
 // swin_transformer.py:310-337), fp16, on the persistent 256 x 256 GEMM kernel (gemm_stream.hip):
-//   producer  tlxmi_linear_stats: y = x W^T + bias (+ res), and from the same epilogue the per-row partial (sum y, sum y^2) of every
-//             32-channel slot -> partials[Cout / 32][rows][2] (the LayerNorm that follows needs no pass over y);
-//   finalize  tlxmi_ln_finalize (norm.hip): slots -> rowab[rows][2] = (rstd, -mean * rstd);
-//   consumer  tlxmi_linear_ln: y = act(rowab[m][0] * (x W'^T) + rowab[m][1] * c1[n] + c2[n]) on the RAW rows x, with the caller's
-//             W' = W * gamma (packed), c1[n] = sum_k W'[n][k] (of the values as packed), c2[n] = bias[n] + sum_k W[n][k] * beta[k].
+//   producer  tlxmi_linear_stats: y = x W^T + bias (+ res), and from the same epilogue per row (sum y, sum y^2) over every 256-channel
+//             tile column -> partials[ceil(Cout / 256)][rows][2] (the LayerNorm that follows needs no pass over y);
+//   consumer  tlxmi_linear_ln: mean / rstd of each row from the ceil(K / 256) <= 4 planes of the producer (no launch in between), then
+//             y = act(rstd * (x W'^T) - mean * rstd * c1[n] + c2[n]) on the RAW rows x, with the caller's W' = W * gamma (packed),
+//             c1[n] = sum_k W'[n][k] (of the values as packed), c2[n] = bias[n] + sum_k W[n][k] * beta[k].
 // The normalised activations are never written or read.  Shapes / options the persistent kernel does not take return
 // TLXMI_ERR_UNSUPPORTED (tlxmi_linear_ln_supported asks first) and the caller keeps tlxmi_layernorm + tlxmi_conv2d.
 // ------------------------------------------------------------------------------------------
@@ -1238,6 +1238,7 @@ extern "C" int tlxmi_linear_ln_supported(int dtype, int64_t rows, int K, int Cou
     const int ktiles = (K * 2 / 16 + 7) / 8;
     if (ktiles < 2) return 0;      // (a residual with fewer than 11 K tiles runs on the one-tile-per-workgroup kernel, gemm_pp.hip LNF)
     if (act != TLXMI_ACT_NONE && !(act == TLXMI_ACT_GELU && !with_res)) return 0;
+    if (!with_res && K > 1024) return 0;      // the consumer holds the statistics of a row as ceil(K / 256) <= 4 planes
     return 1;
 }
 
@@ -1248,7 +1249,7 @@ extern "C" int tlxmi_linear_stats(int dtype, int64_t rows, int K, int Cout, int 
     if (int rc = fill_ln_gemm(g, "linear_stats", dtype, rows, K, Cout, x_ld, y_ld, x, w_packed, y)) return rc;
     TLXMI_REQUIRE(partials && ((uintptr_t)partials & 7) == 0, TLXMI_ERR_BAD_ARG, "linear_stats: partials must be an 8-byte aligned buffer");
     TLXMI_REQUIRE(!res || (res_ld >= Cout && (res_ld * 2) % 16 == 0 && aligned16(res)), TLXMI_ERR_BAD_ARG, "linear_stats: bad residual");
-    if ((long long)(Cout / 32) * rows * 8 >= (1ll << 31)) return fail(TLXMI_ERR_UNSUPPORTED, "linear_stats: partial sums exceed 2 GiB");
+    if ((long long)((Cout + 255) / 256) * rows * 8 >= (1ll << 31)) return fail(TLXMI_ERR_UNSUPPORTED, "linear_stats: partial sums exceed 2 GiB");
     g.shift = bias;
     g.res = (const char*)res;
     g.res_ld = res ? res_ld : 0;
@@ -1263,15 +1264,21 @@ extern "C" int tlxmi_linear_stats(int dtype, int64_t rows, int K, int Cout, int 
 }
 
 extern "C" int tlxmi_linear_ln(int dtype, int64_t rows, int K, int Cout, int x_ld, int y_ld, const void* x, const void* w_packed,
-                               const float* c1, const float* c2, const float* rowab, int act, void* y, unsigned flags, void* stream) {
+                               const float* c1, const float* c2, const float* partials, float eps, int act, void* y, unsigned flags,
+                               void* stream) {
     using namespace tlxmi;
     Gemm256Args g;
     if (int rc = fill_ln_gemm(g, "linear_ln", dtype, rows, K, Cout, x_ld, y_ld, x, w_packed, y)) return rc;
-    TLXMI_REQUIRE(c1 && c2 && rowab && ((uintptr_t)rowab & 15) == 0, TLXMI_ERR_BAD_ARG, "linear_ln: c1 / c2 / rowab (16-byte aligned) are required");
+    TLXMI_REQUIRE(c1 && c2 && partials && ((uintptr_t)partials & 15) == 0, TLXMI_ERR_BAD_ARG, "linear_ln: c1 / c2 / partials (16-byte aligned) are required");
+    TLXMI_REQUIRE(eps >= 0.f, TLXMI_ERR_BAD_ARG, "linear_ln: eps %g", (double)eps);
     TLXMI_REQUIRE(act == TLXMI_ACT_NONE || act == TLXMI_ACT_GELU, TLXMI_ERR_UNSUPPORTED, "linear_ln: activation %d (none or GELU)", act);
+    if (K > 1024) return fail(TLXMI_ERR_UNSUPPORTED, "linear_ln: rows of %d channels (the statistics of a row are held as <= 4 planes of 256)", K);
     g.scale = c1;
     g.shift = c2;
-    g.rowstats = rowab;
+    g.rowstats = partials;
+    g.ln_planes = (K + 255) / 256;
+    g.ln_inv_c = 1.0f / (float)K;
+    g.ln_eps = eps;
     g.act = act;
     g.flags = flags & (TLXMI_PLAN_SHARED_HALF | TLXMI_PLAN_SHARED_FULL);
     // TLXMI_LN_GELU_PP (tuning flavour): 1 = GELU layers on the one-tile-per-workgroup kernel (its epilogue is not squeezed between MFMAs)

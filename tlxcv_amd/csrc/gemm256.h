@@ -12,12 +12,15 @@ struct Gemm256Args {
     const float* shift;
     const char* res;
     // LayerNorm folded around the Linear layers (gemm_stream.hip only; fp16):
-    //   rowstats  [M][2] per-row (a, b) = (rstd, -mean * rstd): y = act(a * acc + b * scale[n] + shift[n]) — the CONSUMER of a LayerNorm
-    //             whose gamma is folded into the packed filter (scale = c1[n] = sum_k W'[n][k], shift = c2[n] = bias + W beta);
-    //   stats_out [Cout / 32][M][2] per-row partial (sum y, sum y^2) over each 32-channel slot of the outputs this launch stores — the
-    //             PRODUCER side: the next LayerNorm's statistics without a pass over y (tlxmi_ln_finalize adds the slots up).
+    //   stats_out [ceil(Cout / 256)][M][2]: per row (sum y, sum y^2) over each 256-channel tile column of the outputs this launch stores —
+    //             the PRODUCER side: the next LayerNorm's statistics without a pass over y;
+    //   rowstats  such planes of the rows this launch READS (ln_planes of them, <= 4; ln_inv_c = 1 / row width, ln_eps): the CONSUMER of a
+    //             LayerNorm whose gamma is folded into the packed filter forms (a, b) = (rstd, -mean * rstd) per row from them and stores
+    //             y = act(a * acc + b * scale[n] + shift[n])  (scale = c1[n] = sum_k W'[n][k], shift = c2[n] = bias + W beta).
     const float* rowstats = nullptr;
     float* stats_out = nullptr;
+    int ln_planes = 0;
+    float ln_inv_c = 0.f, ln_eps = 0.f;
     int M, Cout, x_ld, y_ld, res_ld;
     int kchunks;   // true 16-byte chunks per row
     int ksteps;    // 64-byte steps (packed pitch / 64)

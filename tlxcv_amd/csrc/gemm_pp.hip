@@ -71,10 +71,11 @@ template <> struct MmaPP<float> {
 // mask of the taps that fall inside the image (bit clear -> out-of-range descriptor offset -> zero fill).
 // HN = W half tiles per K tile: (HM, HN) = (2, 1) is the mirror image of (1, 2) — a 256 x 128 tile for layers with 128
 // output channels (3x3 convs of ResNet's 28 x 28 stage): phases (0,0) and (1,0), X1 taking W1's place in the DMA order.
-// LNF (fp16, plain GEMM rows): the LayerNorm fold of gemm_stream.hip in this kernel's end-of-tile epilogue — a.rowstats: per-row (a, b)
-// applied as y = act(a * acc + b * scale[n] + shift[n]) (the consumer of a folded LayerNorm); a.stats_out: per-row partial (sum, sum of
-// squares) of the outputs over each 32-channel slot (the producer).  Used where the persistent kernel does not apply: a residual with
-// fewer than 11 K tiles (Swin-B stage 3 proj: K = 512), fewer tiles than CUs.
+// LNF (fp16, plain GEMM rows): the LayerNorm fold of gemm_stream.hip in this kernel's end-of-tile epilogue — a.rowstats: the producer's
+// planes of per-row (sum, sum^2), turned into (a, b) per row and applied as y = act(a * acc + b * scale[n] + shift[n]) (the consumer of a
+// folded LayerNorm); a.stats_out: per-row (sum, sum^2) of this tile's 256 output channels as plane bn0 / 256 (the producer; the four
+// wc waves of a row are added through LDS).  Used where the persistent kernel does not apply: a residual with fewer than 11 K tiles
+// (Swin-B stage 3 proj: K = 512), fewer tiles than half the CUs.
 template <typename T, int HM, int HN, bool CONV, bool LNF = false>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
     static_assert(HM + HN >= 3 && HM <= 2 && HN <= 2, "tile is 256x256, 128x256 or 256x128");
@@ -363,6 +364,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
     const __amdgpu_buffer_rsrc_t ysrd = pp_srd(a.y, a.y_bytes), rsrd = pp_srd(a.res ? a.res : a.y, a.res ? a.res_bytes : 0u);
     auto epi = [&](auto act_tag) {
         constexpr int ACT = decltype(act_tag)::value;
+        float hs_[HM], hq_[HM];      // LNF producer: this wave's (sum, sum^2) of row 128 h + 64 wr + lane over its channels of both column halves
+#pragma unroll
+        for (int h = 0; h < HM; ++h) { hs_[h] = 0.f; hq_[h] = 0.f; }
 #pragma unroll
         for (int g = 0; g < HN; ++g) {
             const int col = 128 * g + 32 * wc + 8 * fg;
@@ -389,11 +393,24 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
                 }
                 f32x2 rab[4];
                 if constexpr (LNF) {
-                    if (a.rowstats) {
+                    if (a.rowstats) {      // (a, b) = (rstd, -mean * rstd) of the row from the producer's planes of (sum, sum^2) over 256 channels each
 #pragma unroll
                         for (int pi = 0; pi < 4; ++pi) {
                             const int m = bm0 + 128 * h + 64 * wr + prow(pi) * 16 + px;
-                            rab[pi] = m < a.M ? *reinterpret_cast<const f32x2*>(a.rowstats + 2 * (size_t)m) : f32x2{0.f, 0.f};
+                            float sm = 0.f, sq = 0.f;
+                            if (m < a.M) {
+#pragma unroll
+                                for (int p = 0; p < 4; ++p)
+                                    if (p < a.ln_planes) {
+                                        const f32x2 pl = *reinterpret_cast<const f32x2*>(a.rowstats + 2 * ((size_t)p * a.M + m));
+                                        sm += pl[0];
+                                        sq += pl[1];
+                                    }
+                            }
+                            const float mean = sm * a.ln_inv_c;
+                            const float var = fmaxf(__builtin_fmaf(-mean, mean, sq * a.ln_inv_c), 0.f);
+                            const float rstd = 1.f / sqrtf(var + a.ln_eps);
+                            rab[pi] = f32x2{rstd, -mean * rstd};
                         }
                     }
                 }
@@ -471,13 +488,34 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
                 }
                 if constexpr (LNF) {
                     if (a.stats_out) {
-                        // the four lanes (fg = 0..3) of a row hold its 32 channels of this slot: three lane-swap steps per four quantities
-                        // (gemm_stream.hip STATS); lane row fg ends with the total of sub-tile pi = fg -> rows 16 fg + px = lane, 512 B per wave
+                        // the four lanes (fg = 0..3) of a row hold its 32 channels of this wave and column half: three lane-swap steps per four
+                        // quantities (gemm_stream.hip STATS); lane row fg ends with the total of sub-tile pi = fg -> row 16 fg + px = lane
                         auto tree = [&](const float (&x)[4]) -> float { return ln_row_tree(x[0], x[1], x[2], x[3]); };
-                        const float ts = tree(st_s), tq = tree(st_q);
+                        hs_[h] += tree(st_s);
+                        hq_[h] += tree(st_q);
+                    }
+                }
+            }
+        }
+        if constexpr (LNF) {
+            if (a.stats_out) {
+                // the four wc waves of a row half -> LDS (the K tiles are dead: every wave is past its last fragment read and its DMAs),
+                // added in a fixed order, stored by wave wc == 0 as plane bn0 / 256 of a.stats_out: [ceil(Cout / 256)][M][2]
+                f32x2* scr = reinterpret_cast<f32x2*>(smem);
+                __builtin_amdgcn_s_barrier();
+#pragma unroll
+                for (int h = 0; h < HM; ++h) scr[((h * 2 + wr) * 4 + wc) * 64 + lane] = f32x2{hs_[h], hq_[h]};
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (wc == 0) {
+#pragma unroll
+                    for (int h = 0; h < HM; ++h) {
+                        const f32x2* q = scr + (h * 2 + wr) * 4 * 64 + lane;
+                        const f32x2 p0 = q[0], p1 = q[64], p2 = q[128], p3 = q[192];
                         const int m = bm0 + 128 * h + 64 * wr + lane;
-                        const int slot = (bn0 + 128 * g + 32 * wc) >> 5;
-                        if (m < a.M) *reinterpret_cast<f32x2*>(a.stats_out + 2 * ((size_t)slot * a.M + m)) = f32x2{ts, tq};
+                        if (m < a.M)
+                            *reinterpret_cast<f32x2*>(a.stats_out + 2 * ((size_t)(bn0 >> 8) * a.M + m)) =
+                                f32x2{(p0[0] + p1[0]) + (p2[0] + p3[0]), (p0[1] + p1[1]) + (p2[1] + p3[1])};
                     }
                 }
             }

@@ -97,12 +97,19 @@ template <int N> __device__ __forceinline__ void gs_vmcnt() {
 
 // ACT: TLXMI_ACT_NONE / RELU / GELU (other activations, and exact-erf GELU in fp32, stay on gemm_pp.hip).
 // RES: a.res is added (before the activation; a.scale must be null) — needs >= 11 K tiles.
-// ROWAFF: the CONSUMER of a folded LayerNorm — per-row (a, b) = (rstd, -mean * rstd) of a.rowstats applied in the epilogue,
-//   y = act(a[m] * acc + b[m] * c1[n] + c2[n]) with c1 = a.scale, c2 = a.shift; one more table piece per tile (256 rows x 8 B).
+// ROWAFF: the CONSUMER of a folded LayerNorm — y = act(a[m] * acc + b[m] * c1[n] + c2[n]) with c1 = a.scale, c2 = a.shift and the
+//   per-row (a, b) = (rstd, -mean * rstd) formed in the kernel from the producer's planes a.rowstats[p][m] = (sum, sum^2) of row m
+//   over 256 channels, p < a.ln_planes <= 4: ONE more table piece per tile and wave (4 planes x 32 rows x 8 B on the 64 lanes; a plane
+//   that does not exist is out of range and arrives as zeros), added up and inverted once per tile by rowab_convert.
 // STATS: the PRODUCER — every quadrant epilogue also adds up its 8 channels x 4 rows per lane (sum, sum of squares of the fp32
-//   values before the rounding), reduces the four lanes of a row with three lane-swap steps per four quantities and stores
-//   (sum, sum^2) of row m over the 32 channels of slot (bn0 + 128 G + 32 wc) / 32 at a.stats_out[slot][m]: 512 contiguous
-//   bytes per wave, one more store per quadrant (S + 1 in every counted wait).
+//   values before the rounding) and reduces the four lanes of a row with three lane-swap steps per four quantities: lane l then
+//   holds (sum, sum^2) of row 128 H + 64 wr + l over the wave's 32 channels of column half G.  The two column halves of a row
+//   half H go into an LDS scratch [H][G][wr][wc][64] (a tile's epilogues run in the order E00, E01, E11, E10), and one epilogue
+//   after the second of them — at least one barrier later — the eight pairs (2 column halves x 4 wc waves) of a row are added up
+//   and wave wc == 0 stores (sum, sum^2) of the row over the tile's 256 channels
+//   at a.stats_out[bn0 / 256][m]: E11 carries half 0 of its own tile, E00 half 1 of the tile before (the last tile's at the end
+//   of the kernel).  Every phase of the last K tile still issues exactly ONE more store (S + 1 in every counted wait): E01 / E10
+//   send a dummy out of range, for E00 / E11 it is the stage-2 store, issued by the load segment of their phase.  No atomics, one writer per (plane, row), a fixed order of additions: bit-reproducible.
 // (the ablation branches of the tuning flavour exist in the plain variants only: with them the LayerNorm-fold variants spill — 880 bytes
 //  of scratch per lane for GELU + ROWAFF, i.e. a vmcnt(0) drain per reload — and tools/ab_graph.py would time an artefact)
 #define GS_DBG(args, bit) (!ROWAFF && !STATS && TLXMI_DBG(args, bit))
@@ -113,7 +120,8 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
     constexpr int RX0 = 0, RX1 = HALF, RW0 = 2 * HALF, RW1 = 3 * HALF;   // regions of a K tile
     constexpr int TABLE = 8 * HALF;            // two tables of 8 x 256 B behind the two K tiles
     constexpr int OOB = (int)0x80000000;
-    constexpr int ROWTAB = TABLE + 2 * 2048;   // ROWAFF: two tables of 256 rows x (a, b) behind the channel tables
+    constexpr int ROWTAB = TABLE + 2 * 2048;   // ROWAFF: two tables of 4 planes x 256 rows x (sum, sum^2) behind the channel tables
+    constexpr int STATSCR = TABLE + 2 * 2048;  // STATS (never with ROWAFF): [H][G][wr][wc][64 lanes] x (sum, sum^2), 16 KB
     constexpr int SY = ES == 2 ? 4 : 8;        // 16-byte stores of a quadrant's outputs
     constexpr int S = SY + (STATS ? 1 : 0), R = ES, TT = ROWAFF ? 3 : 2;   // R: loads of one residual step (2 pixel rows x 8 channels per lane)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -149,8 +157,8 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
     const __amdgpu_buffer_rsrc_t rsrd = gs_srd(a.res ? a.res : a.y, a.res ? a.res_bytes : 0u);
     const __amdgpu_buffer_rsrc_t hsrd = gs_srd(a.shift, a.shift ? (unsigned)a.Cout * 4u : 0u);   // null: zero fill
     const __amdgpu_buffer_rsrc_t ssrd = a.scale ? gs_srd(a.scale, (unsigned)a.Cout * 4u) : gs_srd(g_ones4, 16u);
-    const __amdgpu_buffer_rsrc_t rowsrd = gs_srd(a.rowstats, (ROWAFF && a.rowstats) ? (unsigned)a.M * 8u : 0u);               // null: zero fill
-    const __amdgpu_buffer_rsrc_t stsrd = gs_srd(a.stats_out, (STATS && a.stats_out) ? (unsigned)(a.Cout >> 5) * (unsigned)a.M * 8u : 0u);   // null: dropped
+    const __amdgpu_buffer_rsrc_t rowsrd = gs_srd(a.rowstats, (ROWAFF && a.rowstats) ? (unsigned)a.ln_planes * (unsigned)a.M * 8u : 0u);   // null: zero fill
+    const __amdgpu_buffer_rsrc_t stsrd = gs_srd(a.stats_out, (STATS && a.stats_out) ? (unsigned)((a.Cout + 255) >> 8) * (unsigned)a.M * 8u : 0u);   // null: dropped
 
     // ---- loader (gemm_pp.hip): piece = 8 rows x 128 B; wave w fills pieces w, w+8 of a half tile
     const int lrow = lane >> 3;
@@ -198,9 +206,13 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
             gs_dma16(hsrd, dst, off);
             gs_dma16(ssrd, dst + 128, a.scale ? off : 0);
         }
-        // ROWAFF: (a, b) of rows 32w .. 32w+31 of the tile, two rows per lane (rows past M: zero fill)
+        // ROWAFF: the statistics planes of rows 32w .. 32w+31 of the tile in ONE piece per wave — lane group p = lane / 16 brings plane p,
+        // two rows per lane, to [wave][plane][32 rows x 8 B] (rows past M, planes past ln_planes: zero fill).  (Measured, tools/lnfold_micro.py:
+        // one plane only 132.8 us for ViT-B/16's qkv, four planes as four 16-lane pieces 137.4, as this one piece 138.7 with the
+        // conversion — it is the plane LINES that cost, three more places in memory in front of an in-order stream, not the operations.)
         if constexpr (ROWAFF) {
-            if (lane < 16) gs_dma16(rowsrd, smem + ROWTAB + (i & 1) * 2048 + wid * 256, ok ? (bm0 + 32 * wid + 2 * lane) * 8 : OOB);
+            const int p = lane >> 4;
+            gs_dma16(rowsrd, smem + ROWTAB + (i & 1) * 8192 + wid * 1024, (ok && p < a.ln_planes) ? (p * a.M + bm0 + 32 * wid + 2 * (lane & 15)) * 8 : OOB);
         }
     };
 
@@ -230,7 +242,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
     // the S stores of a quadrant that does not exist (H = 1 of a half-height tile), dropped by the range check: the counts stay
     auto dead_stores = [&]() {
 #pragma unroll
-        for (int q = 0; q < S; ++q) gs_store16_wb(ysrd, u32x4{0u, 0u, 0u, 0u}, OOB);
+        for (int q = 0; q < SY; ++q) gs_store16_wb(ysrd, u32x4{0u, 0u, 0u, 0u}, OOB);
     };
 
     // ROWAFF: the (a, b) pairs of this lane's four rows (sub-tiles pi = 0..3 of half h) are read from the row table in the LOAD segment of
@@ -241,13 +253,66 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
     f32x2 rab[4];
     auto rowab_fetch = [&](int h, int tpar) {
         if constexpr (ROWAFF) {
+            // row r of the tile lives at (r / 32) * 1024 + (r % 32) * 8 (rowab_convert): rows 128 h + 64 wr + 16 pi + px -> offsets 0, 128, 1024, 1152
             const int ln = lane_now();
-            const unsigned la = (unsigned)(uintptr_t)(lds_ptr_gs_t)(smem + ROWTAB + tpar * 2048 + (128 * h + 64 * wr + (ln & 15)) * 8);
-            asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:128\n\tds_read_b64 %2, %4 offset:256\n\tds_read_b64 %3, %4 offset:384\n\t"
+            const unsigned la = (unsigned)(uintptr_t)(lds_ptr_gs_t)(smem + ROWTAB + tpar * 8192 + (4 * h + 2 * wr) * 1024 + (ln & 15) * 8);
+            asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:128\n\tds_read_b64 %2, %4 offset:1024\n\tds_read_b64 %3, %4 offset:1152\n\t"
                          "s_waitcnt lgkmcnt(0)"
                          : "=&v"(rab[0]), "=&v"(rab[1]), "=&v"(rab[2]), "=&v"(rab[3])
                          : "v"(la)
                          : "memory");
+        }
+    };
+    // ROWAFF: the statistics planes of a tile -> its (a, b) table, in place over plane 0.  Wave w converts the 32 rows it brought itself
+    // (dma_table: complete since the p3 wait of the tile's first K tile), one row per lane of its lower half, in the load segment of p0 of
+    // the LAST K tile; the barrier of that phase stands between this write and the reads of rowab_fetch (p1, p3) by the other waves.
+    auto rowab_convert = [&](int tpar) {
+        if constexpr (ROWAFF) {
+            const int ln = lane_now();
+            if (ln < 32) {
+                const unsigned la = (unsigned)(uintptr_t)(lds_ptr_gs_t)(smem + ROWTAB + tpar * 8192 + wid * 1024 + ln * 8);
+                f32x2 t0, t1, t2, t3;
+                asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:256\n\tds_read_b64 %2, %4 offset:512\n\tds_read_b64 %3, %4 offset:768\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+                             : "v"(la)
+                             : "memory");
+                const float sm = (t0[0] + t1[0]) + (t2[0] + t3[0]), sq = (t0[1] + t1[1]) + (t2[1] + t3[1]);
+                const float mean = sm * a.ln_inv_c;
+                const float var = fmaxf(__builtin_fmaf(-mean, mean, sq * a.ln_inv_c), 0.f);
+                const float rstd = 1.f / sqrtf(var + a.ln_eps);
+                const f32x2 ab = f32x2{rstd, -mean * rstd};
+                asm volatile("ds_write_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : : "v"(la), "v"(ab) : "memory");
+            }
+        }
+    };
+
+    int bm0 = 0, bn0 = 0, pbm0 = 0, pbn0 = 0;      // origin of the tile being multiplied, of the one before
+    bool hcur = false;      // the tile being multiplied is half-height
+
+    // STATS, stage 2: the eight pairs (2 column halves x 4 wc waves) of this lane's row of half `hp` of the tile at (sbm, sbn), read from
+    // the scratch by asm blocks (the same precaution as rowab_fetch), added in a fixed order, stored by wave wc == 0.  Runs in a LOAD
+    // segment, behind that segment's DMA and in front of its counted wait: the store stands where the quadrant's (S + 1)-th store stood
+    // relative to every LATER wait's target, and the wait right behind it only gets one operation more conservative.
+    bool have_prev = false;                            // the tile before this one left its half 1 in the scratch
+    auto stats_stage2 = [&](int hp, int sbm, int sbn, bool pend) {
+        if constexpr (STATS) {
+            const int ln = lane_now();
+            const unsigned la = (unsigned)(uintptr_t)(lds_ptr_gs_t)(smem + STATSCR + hp * 8192 + wr * 2048 + ln * 8);
+            // (all eight pairs in flight: ONE LDS round trip in this load segment — four blocks of two cost the producers 6 %)
+            f32x2 p0, p1, p2, p3, p4, p5, p6, p7;
+            asm volatile("ds_read_b64 %0, %8\n\tds_read_b64 %1, %8 offset:512\n\tds_read_b64 %2, %8 offset:1024\n\tds_read_b64 %3, %8 offset:1536\n\t"
+                         "ds_read_b64 %4, %8 offset:4096\n\tds_read_b64 %5, %8 offset:4608\n\tds_read_b64 %6, %8 offset:5120\n\tds_read_b64 %7, %8 offset:5632\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3), "=&v"(p4), "=&v"(p5), "=&v"(p6), "=&v"(p7)
+                         : "v"(la)
+                         : "memory");
+            const float s4 = ((p0[0] + p1[0]) + (p2[0] + p3[0])) + ((p4[0] + p5[0]) + (p6[0] + p7[0]));
+            const float q4 = ((p0[1] + p1[1]) + (p2[1] + p3[1])) + ((p4[1] + p5[1]) + (p6[1] + p7[1]));
+            const int m = sbm + 128 * hp + 64 * wr + ln;
+            const int okm = (pend && wc == 0) ? ((m - a.M) >> 31) : 0;
+            const int so = ((((sbn >> 8) * a.M + m) * 8) & okm) | (OOB & ~okm);
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2{__builtin_bit_cast(unsigned, s4), __builtin_bit_cast(unsigned, q4)}, stsrd, so, 0, 0);
         }
     };
 
@@ -339,14 +404,15 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
         if constexpr (STATS) {
             // lanes (fg = 0..3, px) hold the four 8-channel parts of row px of sub-tile pi.  v_permlane16_swap(A, B) trades A's odd lane
             // rows with B's even ones, so A + B afterwards = [A0+A1, B0+B1, A2+A3, B2+B3] by lane row: one swap and one add take TWO
-            // quantities one level up; v_permlane32_swap joins the halves: lane row g ends with the 32-channel total of sub-tile pi = g.
+            // quantities one level up; v_permlane32_swap joins the halves: lane row g ends with the 32-channel total of sub-tile pi = g,
+            // i.e. lane l with the total of row 128 H + 64 wr + l.
             auto tree = [&](const float (&x)[4]) -> float { return ln_row_tree(x[0], x[1], x[2], x[3]); };
             const float ts = tree(st_s), tq = tree(st_q);
-            const int m = bm0 + 128 * H + 64 * wr + ln;            // row of sub-tile fg, pixel px: 16 * fg + px = the lane index
-            const int slot = (bn0 + 128 * G + 32 * wc) >> 5;
-            const int okm = chm & ((m - a.M) >> 31);
-            const int so = (((slot * a.M + m) * 8) & okm) | (OOB & ~okm);
-            __builtin_amdgcn_raw_buffer_store_b64(u32x2{__builtin_bit_cast(unsigned, ts), __builtin_bit_cast(unsigned, tq)}, stsrd, so, 0, 0);
+            // this wave's pair -> scratch [H][G][wr][wc][lane].  The quadrant's extra store: E01 / E10 send a dummy; for E00 / E11 it is the
+            // stage-2 store of the half completed one epilogue ago, issued by the load segment of this same phase (stats_stage2)
+            // (visible to the other waves from the barrier behind this segment: GS_SYNC_E waits for lgkmcnt(0) in front of it)
+            *reinterpret_cast<f32x2*>(smem + STATSCR + H * 8192 + G * 4096 + wr * 2048 + wc * 512 + ln * 8) = f32x2{ts, tq};
+            if constexpr (H != G) __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, stsrd, OOB, 0, 0);
         }
     };
     // Residual step r = 0..7 covers quadrant (r>>1) in the phase order (0,0) (0,1) (1,1) (1,0), pixel sub-tiles
@@ -390,6 +456,13 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
 #define GS_SYNC()                          \
     __builtin_amdgcn_sched_barrier(0);     \
     __builtin_amdgcn_s_barrier();          \
+    __builtin_amdgcn_sched_barrier(0);
+// the barrier behind an MFMA segment that carried a quadrant epilogue: a STATS kernel first waits for that epilogue's LDS write (long
+// landed by now; a wait right behind the write would stall the segment), so that the other waves may read it after the next barrier
+#define GS_SYNC_E()                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                               \
+    if constexpr (STATS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          \
+    __builtin_amdgcn_s_barrier();                                                    \
     __builtin_amdgcn_sched_barrier(0);
 // one quadrant x one K tile; ZERO: the accumulators start from 0 (first K tile of an output tile).  EPI: a statement (the
 // epilogue of the quadrant finished one phase earlier) whose instructions the scheduler spreads between the MFMAs: 3 vector
@@ -442,8 +515,6 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
     GS_SYNC();
     if (wr == 1) { GS_SYNC(); }   // group 1 runs one barrier behind
 
-    int bm0 = 0, bn0 = 0, pbm0 = 0, pbn0 = 0;
-    bool hcur = false;      // the tile being multiplied is half-height
 
     // HF: the tile is half-height (compile time: a run-time test around the MFMA blocks makes the register allocator split the
     // accumulators' live ranges at every join — 80 - 120 spilled registers; a half-height tile is always a workgroup's last)
@@ -457,6 +528,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
         // ---- p0: quadrant (0,0)
         read_x(kb, RX0);
         read_w(kb, RW0, w0f);
+        if constexpr (MODE == GS_LAST) rowab_convert(i & 1);
         if constexpr (MODE > GS_R0 && MODE <= GS_RC) res_add(IntTag<MODE - GS_R0 - 1>{});
         if constexpr (RI) {
             __builtin_amdgcn_sched_barrier(0);   // the new loads re-use the registers just consumed
@@ -467,17 +539,18 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
         GS_SYNC();
         if constexpr (MODE == GS_K0_AFTER) { GS_MMA_E(0, 0, w0f, K0, epi(IntTag<1>{}, IntTag<0>{}, pbm0, pbn0, (i - 1) & 1, true)); }      // (the tile before is never half-height)
         else { GS_MMA(0, 0, w0f, K0); }
-        GS_SYNC();
+        if constexpr (MODE == GS_K0_AFTER) { GS_SYNC_E(); } else { GS_SYNC(); }
         // ---- p1: quadrant (0,1)
         read_w(kb, RW1, w1f);
         if constexpr (MODE == GS_LAST) rowab_fetch(0, i & 1);
         dma_x(RX1, para, xa, kta);
+        if constexpr (MODE == GS_LAST) stats_stage2(1, pbm0, pbn0, have_prev);      // half 1 of the tile before (completed by its E10): E00's extra store
         adv_a();
         gs_vmcnt<(MODE == GS_K0_AFTER ? 8 + 4 * S + TT : 8 + RQ)>();
         GS_SYNC();
         if constexpr (MODE == GS_LAST) { GS_MMA_E(0, 1, w1f, K0, epi(IntTag<0>{}, IntTag<0>{}, bm0, bn0, i & 1, true)); }
         else { GS_MMA(0, 1, w1f, K0); }
-        GS_SYNC();
+        if constexpr (MODE == GS_LAST) { GS_SYNC_E(); } else { GS_SYNC(); }
         // ---- p2: quadrant (1,1) — idle in a half-height tile (its MFMA segment still carries the epilogue of (0,1))
         if constexpr (!HF) read_x(kb, RX1);
         dma_x(RX0, parb, xb, ktb);
@@ -489,10 +562,11 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
         } else {
             if constexpr (MODE == GS_LAST) epi(IntTag<0>{}, IntTag<1>{}, bm0, bn0, i & 1, true);
         }
-        GS_SYNC();
+        if constexpr (MODE == GS_LAST) { GS_SYNC_E(); } else { GS_SYNC(); }
         // ---- p3: quadrant (1,0)
         if constexpr (MODE == GS_LAST && !HF) rowab_fetch(1, i & 1);
         dma_w(RW0, parb, wb, ktb);
+        if constexpr (MODE == GS_LAST) stats_stage2(0, bm0, bn0, true);      // half 0 of this tile (completed by E01): E11's extra store (also of a half-height tile)
         adv_b();
         gs_vmcnt<(MODE == GS_K0_AFTER ? 8 + 2 * S : MODE == GS_LAST ? 8 + 2 * S + TT : 8 + RQ)>();
         GS_SYNC();
@@ -502,7 +576,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
         } else {
             if constexpr (MODE == GS_LAST) dead_stores();
         }
-        GS_SYNC();
+        if constexpr (MODE == GS_LAST) { GS_SYNC_E(); } else { GS_SYNC(); }
         cpar ^= 1;
     };
 
@@ -536,21 +610,30 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
     for (int i = 0; i < n_full; ++i) {
         pbm0 = bm0;
         pbn0 = bn0;
+        have_prev = i > 0;
         tile_origin(i, bm0, bn0, hcur);
         tile(IntTag<0>{}, i);
     }
     if (last_half) {
         pbm0 = bm0;
         pbn0 = bn0;
+        have_prev = n_full > 0;
         tile_origin(n_full, bm0, bn0, hcur);
         tile(IntTag<1>{}, n_full);
     }
     if (wr == 0) { GS_SYNC(); }   // barrier counts match again
-    if (n_mine > 0 && !hcur) epi(IntTag<1>{}, IntTag<0>{}, bm0, bn0, (n_mine - 1) & 1, true);
+    if (n_mine > 0 && !hcur) {
+        epi(IntTag<1>{}, IntTag<0>{}, bm0, bn0, (n_mine - 1) & 1, true);
+        if constexpr (STATS) {      // ... and half 1 of the last tile, which no later epilogue carries
+            GS_SYNC_E();
+            stats_stage2(1, bm0, bn0, true);
+        }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // zero-fill DMAs of the stream's tail
 #undef GS_MMA
 #undef GS_MMA_E
 #undef GS_SYNC
+#undef GS_SYNC_E
 #undef GS_DBG
 }
 
@@ -564,7 +647,7 @@ template <typename T, int ACT, bool RES, bool ROWAFF = false, bool STATS = false
     a.ntiles = (a.Cout + 255) / 256;
     a.gn = a.ntiles;
     if (const long g = tune_int("TLXMI_GS_PANEL", 3); g > 0 && g < a.ntiles) a.gn = (int)g;
-    const size_t lds = (size_t)8 * 128 * 128 + 2 * 2048 + (ROWAFF ? 2 * 2048 : 0);   // two K tiles, channel tables, row tables
+    const size_t lds = (size_t)8 * 128 * 128 + 2 * 2048 + (ROWAFF ? 2 * 8192 : 0) + (STATS ? 16384 : 0);   // two K tiles, channel tables, row tables / statistics scratch
     const void* fn = reinterpret_cast<const void*>(&gemm_stream_kernel<T, ACT, RES, ROWAFF, STATS>);
     if (int rc = raise_lds_limit(fn, (int)lds, "gemm_stream")) return rc;
     int maxgrid = cus & ~7;         // one workgroup per CU; a multiple of 8 keeps a virtual block on its XCD

@@ -293,74 +293,6 @@ extern "C" int tlxmi_layernorm(const void* x, const float* gamma, const float* b
     return launch_ln<float>(x, gamma, beta, y, (long)rows, C, x_ld, y_ld, eps, as_stream(stream));
 }
 
-// LayerNorm statistics from the producing GEMM's epilogue (tlxmi_linear_stats, gemm_stream.hip STATS): partials[slot][row] = (sum, sum of
-// squares) of the row's values over one 32-channel slot.  One thread per row adds the slots up in a fixed order (bit-reproducible)
-// and writes rowab[row] = (rstd, -mean * rstd), the per-row affine tlxmi_linear_ln applies:  LN(x)[row][k] = x[row][k] * a + b before
-// gamma / beta (biased variance, eps as nn.LayerNorm: vision_transformer.py:144,159).  The variance is combined slot by slot —
-// M2 = sum_i (q_i - s_i * m_i) + 32 * sum_i (m_i - mean)^2 with m_i = s_i / 32 — so a row whose mean is far from zero loses no more
-// than each 32-channel group loses on its own.
-namespace tlxmi {
-// SL >= slots: every partial of the row in registers at once (ONE round of loads; the two-pass form re-read them: 5 - 6 us per launch
-// of dependent latencies, 4 % of Swin-B's kernel time); SL = 0: the generic two-pass form for wider rows.
-template <int SL>
-__global__ __launch_bounds__(64) void ln_finalize_kernel(const f32x2* __restrict__ part, int slots, int rows, float inv_c, float eps,
-                                                         f32x2* __restrict__ rowab) {
-    const int r = blockIdx.x * 64 + threadIdx.x;
-    if (r >= rows) return;
-    float mean, m2 = 0.f;
-    if constexpr (SL > 0) {
-        f32x2 p[SL];
-#pragma unroll
-        for (int i = 0; i < SL; ++i) p[i] = i < slots ? part[(size_t)i * rows + r] : f32x2{0.f, 0.f};
-        float sum = 0.f;
-#pragma unroll
-        for (int i = 0; i < SL; ++i) sum += p[i][0];
-        mean = sum * inv_c;
-#pragma unroll
-        for (int i = 0; i < SL; ++i) {
-            const float mi = p[i][0] * (1.f / 32.f), d = mi - mean;
-            if (i < slots) m2 += (p[i][1] - p[i][0] * mi) + 32.f * d * d;
-        }
-    } else {
-        float sum = 0.f;
-        for (int i0 = 0; i0 < slots; i0 += 16) {
-            float s16[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) s16[i] = i0 + i < slots ? part[(size_t)(i0 + i) * rows + r][0] : 0.f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) sum += s16[i];
-        }
-        mean = sum * inv_c;
-        for (int i0 = 0; i0 < slots; i0 += 16) {
-            f32x2 p16[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) p16[i] = i0 + i < slots ? part[(size_t)(i0 + i) * rows + r] : f32x2{32.f * mean, 32.f * mean * mean};
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float mi = p16[i][0] * (1.f / 32.f), d = mi - mean;
-                m2 += (p16[i][1] - p16[i][0] * mi) + 32.f * d * d;
-            }
-        }
-    }
-    const float rstd = 1.f / sqrtf(fmaxf(m2 * inv_c, 0.f) + eps);
-    rowab[r] = f32x2{rstd, -mean * rstd};
-}
-}  // namespace tlxmi
-
-extern "C" int tlxmi_ln_finalize(const float* partials, int slots, int64_t rows, int C, float eps, float* rowab, void* stream) {
-    using namespace tlxmi;
-    TLXMI_REQUIRE(partials && rowab && slots > 0 && rows > 0 && rows < (1ll << 27) && C == 32 * slots && eps >= 0.f, TLXMI_ERR_BAD_ARG,
-                  "ln_finalize: bad argument (C must be 32 * slots)");
-    TLXMI_REQUIRE(((uintptr_t)partials & 7) == 0 && ((uintptr_t)rowab & 15) == 0, TLXMI_ERR_ALIGNMENT, "ln_finalize: partials 8-byte, rowab 16-byte aligned");
-    const dim3 grid((unsigned)((rows + 63) / 64));
-    const f32x2* pp = reinterpret_cast<const f32x2*>(partials);
-    f32x2* ab = reinterpret_cast<f32x2*>(rowab);
-    if (slots <= 16) hipLaunchKernelGGL(ln_finalize_kernel<16>, grid, dim3(64), 0, as_stream(stream), pp, slots, (int)rows, 1.f / (float)C, eps, ab);
-    else if (slots <= 32) hipLaunchKernelGGL(ln_finalize_kernel<32>, grid, dim3(64), 0, as_stream(stream), pp, slots, (int)rows, 1.f / (float)C, eps, ab);
-    else hipLaunchKernelGGL(ln_finalize_kernel<0>, grid, dim3(64), 0, as_stream(stream), pp, slots, (int)rows, 1.f / (float)C, eps, ab);
-    return check_launch("ln_finalize");
-}
-
 // LayerNorm fused with Swin's window plumbing (swin_transformer.py:315-335):
 //   tlxmi_layernorm_window_partition: win = window_partition(roll(LN(x), -shift))      (norm1 + :316-324)
 //   tlxmi_window_reverse_layernorm:   sum = res + roll(window_reverse(win), +shift);  y = LN(sum)   (:327-335 + norm2)

@@ -839,9 +839,9 @@ def _probe_pair():
 
 
 def linear_stats(x, pk, bias=None, res=None, out=None):
-    """y = x W^T + bias (+ res) as linear(), plus the per-row partial (sum, sum of squares) of y over every 32-channel slot from the
-    same epilogue: returns (y, partials (Cout / 32, rows, 2) fp32) — the statistics of the LayerNorm that follows, without a pass
-    over y (ln_finalize turns them into the row affine of linear_ln)."""
+    """y = x W^T + bias (+ res) as linear(), plus per row (sum, sum of squares) of y over every 256-channel tile column from the same
+    epilogue: returns (y, partials (ceil(Cout / 256), rows, 2) fp32) — the statistics of the LayerNorm that follows, without a pass
+    over y; linear_ln takes them as they are."""
     need_gpu(x, "input")
     shp = x.shape
     if not x.is_contiguous():
@@ -853,7 +853,7 @@ def linear_stats(x, pk, bias=None, res=None, out=None):
     if res is not None and (not res.is_contiguous() or res.dtype != x.dtype):
         raise RuntimeError("linear_stats: the residual must be a dense tensor of the input's dtype")
     y = out if out is not None else torch.empty((*shp[:-1], pk.Cout), dtype=x.dtype, device=x.device)
-    part = torch.empty((pk.Cout // 32, rows, 2), dtype=torch.float32, device=x.device)
+    part = torch.empty(((pk.Cout + 255) // 256, rows, 2), dtype=torch.float32, device=x.device)
     if _probe is not None:
         e0, e1 = _probe_pair()
     _lib.call("tlxmi_linear_stats", dt_code(x.dtype), rows, K, pk.Cout, K, pk.Cout, _p(x), _p(pk.buf), _p(bias), _p(res),
@@ -866,32 +866,25 @@ def linear_stats(x, pk, bias=None, res=None, out=None):
     return y, part
 
 
-def ln_finalize(part, C, eps):
-    """partials (C / 32, rows, 2) of linear_stats -> rowab (rows, 2) = (rstd, -mean * rstd) (tlxmi_ln_finalize)."""
-    slots, rows, _ = part.shape
-    rowab = torch.empty((rows, 2), dtype=torch.float32, device=part.device)
-    _lib.call("tlxmi_ln_finalize", _p(part), slots, rows, int(C), float(eps), _p(rowab), _stream())
-    return rowab
-
-
-def linear_ln(x, prep, rowab, act=ACT_NONE):
-    """act(Linear(LayerNorm(x))) on the RAW rows x (..., K): the row affine `rowab` of ln_finalize applied in the GEMM epilogue."""
+def linear_ln(x, prep, part, eps, act=ACT_NONE):
+    """act(Linear(LayerNorm(x))) on the RAW rows x (..., K): `part` = the (ceil(K / 256), rows, 2) planes of (sum, sum of squares) the
+    linear_stats launch that wrote x left; mean / rstd of a row are formed inside the GEMM and applied in its epilogue."""
     need_gpu(x, "input")
     shp = x.shape
     if not x.is_contiguous():
         x = x.contiguous()
     rows = x.numel() // shp[-1]
-    if rowab.shape[0] != rows:
-        raise RuntimeError(f"linear_ln: {rowab.shape[0]} row statistics for {rows} rows")
+    if tuple(part.shape) != ((prep.K + 255) // 256, rows, 2) or part.dtype != torch.float32 or not part.is_contiguous():
+        raise RuntimeError(f"linear_ln: statistics of shape {tuple(part.shape)} for {rows} rows of {prep.K} channels (expected {((prep.K + 255) // 256, rows, 2)} fp32)")
     y = torch.empty((*shp[:-1], prep.Cout), dtype=x.dtype, device=x.device)
     if _probe is not None:
         e0, e1 = _probe_pair()
     _lib.call("tlxmi_linear_ln", dt_code(x.dtype), rows, prep.K, prep.Cout, prep.K, prep.Cout, _p(x), _p(prep.pk.buf), _p(prep.c1), _p(prep.c2),
-              _p(rowab), act, _p(y), plan_flags(), _stream())
+              _p(part), C.c_float(float(eps)), act, _p(y), plan_flags(), _stream())
     if _probe is not None:
         e1.record()
         es = x.element_size()
-        _probe.append((e0, e1, (rows * prep.K + rows * prep.Cout + prep.Cout * prep.K) * es + rows * 8,
+        _probe.append((e0, e1, (rows * prep.K + rows * prep.Cout + prep.Cout * prep.K) * es + part.numel() * 4,
                        2 * rows * prep.Cout * prep.K, (rows, 1, 1, prep.K, prep.Cout, 1, 1, False)))
     return y
 

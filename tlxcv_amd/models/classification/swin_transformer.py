@@ -14,8 +14,8 @@ bias (+ shift mask) -> softmax -> @v -> proj -> window_reverse -> roll back -> r
   * PatchMerging's strided 2x2 gather + concat + LayerNorm is one pass (tlxmi_patch_merge_layernorm), then the GEMM.
 Round 5, fp16 at >= `lnfold_min_rows` token rows per launch and channel widths >= `lnfold_min_c` (stages 2 - 4 of
 Swin-B at bench size): the residual stream stays in IMAGE order and neither LayerNorm-type pass runs — the producing GEMM (proj,
-fc2, the PatchMerging reduction) leaves per-row (sum, sum of squares) partials, qkv / fc1 run on the raw stream with gamma folded
-into the weight and the per-row affine in the epilogue, and roll + window_partition / window_reverse + roll back are row
+fc2, the PatchMerging reduction) leaves per-row (sum, sum of squares) per 256-channel tile column, qkv / fc1 run on the raw stream
+with gamma folded into the weight, form mean / rstd of their rows from those and apply the per-row affine in the epilogue, and roll + window_partition / window_reverse + roll back are row
 arithmetic inside the attention kernel (tlxmi_attention_windows).  Stage 1 (128 channels: statistics of a row fit no tile
 economy, the passes stay) runs its Mlp as one launch with the hidden map on chip (tlxmi_mlp_seam).
 Quirks kept on purpose: the -100.0 (not -inf) mask, and the PatchMerging reduction bias (:369-370).
@@ -227,12 +227,12 @@ class SwinTransformerBlock(nn.Module):
         B, L, C = x.shape
         assert L == H * W, 'input feature has wrong size'
         a, ws = self.attn, self.window_size
-        qkv = a.qkv.run_ln(x, self.norm1, E.ln_finalize(part, C, self.norm1.epsilon))                       # norm1 + qkv (:315, :194)
+        qkv = a.qkv.run_ln(x, self.norm1, part)                       # norm1 + qkv (:315, :194)
         tab = a.table(self.attn_mask, ws * ws)
         aw = E.attention_windows(qkv, a.num_heads, a.scale, tab, 0 if self.attn_mask is None else self.attn_mask.shape[0], H, W, ws,
                                  self.shift_size)                                                            # :316-333 around :202-226
         part = a.proj.run_stats(aw, res=x, out=x)[1]                                                         # proj + shortcut (:226, :334)
-        h = self.mlp.fc1.run_ln(x, self.norm2, E.ln_finalize(part, C, self.norm2.epsilon), act=self.mlp.act.ACT)   # norm2 + fc1 + GELU
+        h = self.mlp.fc1.run_ln(x, self.norm2, part, act=self.mlp.act.ACT)   # norm2 + fc1 + GELU
         if stats:
             return self.mlp.fc2.run_stats(h, res=x, out=x)[1]                                                # fc2 + residual (:335)
         self.mlp.fc2.run(h, res=x, out=x)

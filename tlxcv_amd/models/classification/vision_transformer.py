@@ -15,8 +15,8 @@ change of arithmetic):
   * Mlp (:81-87) = fc1 GEMM with bias+exact-erf GELU epilogue -> fc2 GEMM with bias + residual (:174).
   * norm1 / norm2 (:172-174) are no launches and no passes over the token matrix at fp16 bench sizes (round 5): the
     GEMM that writes the residual stream (patch Linear, proj, fc2) leaves per-row (sum, sum of squares) partials from its fp32
-    epilogue values, a 3 us launch turns them into (rstd, -mean * rstd) per row, and qkv / fc1 run on the RAW stream with gamma
-    folded into the weight and  y = a * acc + b * c1[n] + c2[n]  in the epilogue.  Below `lnfold_min_rows` token rows per launch,
+    epilogue values (one pair per 256-channel tile column), and qkv / fc1 run on the RAW stream with gamma folded into the weight,
+    form (a, b) = (rstd, -mean * rstd) per row from those pairs and store  y = a * acc + b * c1[n] + c2[n].  Below `lnfold_min_rows` token rows per launch,
     in fp32, and with set_option("lnfold", 0): LayerNorm launches of their own in front of the qkv / fc1 GEMMs.
   * final LayerNorm only on the cls rows (x[:, 0] commutes with a per-row norm, :327-328).
 """
@@ -72,10 +72,10 @@ class Mlp(nn.Module):
         h = self.fc1.run(norm(x) if norm is not None else x, act=self.act.ACT)
         return self.fc2.run(h, res=res, out=res)       # bias + residual, written in place
 
-    def run_folded(self, x, norm, rowab, stats=True):
-        """x += fc2(act(fc1(norm(x)))) with `norm` applied in fc1's epilogue from the row statistics `rowab` of x; returns the partial
+    def run_folded(self, x, norm, part, stats=True):
+        """x += fc2(act(fc1(norm(x)))) with `norm` applied in fc1's epilogue from the row statistics `part` of x; returns the partial
         row statistics of the new x out of fc2's epilogue (None when stats is False: the last block)."""
-        h = self.fc1.run_ln(x, norm, rowab, act=self.act.ACT)
+        h = self.fc1.run_ln(x, norm, part, act=self.act.ACT)
         if stats:
             return self.fc2.run_stats(h, res=x, out=x)[1]
         self.fc2.run(h, res=x, out=x)
@@ -105,10 +105,10 @@ class Attention(nn.Module):
         a = E.attention(qkv, self.num_heads, self.scale)               # softmax(q k^T * scale) v, heads merged
         return self.proj.run(a, res=res, out=res)
 
-    def run_folded(self, x, norm, rowab):
-        """x += proj(attention(qkv(norm(x)))) with `norm` applied in qkv's epilogue from the row statistics `rowab` of x; returns the
+    def run_folded(self, x, norm, part):
+        """x += proj(attention(qkv(norm(x)))) with `norm` applied in qkv's epilogue from the row statistics `part` of x; returns the
         partial row statistics of the new x out of proj's epilogue."""
-        qkv = self.qkv.run_ln(x, norm, rowab)
+        qkv = self.qkv.run_ln(x, norm, part)
         a = E.attention(qkv, self.num_heads, self.scale)
         return self.proj.run_stats(a, res=x, out=x)[1]
 
@@ -158,8 +158,8 @@ class Block(nn.Module):
         """run_inplace with the LayerNorms folded: `part` = partial row statistics of x (from whoever wrote x); returns those of the
         new x (None for the last block)."""
         D = x.shape[2]
-        part = self.attn.run_folded(x, self.norm1, E.ln_finalize(part, D, self.norm1.epsilon))
-        return self.mlp.run_folded(x, self.norm2, E.ln_finalize(part, D, self.norm2.epsilon), stats=not last)
+        part = self.attn.run_folded(x, self.norm1, part)
+        return self.mlp.run_folded(x, self.norm2, part, stats=not last)
 
     def forward(self, x):
         E.need_gpu(x, "input")

@@ -674,12 +674,12 @@ class Linear(Module):
         b = self._cached("bias", lambda: E._f32(self.biases)) if self.biases is not None else None
         return E.linear_stats(x, pk, b, res, out)
 
-    def run_ln(self, x, norm, rowab, act=E.ACT_NONE):
-        """act(self(norm(x))) on the raw rows x, `norm` (an nn.LayerNorm) folded in: rowab = engine.ln_finalize(partials of x)."""
+    def run_ln(self, x, norm, part, act=E.ACT_NONE):
+        """act(self(norm(x))) on the raw rows x, `norm` (an nn.LayerNorm) folded in: part = the row statistics of x (run_stats of whoever wrote x)."""
         dt = E.precision()
         prep = self._cached(("ln_fold", id(norm)), lambda: E.LinearLN(self.weights.detach().t().contiguous(), self.biases.detach() if self.biases is not None else None,
                                                                       norm.gamma, norm.beta, dt), deps=(norm,))
-        return E.linear_ln(x, prep, rowab, act)
+        return E.linear_ln(x, prep, part, norm.epsilon, act)
 
     def forward(self, x):
         y = self.run(x)

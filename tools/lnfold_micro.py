@@ -37,30 +37,25 @@ for (M, K, D, N2, act) in [(25216, 768, 768, 2304, E.ACT_NONE), (25216, 3072, 76
     prep = E.LinearLN(w2, b2, g, be, torch.float16)
     with E.shared_plan("half"):
         y, part = E.linear_stats(x, pk, b, res=r)
-        rowab = E.ln_finalize(part, D, 1e-6)
-        z = E.linear_ln(y, prep, rowab, act)
+        z = E.linear_ln(y, prep, part, 1e-6, act)
         yref = x.float() @ w.t() + b + r.float()
         e_y = (y.float() - yref).abs().max().item()
-        sl = yref.view(M, D // 32, 32)
+        sl = yref.view(M, D // 256, 256)
         e_s = (part[..., 0] - sl.sum(-1).t()).abs().max().item()
         e_q = (part[..., 1] - (sl * sl).sum(-1).t()).abs().max().item()
         yf = y.float()
-        rstd = 1 / torch.sqrt(yf.var(1, unbiased=False) + 1e-6)
-        e_a = (rowab[:, 0] - rstd).abs().max().item()
-        e_b = (rowab[:, 1] + yf.mean(1) * rstd).abs().max().item()
         zref = torch.nn.functional.layer_norm(yf, (D,), g, be, 1e-6) @ w2.t() + b2
         if act == E.ACT_GELU:
             zref = torch.nn.functional.gelu(zref)
         e_z = (z.float() - zref).abs().max().item()
-        print(f"M={M} K={K} D={D} N2={N2}: err y {e_y:.2e}  sum {e_s:.2e}  sumsq {e_q:.2e}  rstd {e_a:.2e}  b {e_b:.2e}  consumer {e_z:.2e}", flush=True)
+        print(f"M={M} K={K} D={D} N2={N2}: err y {e_y:.2e}  sum {e_s:.2e}  sumsq {e_q:.2e}  consumer {e_z:.2e}", flush=True)
         ln = lambda: E.layernorm(y, g, be, 1e-6)
         yn = ln()
         t = {
             "linear+res": timed(lambda: E.linear(x, pk, b, res=r)),
             "linear_stats+res": timed(lambda: E.linear_stats(x, pk, b, res=r)),
-            "ln_finalize": timed(lambda: E.ln_finalize(part, D, 1e-6)),
             "layernorm": timed(ln),
             "linear (consumer shape)": timed(lambda: E.linear(yn, pk2, b2, act=act)),
-            "linear_ln": timed(lambda: E.linear_ln(y, prep, rowab, act)),
+            "linear_ln": timed(lambda: E.linear_ln(y, prep, part, 1e-6, act)),
         }
         print("   " + "   ".join(f"{k} {v:.1f} us" for k, v in t.items()), flush=True)
