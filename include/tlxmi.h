@@ -411,17 +411,19 @@ int tlxmi_mlp_seam(int dtype, int64_t rows, int K, int hidden, int N, const void
  * norm2 -> mlp.fc1; swin_transformer.py:310-337).  The Linear that PRODUCES the residual stream (proj, fc2, the patch embedding)
  * also emits the row statistics of its output, the Linear that CONSUMES a LayerNorm applies it in its epilogue; the normalised
  * activations are never written or read:
- *   tlxmi_linear_stats   y[m][n] = sum_k x[m][k] W[n][k] + bias[n] (+ res[m][n]);  partials[p][m] = (sum, sum of squares) of
- *                        y[m][256 p .. 256 p + 255] (the fp32 values before rounding) — ceil(Cout / 256) * rows * 2 floats, 16-byte aligned
- *   tlxmi_linear_ln      per row m: mean = sum_p partials[p][m][0] / K, var = sum_p partials[p][m][1] / K - mean^2 (biased, as
+ *   tlxmi_linear_stats   y[m][n] = sum_k x[m][k] W[n][k] + bias[n] (+ res[m][n]);  partials[m][p] = (sum, sum of squares) of
+ *                        y[m][256 p .. 256 p + 255] (the fp32 values before rounding) for p < ceil(Cout / 256) <= 4 — `partials` is
+ *                        rows x 4 x 2 floats (32 bytes a row, 16-byte aligned); pairs past ceil(Cout / 256) are not written
+ *   tlxmi_linear_ln      per row m: mean = sum_p partials[m][p][0] / K, var = sum_p partials[m][p][1] / K - mean^2 (biased, as
  *                        nn.LayerNorm), rstd = 1 / sqrt(var + eps);  y[m][n] = act(rstd * sum_k x[m][k] Wg[n][k] - mean * rstd * c1[n]
  *                        + c2[n]) on the RAW rows x, with Wg = W * gamma packed by tlxmi_pack_filter (1 x 1), c1[n] = sum_k Wg[n][k]
  *                        (of the fp16 values as packed), c2[n] = bias[n] + sum_k W[n][k] * beta[k];  act: TLXMI_ACT_NONE or
- *                        TLXMI_ACT_GELU;  `partials`: the ceil(K / 256) <= 4 planes a tlxmi_linear_stats launch with Cout = K left for
- *                        these rows — no launch in between
+ *                        TLXMI_ACT_GELU;  `partials`: what a tlxmi_linear_stats launch with Cout = K left for these rows (its first
+ *                        ceil(K / 256) pairs of a row are read) — no launch in between
  * Both run on the 256 x 256 GEMM kernels (the persistent one; a residual with K < 704 and launches of few tiles on its
  * one-tile-per-workgroup form): fp16, Cout % 32 == 0, Cout >= 256, K >= 128, K <= 1024 for the consumer;
- * tlxmi_linear_ln_supported(dtype, rows, K, Cout, act, with_res) answers 1 when the shape is taken, otherwise the calls return
+ * tlxmi_linear_ln_supported(dtype, rows, K, Cout, act, with_res) — with_res 0: the consumer, 1: a producer with a residual, 2: a producer
+ * without (a producer's Cout, the consumer's K <= 1024: the LayerNorm's width) — answers 1 when the shape is taken, otherwise the calls return
  * TLXMI_ERR_UNSUPPORTED and the caller keeps tlxmi_layernorm + tlxmi_conv2d.  `flags`: TLXMI_PLAN_SHARED_* or 0.
  * ---------------------------------------------------------------------------------------- */
 int tlxmi_linear_ln_supported(int dtype, int64_t rows, int K, int Cout, int act, int with_res);

@@ -121,7 +121,7 @@ def test_round5_entry_points_reject_bad_arguments_without_a_gpu():
     assert lib.tlxmi_linear_stats(F16, 4096, 768, 768, 760, 768, p, q, None, None, 0, r, t, 0, None) == -1 and b"extent" in err()
     assert lib.tlxmi_linear_stats(F16, 4096, 768, 100, 768, 104, p, q, None, None, 0, r, t, 0, None) == -2 and b"outside" in err()
     assert lib.tlxmi_linear_stats(F16, 4096, 768, 768, 768, 768, p, q, None, None, 0, r, None, 0, None) == -1 and b"partials" in err()
-    assert lib.tlxmi_linear_stats(F16, 4096, 768, 768, 768, 768, p, q, None, None, 0, r, odd4, 0, None) == -1 and b"partials" in err()
+    assert lib.tlxmi_linear_stats(F16, 4096, 768, 768, 768, 768, p, q, None, None, 0, r, odd8, 0, None) == -1 and b"partials" in err()
     assert lib.tlxmi_linear_stats(F16, 4096, 768, 768, 768, 768, p, q, None, t, 760, r, t, 0, None) == -1 and b"residual" in err()
     assert lib.tlxmi_linear_stats(F16, 4096, 768, 768, 768, 768, p, odd8, None, None, 0, r, t, 0, None) == -3
     # linear_ln(dtype, rows, K, Cout, x_ld, y_ld, x, w, c1, c2, partials, eps, act, y, flags, stream)
@@ -132,6 +132,8 @@ def test_round5_entry_points_reject_bad_arguments_without_a_gpu():
     assert lib.tlxmi_linear_ln(F32, 4096, 768, 2304, 768, 2304, p, q, r, r, r, 1e-5, GELU, t, 0, None) == -2
     assert lib.tlxmi_linear_ln(F16, 4096, 1536, 4608, 1536, 4608, p, q, r, r, r, 1e-5, NONE, t, 0, None) == -2 and b"planes" in err()
     assert lib.tlxmi_linear_ln_supported(F16, 50432, 1536, 4608, NONE, 0) == 0 and lib.tlxmi_linear_ln_supported(F16, 50432, 3072, 768, NONE, 1) == 1
+    assert lib.tlxmi_linear_ln_supported(F16, 3136, 2048, 1024, NONE, 2) == 1 and lib.tlxmi_linear_ln_supported(F16, 3136, 2048, 1536, NONE, 2) == 0      # producers: Cout <= 1024
+    assert lib.tlxmi_linear_stats(F16, 4096, 768, 1536, 768, 1536, p, q, None, None, 0, r, t, 0, None) == -2 and b"4 pairs" in err()
     assert lib.tlxmi_linear_ln_supported(F16, 50432, 768, 2304, GELU, 0) == 1 and lib.tlxmi_linear_ln_supported(F32, 50432, 768, 2304, NONE, 0) == 0
     assert lib.tlxmi_linear_ln_supported(F16, 50432, 768, 2304, RELU, 0) == 0 and lib.tlxmi_linear_ln_supported(F16, 50432, 768, 100, NONE, 0) == 0
     # mlp_seam(dtype, rows, K, hidden, N, x, x_ld, w1, b1, w2, b2, res, res_ld, out, out_ld, stream)

@@ -389,7 +389,8 @@ def test_swin_blocks_without_layernorm_or_window_passes(dev, fp16_mode, shift):
     # statistics of the input from a producer: an identity-free way is a Linear with stats; here the stand-alone pass + a dummy producer
     # would hide bugs, so the input goes through PatchMerging-like statistics by hand: sums over the 256-channel tile columns
     xf = xd.float().view(B * H * W, C // 256, 256)
-    part = torch.stack([xf.sum(-1), (xf * xf).sum(-1)], -1).permute(1, 0, 2).contiguous()       # (C / 256, rows, 2)
+    part = torch.zeros((B * H * W, 4, 2), device=dev)
+    part[:, :C // 256] = torch.stack([xf.sum(-1), (xf * xf).sum(-1)], -1)                       # (rows, 4, 2), C / 256 pairs valid
     x = xd.clone()
     part = blks[0].run_folded(x, part)
     assert blks[1].run_folded(x, part, stats=False) is None

@@ -1181,8 +1181,8 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, int splits,
 // LayerNorm folded AROUND the Linear layers of a transformer block (vision_transformer.py:144-175 norm1 -> attn.qkv, norm2 -> mlp.fc1;
 // swin_transformer.py:310-337), fp16, on the persistent 256 x 256 GEMM kernel (gemm_stream.hip):
 //   producer  tlxmi_linear_stats: y = x W^T + bias (+ res), and from the same epilogue per row (sum y, sum y^2) over every 256-channel
-//             tile column -> partials[ceil(Cout / 256)][rows][2] (the LayerNorm that follows needs no pass over y);
-//   consumer  tlxmi_linear_ln: mean / rstd of each row from the ceil(K / 256) <= 4 planes of the producer (no launch in between), then
+//             tile column -> partials[rows][4][2], pair p < ceil(Cout / 256) written (the LayerNorm that follows needs no pass over y);
+//   consumer  tlxmi_linear_ln: mean / rstd of each row from the ceil(K / 256) <= 4 pairs the producer left (no launch in between), then
 //             y = act(rstd * (x W'^T) - mean * rstd * c1[n] + c2[n]) on the RAW rows x, with the caller's W' = W * gamma (packed),
 //             c1[n] = sum_k W'[n][k] (of the values as packed), c2[n] = bias[n] + sum_k W[n][k] * beta[k].
 // The normalised activations are never written or read.  Shapes / options the persistent kernel does not take return
@@ -1237,8 +1237,9 @@ extern "C" int tlxmi_linear_ln_supported(int dtype, int64_t rows, int K, int Cou
     if (dtype != TLXMI_F16 || rows <= 0 || rows >= (1ll << 27) || K <= 0 || Cout < 256 || Cout % 32 || (K * 2) % 16) return 0;
     const int ktiles = (K * 2 / 16 + 7) / 8;
     if (ktiles < 2) return 0;      // (a residual with fewer than 11 K tiles runs on the one-tile-per-workgroup kernel, gemm_pp.hip LNF)
+    // with_res: 0 = the consumer (tlxmi_linear_ln), 1 = a producer with a residual, 2 = a producer without (tlxmi_linear_stats)
     if (act != TLXMI_ACT_NONE && !(act == TLXMI_ACT_GELU && !with_res)) return 0;
-    if (!with_res && K > 1024) return 0;      // the consumer holds the statistics of a row as ceil(K / 256) <= 4 planes
+    if (with_res ? Cout > 1024 : K > 1024) return 0;      // the statistics of a row are 4 pairs, one per 256 channels of the LayerNorm's width
     return 1;
 }
 
@@ -1247,9 +1248,10 @@ extern "C" int tlxmi_linear_stats(int dtype, int64_t rows, int K, int Cout, int 
     using namespace tlxmi;
     Gemm256Args g;
     if (int rc = fill_ln_gemm(g, "linear_stats", dtype, rows, K, Cout, x_ld, y_ld, x, w_packed, y)) return rc;
-    TLXMI_REQUIRE(partials && ((uintptr_t)partials & 7) == 0, TLXMI_ERR_BAD_ARG, "linear_stats: partials must be an 8-byte aligned buffer");
+    TLXMI_REQUIRE(partials && ((uintptr_t)partials & 15) == 0, TLXMI_ERR_BAD_ARG, "linear_stats: partials must be a 16-byte aligned buffer");
     TLXMI_REQUIRE(!res || (res_ld >= Cout && (res_ld * 2) % 16 == 0 && aligned16(res)), TLXMI_ERR_BAD_ARG, "linear_stats: bad residual");
-    if ((long long)((Cout + 255) / 256) * rows * 8 >= (1ll << 31)) return fail(TLXMI_ERR_UNSUPPORTED, "linear_stats: partial sums exceed 2 GiB");
+    if (Cout > 1024) return fail(TLXMI_ERR_UNSUPPORTED, "linear_stats: %d output channels (a row's statistics are 4 pairs, one per 256 channels)", Cout);
+    if (rows * 32 >= (1ll << 31)) return fail(TLXMI_ERR_UNSUPPORTED, "linear_stats: statistics exceed 2 GiB");
     g.shift = bias;
     g.res = (const char*)res;
     g.res_ld = res ? res_ld : 0;

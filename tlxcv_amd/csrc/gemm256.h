@@ -12,9 +12,9 @@ struct Gemm256Args {
     const float* shift;
     const char* res;
     // LayerNorm folded around the Linear layers (gemm_stream.hip only; fp16):
-    //   stats_out [ceil(Cout / 256)][M][2]: per row (sum y, sum y^2) over each 256-channel tile column of the outputs this launch stores —
-    //             the PRODUCER side: the next LayerNorm's statistics without a pass over y;
-    //   rowstats  such planes of the rows this launch READS (ln_planes of them, <= 4; ln_inv_c = 1 / row width, ln_eps): the CONSUMER of a
+    //   stats_out [M][4][2]: per row (sum y, sum y^2) over each 256-channel tile column of the outputs this launch stores (pairs past
+    //             ceil(Cout / 256) are not written) — the PRODUCER side: the next LayerNorm's statistics without a pass over y;
+    //   rowstats  such rows of pairs for the rows this launch READS (ln_planes of them valid, <= 4; ln_inv_c = 1 / row width, ln_eps): the CONSUMER of a
     //             LayerNorm whose gamma is folded into the packed filter forms (a, b) = (rstd, -mean * rstd) per row from them and stores
     //             y = act(a * acc + b * scale[n] + shift[n])  (scale = c1[n] = sum_k W'[n][k], shift = c2[n] = bias + W beta).
     const float* rowstats = nullptr;

@@ -402,7 +402,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
 #pragma unroll
                                 for (int p = 0; p < 4; ++p)
                                     if (p < a.ln_planes) {
-                                        const f32x2 pl = *reinterpret_cast<const f32x2*>(a.rowstats + 2 * ((size_t)p * a.M + m));
+                                        const f32x2 pl = *reinterpret_cast<const f32x2*>(a.rowstats + 2 * ((size_t)m * 4 + p));
                                         sm += pl[0];
                                         sq += pl[1];
                                     }
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
         if constexpr (LNF) {
             if (a.stats_out) {
                 // the four wc waves of a row half -> LDS (the K tiles are dead: every wave is past its last fragment read and its DMAs),
-                // added in a fixed order, stored by wave wc == 0 as plane bn0 / 256 of a.stats_out: [ceil(Cout / 256)][M][2]
+                // added in a fixed order, stored by wave wc == 0 as pair bn0 / 256 of the row: a.stats_out [M][4][2]
                 f32x2* scr = reinterpret_cast<f32x2*>(smem);
                 __builtin_amdgcn_s_barrier();
 #pragma unroll
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const Gemm256Args a) {
                         const f32x2 p0 = q[0], p1 = q[64], p2 = q[128], p3 = q[192];
                         const int m = bm0 + 128 * h + 64 * wr + lane;
                         if (m < a.M)
-                            *reinterpret_cast<f32x2*>(a.stats_out + 2 * ((size_t)(bn0 >> 8) * a.M + m)) =
+                            *reinterpret_cast<f32x2*>(a.stats_out + 2 * ((size_t)m * 4 + (bn0 >> 8))) =
                                 f32x2{(p0[0] + p1[0]) + (p2[0] + p3[0]), (p0[1] + p1[1]) + (p2[1] + p3[1])};
                     }
                 }

@@ -98,16 +98,16 @@ template <int N> __device__ __forceinline__ void gs_vmcnt() {
 // ACT: TLXMI_ACT_NONE / RELU / GELU (other activations, and exact-erf GELU in fp32, stay on gemm_pp.hip).
 // RES: a.res is added (before the activation; a.scale must be null) — needs >= 11 K tiles.
 // ROWAFF: the CONSUMER of a folded LayerNorm — y = act(a[m] * acc + b[m] * c1[n] + c2[n]) with c1 = a.scale, c2 = a.shift and the
-//   per-row (a, b) = (rstd, -mean * rstd) formed in the kernel from the producer's planes a.rowstats[p][m] = (sum, sum^2) of row m
-//   over 256 channels, p < a.ln_planes <= 4: ONE more table piece per tile and wave (4 planes x 32 rows x 8 B on the 64 lanes; a plane
-//   that does not exist is out of range and arrives as zeros), added up and inverted once per tile by rowab_convert.
+//   per-row (a, b) = (rstd, -mean * rstd) formed in the kernel from the producer's a.rowstats[m][p] = (sum, sum^2) of row m over its
+//   p-th 256 channels, p < a.ln_planes <= 4 (32 bytes a row): ONE more table piece per tile and wave (32 rows = one contiguous
+//   kilobyte on the 64 lanes), added up and inverted once per tile by rowab_convert.
 // STATS: the PRODUCER — every quadrant epilogue also adds up its 8 channels x 4 rows per lane (sum, sum of squares of the fp32
 //   values before the rounding) and reduces the four lanes of a row with three lane-swap steps per four quantities: lane l then
 //   holds (sum, sum^2) of row 128 H + 64 wr + l over the wave's 32 channels of column half G.  The two column halves of a row
 //   half H go into an LDS scratch [H][G][wr][wc][64] (a tile's epilogues run in the order E00, E01, E11, E10), and one epilogue
 //   after the second of them — at least one barrier later — the eight pairs (2 column halves x 4 wc waves) of a row are added up
 //   and wave wc == 0 stores (sum, sum^2) of the row over the tile's 256 channels
-//   at a.stats_out[bn0 / 256][m]: E11 carries half 0 of its own tile, E00 half 1 of the tile before (the last tile's at the end
+//   at a.stats_out[m][bn0 / 256] (rows of 4 pairs, 32 bytes): E11 carries half 0 of its own tile, E00 half 1 of the tile before (the last tile's at the end
 //   of the kernel).  Every phase of the last K tile still issues exactly ONE more store (S + 1 in every counted wait): E01 / E10
 //   send a dummy out of range, for E00 / E11 it is the stage-2 store, issued by the load segment of their phase.  No atomics, one writer per (plane, row), a fixed order of additions: bit-reproducible.
 // (the ablation branches of the tuning flavour exist in the plain variants only: with them the LayerNorm-fold variants spill — 880 bytes
@@ -157,8 +157,8 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
     const __amdgpu_buffer_rsrc_t rsrd = gs_srd(a.res ? a.res : a.y, a.res ? a.res_bytes : 0u);
     const __amdgpu_buffer_rsrc_t hsrd = gs_srd(a.shift, a.shift ? (unsigned)a.Cout * 4u : 0u);   // null: zero fill
     const __amdgpu_buffer_rsrc_t ssrd = a.scale ? gs_srd(a.scale, (unsigned)a.Cout * 4u) : gs_srd(g_ones4, 16u);
-    const __amdgpu_buffer_rsrc_t rowsrd = gs_srd(a.rowstats, (ROWAFF && a.rowstats) ? (unsigned)a.ln_planes * (unsigned)a.M * 8u : 0u);   // null: zero fill
-    const __amdgpu_buffer_rsrc_t stsrd = gs_srd(a.stats_out, (STATS && a.stats_out) ? (unsigned)((a.Cout + 255) >> 8) * (unsigned)a.M * 8u : 0u);   // null: dropped
+    const __amdgpu_buffer_rsrc_t rowsrd = gs_srd(a.rowstats, (ROWAFF && a.rowstats) ? (unsigned)a.M * 32u : 0u);   // [M][4 planes][2]; null: zero fill
+    const __amdgpu_buffer_rsrc_t stsrd = gs_srd(a.stats_out, (STATS && a.stats_out) ? (unsigned)a.M * 32u : 0u);   // [M][4 planes][2]; null: dropped
 
     // ---- loader (gemm_pp.hip): piece = 8 rows x 128 B; wave w fills pieces w, w+8 of a half tile
     const int lrow = lane >> 3;
@@ -206,14 +206,9 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
             gs_dma16(hsrd, dst, off);
             gs_dma16(ssrd, dst + 128, a.scale ? off : 0);
         }
-        // ROWAFF: the statistics planes of rows 32w .. 32w+31 of the tile in ONE piece per wave — lane group p = lane / 16 brings plane p,
-        // two rows per lane, to [wave][plane][32 rows x 8 B] (rows past M, planes past ln_planes: zero fill).  (Measured, tools/lnfold_micro.py:
-        // one plane only 132.8 us for ViT-B/16's qkv, four planes as four 16-lane pieces 137.4, as this one piece 138.7 with the
-        // conversion — it is the plane LINES that cost, three more places in memory in front of an in-order stream, not the operations.)
-        if constexpr (ROWAFF) {
-            const int p = lane >> 4;
-            gs_dma16(rowsrd, smem + ROWTAB + (i & 1) * 8192 + wid * 1024, (ok && p < a.ln_planes) ? (p * a.M + bm0 + 32 * wid + 2 * (lane & 15)) * 8 : OOB);
-        }
+        // ROWAFF: the statistics of rows 32w .. 32w+31 of the tile, [row][4 planes][2] = 32 bytes a row, ONE contiguous kilobyte per wave
+        // (rows past M: zero fill; planes past ln_planes were never written and are left out by rowab_convert)
+        if constexpr (ROWAFF) gs_dma16(rowsrd, smem + ROWTAB + (i & 1) * 8192 + wid * 1024, ok ? (bm0 + 32 * wid) * 32 + lane * 16 : OOB);
     };
 
     // ---- fragment reads (gemm_pp.hip)
@@ -253,31 +248,30 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
     f32x2 rab[4];
     auto rowab_fetch = [&](int h, int tpar) {
         if constexpr (ROWAFF) {
-            // row r of the tile lives at (r / 32) * 1024 + (r % 32) * 8 (rowab_convert): rows 128 h + 64 wr + 16 pi + px -> offsets 0, 128, 1024, 1152
+            // row r of the tile lives at (r / 32) * 1024 + (r % 32) * 32 (rowab_convert): rows 128 h + 64 wr + 16 pi + px -> offsets 0, 512, 1024, 1536
             const int ln = lane_now();
-            const unsigned la = (unsigned)(uintptr_t)(lds_ptr_gs_t)(smem + ROWTAB + tpar * 8192 + (4 * h + 2 * wr) * 1024 + (ln & 15) * 8);
-            asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:128\n\tds_read_b64 %2, %4 offset:1024\n\tds_read_b64 %3, %4 offset:1152\n\t"
+            const unsigned la = (unsigned)(uintptr_t)(lds_ptr_gs_t)(smem + ROWTAB + tpar * 8192 + (4 * h + 2 * wr) * 1024 + (ln & 15) * 32);
+            asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:512\n\tds_read_b64 %2, %4 offset:1024\n\tds_read_b64 %3, %4 offset:1536\n\t"
                          "s_waitcnt lgkmcnt(0)"
                          : "=&v"(rab[0]), "=&v"(rab[1]), "=&v"(rab[2]), "=&v"(rab[3])
                          : "v"(la)
                          : "memory");
         }
     };
-    // ROWAFF: the statistics planes of a tile -> its (a, b) table, in place over plane 0.  Wave w converts the 32 rows it brought itself
-    // (dma_table: complete since the p3 wait of the tile's first K tile), one row per lane of its lower half, in the load segment of p0 of
-    // the LAST K tile; the barrier of that phase stands between this write and the reads of rowab_fetch (p1, p3) by the other waves.
+    // ROWAFF: the statistics of a tile's rows -> its (a, b) table, in place over each row's first pair.  Wave w converts the 32 rows it
+    // brought itself (dma_table: complete since the p3 wait of the tile's first K tile), one row per lane of its lower half, in the load
+    // segment of p0 of the LAST K tile; the barrier of that phase stands between this write and the reads of rowab_fetch (p1, p3) by the
+    // other waves.
     auto rowab_convert = [&](int tpar) {
         if constexpr (ROWAFF) {
             const int ln = lane_now();
             if (ln < 32) {
-                const unsigned la = (unsigned)(uintptr_t)(lds_ptr_gs_t)(smem + ROWTAB + tpar * 8192 + wid * 1024 + ln * 8);
-                f32x2 t0, t1, t2, t3;
-                asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:256\n\tds_read_b64 %2, %4 offset:512\n\tds_read_b64 %3, %4 offset:768\n\t"
-                             "s_waitcnt lgkmcnt(0)"
-                             : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
-                             : "v"(la)
-                             : "memory");
-                const float sm = (t0[0] + t1[0]) + (t2[0] + t3[0]), sq = (t0[1] + t1[1]) + (t2[1] + t3[1]);
+                const unsigned la = (unsigned)(uintptr_t)(lds_ptr_gs_t)(smem + ROWTAB + tpar * 8192 + wid * 1024 + ln * 32);
+                f32x4 t01, t23;
+                asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)" : "=&v"(t01), "=&v"(t23) : "v"(la) : "memory");
+                const int np = a.ln_planes;
+                const float sm = (t01[0] + (np > 1 ? t01[2] : 0.f)) + ((np > 2 ? t23[0] : 0.f) + (np > 3 ? t23[2] : 0.f));
+                const float sq = (t01[1] + (np > 1 ? t01[3] : 0.f)) + ((np > 2 ? t23[1] : 0.f) + (np > 3 ? t23[3] : 0.f));
                 const float mean = sm * a.ln_inv_c;
                 const float var = fmaxf(__builtin_fmaf(-mean, mean, sq * a.ln_inv_c), 0.f);
                 const float rstd = 1.f / sqrtf(var + a.ln_eps);
@@ -311,7 +305,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const Gemm256Args a) {
             const float q4 = ((p0[1] + p1[1]) + (p2[1] + p3[1])) + ((p4[1] + p5[1]) + (p6[1] + p7[1]));
             const int m = sbm + 128 * hp + 64 * wr + ln;
             const int okm = (pend && wc == 0) ? ((m - a.M) >> 31) : 0;
-            const int so = ((((sbn >> 8) * a.M + m) * 8) & okm) | (OOB & ~okm);
+            const int so = (((m * 4 + (sbn >> 8)) * 8) & okm) | (OOB & ~okm);
             __builtin_amdgcn_raw_buffer_store_b64(u32x2{__builtin_bit_cast(unsigned, s4), __builtin_bit_cast(unsigned, q4)}, stsrd, so, 0, 0);
         }
     };

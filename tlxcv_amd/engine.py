@@ -806,7 +806,7 @@ def mlp_seam(x, pk1, b1, pk2, b2, res, out=None):
     return y
 
 
-def linear_ln_supported(rows, K, Cout, dtype, act=ACT_NONE, with_res=False):
+def linear_ln_supported(rows, K, Cout, dtype, act=ACT_NONE, with_res=False, producer=False):
     """Whether a Linear of this shape takes the folded-LayerNorm path (tlxmi_linear_stats with_res / tlxmi_linear_ln): fp16 on the
     persistent 256 x 256 GEMM kernel, rows enough to fill it (below ~2 k rows the tiled kernels of the dispatcher win)."""
     # tools/batch_table.py (round 5): inside a two-stream forward the other half's launches fill what a persistent GEMM with few tiles
@@ -815,7 +815,7 @@ def linear_ln_supported(rows, K, Cout, dtype, act=ACT_NONE, with_res=False):
     min_rows = _options["lnfold_min_rows"] if in_halves() else max(_options["lnfold_min_rows"], _options["lnfold_min_rows_one_stream"])
     if not _options["lnfold"] or dtype != torch.float16 or rows < min_rows:
         return False
-    return bool(_lib.load().tlxmi_linear_ln_supported(F16, int(rows), int(K), int(Cout), int(act), 1 if with_res else 0))
+    return bool(_lib.load().tlxmi_linear_ln_supported(F16, int(rows), int(K), int(Cout), int(act), 1 if with_res else 2 if producer else 0))
 
 
 class LinearLN:
@@ -840,8 +840,8 @@ def _probe_pair():
 
 def linear_stats(x, pk, bias=None, res=None, out=None):
     """y = x W^T + bias (+ res) as linear(), plus per row (sum, sum of squares) of y over every 256-channel tile column from the same
-    epilogue: returns (y, partials (ceil(Cout / 256), rows, 2) fp32) — the statistics of the LayerNorm that follows, without a pass
-    over y; linear_ln takes them as they are."""
+    epilogue: returns (y, partials (rows, 4, 2) fp32, pair p < ceil(Cout / 256) written) — the statistics of the LayerNorm that follows,
+    without a pass over y; linear_ln takes them as they are."""
     need_gpu(x, "input")
     shp = x.shape
     if not x.is_contiguous():
@@ -853,7 +853,7 @@ def linear_stats(x, pk, bias=None, res=None, out=None):
     if res is not None and (not res.is_contiguous() or res.dtype != x.dtype):
         raise RuntimeError("linear_stats: the residual must be a dense tensor of the input's dtype")
     y = out if out is not None else torch.empty((*shp[:-1], pk.Cout), dtype=x.dtype, device=x.device)
-    part = torch.empty(((pk.Cout + 255) // 256, rows, 2), dtype=torch.float32, device=x.device)
+    part = torch.empty((rows, 4, 2), dtype=torch.float32, device=x.device)      # pair p < ceil(Cout / 256) written
     if _probe is not None:
         e0, e1 = _probe_pair()
     _lib.call("tlxmi_linear_stats", dt_code(x.dtype), rows, K, pk.Cout, K, pk.Cout, _p(x), _p(pk.buf), _p(bias), _p(res),
@@ -867,15 +867,15 @@ def linear_stats(x, pk, bias=None, res=None, out=None):
 
 
 def linear_ln(x, prep, part, eps, act=ACT_NONE):
-    """act(Linear(LayerNorm(x))) on the RAW rows x (..., K): `part` = the (ceil(K / 256), rows, 2) planes of (sum, sum of squares) the
-    linear_stats launch that wrote x left; mean / rstd of a row are formed inside the GEMM and applied in its epilogue."""
+    """act(Linear(LayerNorm(x))) on the RAW rows x (..., K): `part` = the (rows, 4, 2) pairs of (sum, sum of squares) the linear_stats
+    launch that wrote x left (the first ceil(K / 256) of a row are read); mean / rstd of a row are formed inside the GEMM and applied in its epilogue."""
     need_gpu(x, "input")
     shp = x.shape
     if not x.is_contiguous():
         x = x.contiguous()
     rows = x.numel() // shp[-1]
-    if tuple(part.shape) != ((prep.K + 255) // 256, rows, 2) or part.dtype != torch.float32 or not part.is_contiguous():
-        raise RuntimeError(f"linear_ln: statistics of shape {tuple(part.shape)} for {rows} rows of {prep.K} channels (expected {((prep.K + 255) // 256, rows, 2)} fp32)")
+    if tuple(part.shape) != (rows, 4, 2) or part.dtype != torch.float32 or not part.is_contiguous():
+        raise RuntimeError(f"linear_ln: statistics of shape {tuple(part.shape)} for {rows} rows (expected {(rows, 4, 2)} fp32)")
     y = torch.empty((*shp[:-1], prep.Cout), dtype=x.dtype, device=x.device)
     if _probe is not None:
         e0, e1 = _probe_pair()

@@ -259,7 +259,7 @@ class PatchMerging(nn.Module):
         assert H % 2 == 0 and W % 2 == 0, 'x size ({}*{}) are not even.'.format(H, W)
         if isinstance(self.norm, nn.LayerNorm):      # gather + concat + norm in one pass (:381-388)
             g = E.patch_merge_layernorm(x.view(B, H, W, C), self.norm.gamma.detach(), self.norm.beta.detach(), self.norm.epsilon)
-            if stats and E.linear_ln_supported(B * L // 4, 4 * C, self.reduction.out_features, g.dtype):
+            if stats and E.linear_ln_supported(B * L // 4, 4 * C, self.reduction.out_features, g.dtype, producer=True):
                 return self.reduction.run_stats(g)                                 # + the row statistics for the next stage's first norm1
             return self.reduction.run(g)                                           # :389
         g = E.patch_merge_gather(x.view(B, H, W, C)).view(B, H * W // 4, 4 * C)    # :381-387

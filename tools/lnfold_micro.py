@@ -41,8 +41,8 @@ for (M, K, D, N2, act) in [(25216, 768, 768, 2304, E.ACT_NONE), (25216, 3072, 76
         yref = x.float() @ w.t() + b + r.float()
         e_y = (y.float() - yref).abs().max().item()
         sl = yref.view(M, D // 256, 256)
-        e_s = (part[..., 0] - sl.sum(-1).t()).abs().max().item()
-        e_q = (part[..., 1] - (sl * sl).sum(-1).t()).abs().max().item()
+        e_s = (part[:, :D // 256, 0] - sl.sum(-1)).abs().max().item()
+        e_q = (part[:, :D // 256, 1] - (sl * sl).sum(-1)).abs().max().item()
         yf = y.float()
         zref = torch.nn.functional.layer_norm(yf, (D,), g, be, 1e-6) @ w2.t() + b2
         if act == E.ACT_GELU:
