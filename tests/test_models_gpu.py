@@ -460,3 +460,26 @@ def test_swin_absolute_position_embedding(dev, prec):
         assert np.abs(y - ref).max() <= (1e-4 if prec == "fp32" else 0.004 * span)
     finally:
         tlxcv_amd.set_precision("fp16")
+
+
+@pytest.mark.parametrize("ctor,batch", [("vit_small_patch16_224", 64), ("vit_large_patch16_224", 32), ("swintransformer_tiny_patch4_window7_224", 64),
+                                        ("swintransformer_large_patch4_window7_224", 32)], ids=lambda v: str(v))
+def test_folded_layernorm_on_the_other_widths(dev, fp16_mode, ctor, batch):
+    """The LayerNorm fold on row widths the bench models do not have: 384 (one and a half tile columns: ViT-S, Swin-T stage 3), 1 024 (four
+    statistics pairs a row: ViT-L), 192 / 96 (below `lnfold_min_c`: stay on the passes), 1 536 (Swin-L stage 4: more than four pairs, keeps
+    its LayerNorm) — the folded forward against the same model with LayerNorm launches, inside the two-stream forward both arms take."""
+    from tlxcv_amd import engine as E, models
+    m = getattr(models, ctor)()
+    m.load_dict(seeded.fill(seeded.shapes_of(m), 1))
+    m = m.to(dev).set_eval()
+    x = torch.from_numpy(seeded.image_batch(batch, 0)).to(dev)
+    ys = {}
+    try:
+        for arm in (1, 0):
+            E.set_option("lnfold", arm)
+            ys[arm] = m(x).float()
+    finally:
+        E.set_option("lnfold", 1)
+    span = float(ys[0].max() - ys[0].min())
+    assert float((ys[1] - ys[0]).abs().max()) <= 0.006 * span
+    assert torch.equal(ys[1].argmax(1), ys[0].argmax(1))
